@@ -1,0 +1,439 @@
+"""CPU oracle for the SD2-inpainting UNet forward (test infrastructure).
+
+A *functional* restatement (flat state dict with the reference's key names,
+plain torch fp32 ops, NCHW) of
+
+  UNetModel.__init__/forward   ldm/modules/diffusionmodules/openaimodel.py:442-787
+  ResBlock._forward            openaimodel.py:254-274
+  Upsample / Downsample        openaimodel.py:90-159
+  SpatialTransformer.forward   ldm/modules/attention.py:393-419
+  BasicTransformerBlock        attention.py:279-283
+  CrossAttention.forward       attention.py:165-196  (== xformers path 218-250)
+  GEGLU / FeedForward          attention.py:51-78
+  GroupNorm32 / normalization  ldm/modules/diffusionmodules/util.py:202-219
+  timestep_embedding           util.py:154-174
+  MultiViewBasicTransformerBlock._forward  ldm/modules/multiview_attention.py:431-468
+
+`mode="fp32"` is the exact fp32 restatement (pinned against the imported
+reference by tests/golden).  `mode="autocast16"` additionally rounds to fp16
+at the points where the reference's `torch.autocast("cuda")` region produces
+fp16 tensors; it is only used to size the fp16
+tolerance of the HIP path, never as ground truth.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 9
+    out_channels: int = 4
+    model_channels: int = 320
+    num_res_blocks: int = 2
+    attention_resolutions: Sequence[int] = (4, 2, 1)
+    channel_mult: Sequence[int] = (1, 2, 4, 4)
+    num_head_channels: int = 64
+    context_dim: int = 1024
+    transformer_depth: int = 1
+    use_linear_in_transformer: bool = True
+    # multi-view variant (multiview_unet.py:213-217)
+    multiview: bool = False
+    view_num: int = 4
+    concat_target: bool = False
+    no_rearrange_selfattn: bool = False
+
+    def kwargs(self):
+        """Constructor kwargs for the reference / drop-in UNetModel."""
+        d = dict(image_size=32, in_channels=self.in_channels, out_channels=self.out_channels,
+                 model_channels=self.model_channels, attention_resolutions=list(self.attention_resolutions),
+                 num_res_blocks=self.num_res_blocks, channel_mult=list(self.channel_mult),
+                 num_head_channels=self.num_head_channels, use_spatial_transformer=True,
+                 use_linear_in_transformer=self.use_linear_in_transformer,
+                 transformer_depth=self.transformer_depth, context_dim=self.context_dim,
+                 legacy=False, use_checkpoint=True)
+        if self.multiview:
+            d.update(view_num=self.view_num, concat_target=self.concat_target,
+                     no_rearrange_selfattn=self.no_rearrange_selfattn)
+        return d
+
+
+FULL = UNetConfig()
+# reduced-width model used for whole-network / trajectory goldens
+SMALL = UNetConfig(model_channels=64, num_head_channels=32, context_dim=128)
+
+
+# --------------------------------------------------------------------------------------
+# architecture plan (openaimodel.py:535-731)
+# --------------------------------------------------------------------------------------
+def build_plan(cfg: UNetConfig):
+    """Returns (input_blocks, middle, output_blocks); each block = list of layer tuples.
+
+    layer tuples: ("conv", key, cin, cout) | ("res", key, cin, cout) |
+                  ("st", key, ch, heads, dhead) | ("down", key, ch) | ("up", key, ch)
+    """
+    mc = cfg.model_channels
+    inp = [[("conv", "input_blocks.0.0", cfg.in_channels, mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    nlev = len(cfg.channel_mult)
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            bi = len(inp)
+            layers = [("res", f"input_blocks.{bi}.0", ch, mult * mc)]
+            ch = mult * mc
+            if ds in cfg.attention_resolutions:
+                layers.append(("st", f"input_blocks.{bi}.1", ch, ch // cfg.num_head_channels, cfg.num_head_channels))
+            inp.append(layers)
+            chans.append(ch)
+        if level != nlev - 1:
+            bi = len(inp)
+            inp.append([("down", f"input_blocks.{bi}.0", ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", "middle_block.0", ch, ch),
+           ("st", "middle_block.1", ch, ch // cfg.num_head_channels, cfg.num_head_channels),
+           ("res", "middle_block.2", ch, ch)]
+    out = []
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            bi = len(out)
+            layers = [("res", f"output_blocks.{bi}.0", ch + ich, mc * mult)]
+            ch = mc * mult
+            if ds in cfg.attention_resolutions:
+                layers.append(("st", f"output_blocks.{bi}.{len(layers)}", ch, ch // cfg.num_head_channels,
+                               cfg.num_head_channels))
+            if level and i == cfg.num_res_blocks:
+                layers.append(("up", f"output_blocks.{bi}.{len(layers)}", ch))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out
+
+
+def _res_shapes(key, cin, cout, emb, shapes):
+    shapes[f"{key}.in_layers.0.weight"] = (cin,)
+    shapes[f"{key}.in_layers.0.bias"] = (cin,)
+    shapes[f"{key}.in_layers.2.weight"] = (cout, cin, 3, 3)
+    shapes[f"{key}.in_layers.2.bias"] = (cout,)
+    shapes[f"{key}.emb_layers.1.weight"] = (cout, emb)
+    shapes[f"{key}.emb_layers.1.bias"] = (cout,)
+    shapes[f"{key}.out_layers.0.weight"] = (cout,)
+    shapes[f"{key}.out_layers.0.bias"] = (cout,)
+    shapes[f"{key}.out_layers.3.weight"] = (cout, cout, 3, 3)
+    shapes[f"{key}.out_layers.3.bias"] = (cout,)
+    if cin != cout:
+        shapes[f"{key}.skip_connection.weight"] = (cout, cin, 1, 1)
+        shapes[f"{key}.skip_connection.bias"] = (cout,)
+
+
+def _st_shapes(key, ch, cfg, shapes):
+    lin = cfg.use_linear_in_transformer
+    shapes[f"{key}.norm.weight"] = (ch,)
+    shapes[f"{key}.norm.bias"] = (ch,)
+    shapes[f"{key}.proj_in.weight"] = (ch, ch) if lin else (ch, ch, 1, 1)
+    shapes[f"{key}.proj_in.bias"] = (ch,)
+    for d in range(cfg.transformer_depth):
+        b = f"{key}.transformer_blocks.{d}"
+        for a, cdim in (("attn1", ch), ("attn2", cfg.context_dim)):
+            shapes[f"{b}.{a}.to_q.weight"] = (ch, ch)
+            shapes[f"{b}.{a}.to_k.weight"] = (ch, cdim)
+            shapes[f"{b}.{a}.to_v.weight"] = (ch, cdim)
+            shapes[f"{b}.{a}.to_out.0.weight"] = (ch, ch)
+            shapes[f"{b}.{a}.to_out.0.bias"] = (ch,)
+        shapes[f"{b}.ff.net.0.proj.weight"] = (8 * ch, ch)
+        shapes[f"{b}.ff.net.0.proj.bias"] = (8 * ch,)
+        shapes[f"{b}.ff.net.2.weight"] = (ch, 4 * ch)
+        shapes[f"{b}.ff.net.2.bias"] = (ch,)
+        for n in ("norm1", "norm2", "norm3"):
+            shapes[f"{b}.{n}.weight"] = (ch,)
+            shapes[f"{b}.{n}.bias"] = (ch,)
+    shapes[f"{key}.proj_out.weight"] = (ch, ch) if lin else (ch, ch, 1, 1)
+    shapes[f"{key}.proj_out.bias"] = (ch,)
+
+
+def param_shapes(cfg: UNetConfig):
+    """{state_dict key: shape} with the reference's names (686 tensors for FULL)."""
+    mc = cfg.model_channels
+    emb = 4 * mc
+    shapes = {
+        "time_embed.0.weight": (emb, mc), "time_embed.0.bias": (emb,),
+        "time_embed.2.weight": (emb, emb), "time_embed.2.bias": (emb,),
+    }
+    inp, mid, out = build_plan(cfg)
+    for blk in inp + [mid] + out:
+        for layer in blk:
+            kind, key = layer[0], layer[1]
+            if kind == "conv":
+                shapes[f"{key}.weight"] = (layer[3], layer[2], 3, 3)
+                shapes[f"{key}.bias"] = (layer[3],)
+            elif kind == "res":
+                _res_shapes(key, layer[2], layer[3], emb, shapes)
+            elif kind == "st":
+                _st_shapes(key, layer[2], cfg, shapes)
+            elif kind == "down":
+                shapes[f"{key}.op.weight"] = (layer[2], layer[2], 3, 3)
+                shapes[f"{key}.op.bias"] = (layer[2],)
+            elif kind == "up":
+                shapes[f"{key}.conv.weight"] = (layer[2], layer[2], 3, 3)
+                shapes[f"{key}.conv.bias"] = (layer[2],)
+    shapes["out.0.weight"] = (mc,)
+    shapes["out.0.bias"] = (mc,)
+    shapes["out.2.weight"] = (cfg.out_channels, mc, 3, 3)
+    shapes["out.2.bias"] = (cfg.out_channels,)
+    return shapes
+
+
+# --------------------------------------------------------------------------------------
+# numerics helpers
+# --------------------------------------------------------------------------------------
+class _Mode:
+    def __init__(self, mode):
+        assert mode in ("fp32", "autocast16")
+        self.ac = mode == "autocast16"
+
+    def q(self, x):
+        """Round to fp16 where the reference's autocast region would hold an fp16 tensor."""
+        return x.half().float() if self.ac else x
+
+
+def timestep_embedding(t, dim, max_period=10000):
+    """util.py:154-174 -- cos first, then sin; fp32."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def group_norm(x, w, b, eps, groups=32):
+    return F.group_norm(x, groups, w, b, eps)
+
+
+def attention(q, k, v, heads, m: _Mode):
+    """softmax(q k^T / sqrt(d)) v per head; q [B,Nq,H*d], k/v [B,Nk,H*d]  (attention.py:165-196)."""
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, k.shape[1], heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, v.shape[1], heads, d).permute(0, 2, 1, 3)
+    out = torch.empty_like(qh)
+    scale = d ** -0.5
+    # chunk over queries so the N x N logits never exceed a few hundred MB
+    step = max(1, min(Nq, (1 << 25) // max(1, k.shape[1])))
+    for s in range(0, Nq, step):
+        sim = torch.matmul(qh[:, :, s:s + step], kh.transpose(-1, -2)) * scale
+        p = sim.softmax(dim=-1)
+        p = m.q(p)
+        out[:, :, s:s + step] = torch.matmul(p, vh)
+    return m.q(out.permute(0, 2, 1, 3).reshape(B, Nq, C))
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+# --------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------
+def resblock(sd, key, x, emb, m: _Mode):
+    """openaimodel.py:254-274 (use_scale_shift_norm=False, no up/down)."""
+    h = m.q(F.silu(m.q(group_norm(x, sd[f"{key}.in_layers.0.weight"], sd[f"{key}.in_layers.0.bias"], 1e-5))))
+    h = m.q(F.conv2d(h, sd[f"{key}.in_layers.2.weight"], sd[f"{key}.in_layers.2.bias"], padding=1))
+    e = m.q(F.linear(m.q(F.silu(emb)), sd[f"{key}.emb_layers.1.weight"], sd[f"{key}.emb_layers.1.bias"]))
+    h = m.q(h + e[:, :, None, None])
+    h = m.q(F.silu(m.q(group_norm(h, sd[f"{key}.out_layers.0.weight"], sd[f"{key}.out_layers.0.bias"], 1e-5))))
+    h = m.q(F.conv2d(h, sd[f"{key}.out_layers.3.weight"], sd[f"{key}.out_layers.3.bias"], padding=1))
+    if f"{key}.skip_connection.weight" in sd:
+        x = m.q(F.conv2d(x, sd[f"{key}.skip_connection.weight"], sd[f"{key}.skip_connection.bias"]))
+    return m.q(x + h)
+
+
+def cross_attention(sd, key, x, ctx, heads, m: _Mode):
+    """attention.py:165-196; to_q/k/v without bias, to_out.0 with bias."""
+    q = m.q(F.linear(x, sd[f"{key}.to_q.weight"]))
+    k = m.q(F.linear(ctx, sd[f"{key}.to_k.weight"]))
+    v = m.q(F.linear(ctx, sd[f"{key}.to_v.weight"]))
+    o = attention(q, k, v, heads, m)
+    return m.q(F.linear(o, sd[f"{key}.to_out.0.weight"], sd[f"{key}.to_out.0.bias"]))
+
+
+def feed_forward(sd, key, x, m: _Mode):
+    """attention.py:51-78 -- GEGLU (exact-erf gelu) then Linear."""
+    p = m.q(F.linear(x, sd[f"{key}.net.0.proj.weight"], sd[f"{key}.net.0.proj.bias"]))
+    u, g = p.chunk(2, dim=-1)
+    h = m.q(u * m.q(F.gelu(g)))
+    return m.q(F.linear(h, sd[f"{key}.net.2.weight"], sd[f"{key}.net.2.bias"]))
+
+
+def mv_gather(x, view_num, concat_target, no_rearrange):
+    """multiview_attention.py:436-448: (b v) hw c -> b (V hw') c token re-arrangement."""
+    if concat_target:
+        v = view_num - 1
+        if no_rearrange:
+            return x.reshape(x.shape[0] // v, v * x.shape[1], x.shape[2]), None
+        s = int(math.sqrt(x.shape[1] / 2))
+        xn = x.reshape(x.shape[0] // v, v, s, 2 * s, x.shape[2])
+        seq = torch.cat((xn[:, 0:1, :, s:, :], xn[:, :, :, 0:s, :]), dim=1)  # [target, ref_0..ref_{v-1}]
+        return seq.reshape(seq.shape[0], view_num * s * s, x.shape[2]).contiguous(), (v, s)
+    return x.reshape(x.shape[0] // view_num, view_num * x.shape[1], x.shape[2]), None
+
+
+def mv_scatter(x, view_num, concat_target, no_rearrange, info):
+    """multiview_attention.py:452-462: inverse of mv_gather (target written to every canvas)."""
+    if concat_target:
+        v = view_num - 1
+        if no_rearrange:
+            return x.reshape(x.shape[0] * v, x.shape[1] // v, x.shape[2])
+        v, s = info
+        c = x.shape[2]
+        xs = x.reshape(x.shape[0], view_num, s, s, c)
+        new = torch.zeros(x.shape[0], v, s, 2 * s, c, dtype=x.dtype)
+        new[:, :, :, s:, :] = xs[:, 0:1]
+        new[:, :, :, 0:s, :] = xs[:, 1:]
+        return new.reshape(x.shape[0] * v, 2 * s * s, c)
+    return x.reshape(x.shape[0] * view_num, x.shape[1] // view_num, x.shape[2])
+
+
+def transformer_block(sd, key, x, ctx, heads, m: _Mode, cfg: UNetConfig):
+    """attention.py:279-283; multi-view variant multiview_attention.py:431-468."""
+    if cfg.multiview:
+        x, info = mv_gather(x, cfg.view_num, cfg.concat_target, cfg.no_rearrange_selfattn)
+    n1 = m.q(layer_norm(x, sd[f"{key}.norm1.weight"], sd[f"{key}.norm1.bias"]))
+    x = m.q(cross_attention(sd, f"{key}.attn1", n1, n1, heads, m) + x)
+    if cfg.multiview:
+        x = mv_scatter(x, cfg.view_num, cfg.concat_target, cfg.no_rearrange_selfattn, info)
+    n2 = m.q(layer_norm(x, sd[f"{key}.norm2.weight"], sd[f"{key}.norm2.bias"]))
+    x = m.q(cross_attention(sd, f"{key}.attn2", n2, ctx, heads, m) + x)
+    n3 = m.q(layer_norm(x, sd[f"{key}.norm3.weight"], sd[f"{key}.norm3.bias"]))
+    x = m.q(feed_forward(sd, f"{key}.ff", n3, m) + x)
+    return x
+
+
+def spatial_transformer(sd, key, x, ctx, heads, m: _Mode, cfg: UNetConfig):
+    """attention.py:393-419 (GroupNorm eps 1e-6, no SiLU)."""
+    B, C, H, W = x.shape
+    x_in = x
+    h = m.q(group_norm(x, sd[f"{key}.norm.weight"], sd[f"{key}.norm.bias"], 1e-6))
+    lin = sd[f"{key}.proj_in.weight"].dim() == 2
+    if not lin:
+        h = m.q(F.conv2d(h, sd[f"{key}.proj_in.weight"], sd[f"{key}.proj_in.bias"]))
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    if lin:
+        h = m.q(F.linear(h, sd[f"{key}.proj_in.weight"], sd[f"{key}.proj_in.bias"]))
+    for d in range(cfg.transformer_depth):
+        h = transformer_block(sd, f"{key}.transformer_blocks.{d}", h, ctx, heads, m, cfg)
+    if lin:
+        h = m.q(F.linear(h, sd[f"{key}.proj_out.weight"], sd[f"{key}.proj_out.bias"]))
+    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    if not lin:
+        h = m.q(F.conv2d(h, sd[f"{key}.proj_out.weight"], sd[f"{key}.proj_out.bias"]))
+    return m.q(h + x_in)
+
+
+def run_layer(sd, layer, h, emb, ctx, m: _Mode, cfg: UNetConfig):
+    kind, key = layer[0], layer[1]
+    if kind == "conv":
+        return m.q(F.conv2d(h, sd[f"{key}.weight"], sd[f"{key}.bias"], padding=1))
+    if kind == "res":
+        return resblock(sd, key, h, emb, m)
+    if kind == "st":
+        return spatial_transformer(sd, key, h, ctx, layer[3], m, cfg)
+    if kind == "down":  # openaimodel.py:150-152: conv3x3 stride 2 pad 1
+        return m.q(F.conv2d(h, sd[f"{key}.op.weight"], sd[f"{key}.op.bias"], stride=2, padding=1))
+    if kind == "up":  # openaimodel.py:115-117: nearest x2 then conv3x3
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+        return m.q(F.conv2d(h, sd[f"{key}.conv.weight"], sd[f"{key}.conv.bias"], padding=1))
+    raise ValueError(kind)
+
+
+@torch.no_grad()
+def unet_forward(sd, cfg: UNetConfig, x, timesteps, context, mode="fp32", taps=None):
+    """openaimodel.py:755-787.  x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,ctx] fp32.
+
+    taps: optional dict that receives {"in{i}", "mid", "out{i}"} -> per-block output (for bisecting).
+    """
+    m = _Mode(mode)
+    sd = {k: v.float() for k, v in sd.items()}
+    if m.ac:  # conv / linear weights are cast to fp16 by autocast at use
+        sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
+        context = m.q(context)
+    inp, mid, out = build_plan(cfg)
+    t_emb = timestep_embedding(timesteps, cfg.model_channels)
+    e = m.q(F.linear(m.q(t_emb), sd["time_embed.0.weight"], sd["time_embed.0.bias"]))
+    emb = m.q(F.linear(m.q(F.silu(e)), sd["time_embed.2.weight"], sd["time_embed.2.bias"]))
+    h = m.q(x.float())
+    hs = []
+    for i, blk in enumerate(inp):
+        for layer in blk:
+            h = run_layer(sd, layer, h, emb, context, m, cfg)
+        hs.append(h)
+        if taps is not None:
+            taps[f"in{i}"] = h
+    for layer in mid:
+        h = run_layer(sd, layer, h, emb, context, m, cfg)
+    if taps is not None:
+        taps["mid"] = h
+    for i, blk in enumerate(out):
+        h = torch.cat([h, hs.pop()], dim=1)
+        for layer in blk:
+            h = run_layer(sd, layer, h, emb, context, m, cfg)
+        if taps is not None:
+            taps[f"out{i}"] = h
+    # openaimodel.py:783-787: cast back to x.dtype (fp32) -> GN32 + SiLU in fp32 -> conv (fp16 under autocast)
+    h = F.silu(group_norm(h, sd["out.0.weight"], sd["out.0.bias"], 1e-5))
+    return m.q(F.conv2d(m.q(h), sd["out.2.weight"], sd["out.2.bias"], padding=1))
+
+
+def flops_per_sample(cfg: UNetConfig, H, W, ctx_len=77):
+    """2*MAC of conv / linear / attention matmuls for one batch element."""
+    inp, mid, out = build_plan(cfg)
+    total = 0.0
+    mc = cfg.model_channels
+    emb = 4 * mc
+    total += 2.0 * (mc * emb + emb * emb)
+    h, w = H, W
+
+    def st_flops(ch, hw):
+        f = 0.0
+        f += 2.0 * hw * ch * ch * 2                      # proj_in / proj_out
+        f += 2.0 * hw * ch * ch * 4                      # attn1 q,k,v,out
+        f += 4.0 * hw * hw * ch                          # self-attn QK^T + PV
+        f += 2.0 * hw * ch * ch * 2                      # attn2 q,out
+        f += 2.0 * ctx_len * cfg.context_dim * ch * 2    # attn2 k,v
+        f += 4.0 * hw * ctx_len * ch                     # cross-attn
+        f += 2.0 * hw * ch * 8 * ch + 2.0 * hw * 4 * ch * ch
+        return f * cfg.transformer_depth
+
+    def run(layers):
+        nonlocal total, h, w
+        for layer in layers:
+            kind = layer[0]
+            if kind == "conv":
+                total += 2.0 * h * w * 9 * layer[2] * layer[3]
+            elif kind == "res":
+                cin, cout = layer[2], layer[3]
+                total += 2.0 * h * w * 9 * (cin * cout + cout * cout) + 2.0 * emb * cout
+                if cin != cout:
+                    total += 2.0 * h * w * cin * cout
+            elif kind == "st":
+                total += st_flops(layer[2], h * w)
+            elif kind == "down":
+                h, w = h // 2, w // 2
+                total += 2.0 * h * w * 9 * layer[2] * layer[2]
+            elif kind == "up":
+                h, w = h * 2, w * 2
+                total += 2.0 * h * w * 9 * layer[2] * layer[2]
+
+    for blk in inp:
+        run(blk)
+    run(mid)
+    for blk in out:
+        run(blk)
+    total += 2.0 * h * w * 9 * mc * cfg.out_channels
+    return total

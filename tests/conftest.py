@@ -1,0 +1,29 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    class _G:
+        def __init__(self):
+            self._c = {}
+
+        def __call__(self, fname):
+            if fname not in self._c:
+                self._c[fname] = np.load(os.path.join(GOLDEN, fname + ".npz"))
+            return self._c[fname]
+
+    return _G()
