@@ -1,0 +1,125 @@
+/*
+ * leftrefill_hip.h -- C ABI of the MI355X (gfx950) kernels behind LeftRefill's diffusion-sampling hot path.
+ *
+ * Boundary contract:
+ *   - extern "C", raw device pointers + explicit sizes + a hipStream_t (passed as void*), no torch types;
+ *   - no allocation, no synchronisation, no global mutable state inside; the caller owns every buffer,
+ *     including workspaces; every call is stream-ordered and re-entrant;
+ *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = argument error (LR_E_*).
+ *
+ * Layout convention on the device: activations are NHWC fp16 ("token-major": row m = (n*H + y)*W + x,
+ * channels contiguous), weights are [Cout][tap][Cin] fp16 (K contiguous), statistics and accumulators fp32.
+ *
+ * Each entry point cites the reference call site it replaces (paths relative to the reference repo).
+ */
+#ifndef LEFTREFILL_HIP_H
+#define LEFTREFILL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_E_ARG (-1)      /* bad size / null pointer */
+#define LR_E_ALIGN (-2)    /* channel count / leading dimension not a multiple the kernel needs */
+#define LR_E_UNSUPPORTED (-3)
+
+typedef void* lr_stream_t; /* hipStream_t */
+typedef uint16_t lr_half;  /* IEEE binary16 bits */
+
+/* ABI version; bump on any signature change. */
+int lr_abi_version(void);
+
+/* ---- layout converters at the UNet boundary ------------------------------------------------------------------
+ * replaces: `h = x.type(self.dtype)` + the NCHW<->token-major rearranges, openaimodel.py:775, attention.py:402,412;
+ *           `torch.cat([x] + c_concat, dim=1)` ddpm.py:1349 (optional second source x2).
+ * y[n,h,w,0:C1] = x1[n,:,h,w]; y[...,C1:C1+C2] = x2 (may be NULL with C2 = 0); y[...,C1+C2:Cpad] = 0. */
+int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N, int H,
+                            int W, lr_stream_t s);
+/* out_nchw[n,c,h,w] = y[n,h,w,c] for c < C; out_is_f32 selects float or half output (UNet returns eps). */
+int lr_nhwc_f16_to_nchw(const lr_half* y, int Cstride, int C, void* out_nchw, int out_is_f32, int N, int H, int W,
+                        lr_stream_t s);
+
+/* ---- GroupNorm(32) [+ SiLU] -------------------------------------------------------------------------------------
+ * replaces: GroupNorm32 / normalization (util.py:202-219, eps 1e-5) followed by nn.SiLU in ResBlock.in_layers /
+ *           out_layers / UNetModel.out (openaimodel.py:200-231,726-731) and Normalize (attention.py:90-91, eps 1e-6).
+ * Input is the virtual concat [x1 (C1 ch) | x2 (C2 ch)] (th.cat([h, hs.pop()], 1), openaimodel.py:781); x2 may be NULL.
+ * Two launches: stats writes per-chunk partial (sum, sumsq) to `partials` [N][LR_GN_CHUNKS][32][2] fp32 (deterministic,
+ * no atomics); apply finalises mean/rstd in fp64 from the partials and writes y [N*HW][C1+C2] fp16. */
+#define LR_GN_CHUNKS 16
+int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
+                       lr_stream_t s);
+int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
+                       const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
+
+/* ---- LayerNorm over the channel dimension -------------------------------------------------------------------------
+ * replaces: nn.LayerNorm norm1/2/3 in BasicTransformerBlock (attention.py:271-273, eps 1e-5). x,y [M][C] fp16. */
+int lr_layernorm(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C,
+                 lr_stream_t s);
+
+/* ---- timestep embedding + small-M linear (time MLP) -------------------------------------------------------------
+ * replaces: timestep_embedding (util.py:154-174; cos first), UNetModel.time_embed (openaimodel.py:528-532) and the
+ *           22 ResBlock.emb_layers (217-223) batched as one [sum Cout][1280] weight. */
+int lr_timestep_embedding(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s);
+/* out[m][n] = act_out( sum_k act_in(a[m][k]) * w[n][k] + bias[n] ), M <= 16; act: 0 none, 1 SiLU. K % 8 == 0. */
+int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo, int M,
+                      int N, int K, int act_in, int act_out, lr_stream_t s);
+
+/* ---- implicit-GEMM convolution / linear on MFMA --------------------------------------------------------------------
+ * replaces: conv3x3 s1/s2 (+bias) in ResBlock / Downsample / Upsample / input / output conv (openaimodel.py:106,150,
+ *           200-231,546,730), the 1x1 skip_connection (240), nn.Linear in CrossAttention / SpatialTransformer /
+ *           GEGLU / FeedForward (attention.py:54,74,156-163,359,381); fused epilogues replace `h + emb_out`
+ *           (openaimodel.py:272), `skip(x) + h` (274), the attention/FF residual adds (attention.py:280-282,419) and
+ *           `x * F.gelu(gate)` (attention.py:56-58).
+ *
+ *   C[m][n] = sum_{tap,c} A(m,tap,c) * Wt[n][tap*(C1+C2)+c]  (+ bias[n]) (+ rowvec[m / rows_per_batch][n]) (+ R[m][n])
+ *   rows m = (b*H + y)*W + x over the OUTPUT grid; A gathers from the source grid [Hs][Ws]:
+ *     taps = 1: pointwise (Linear / 1x1);  taps = 9: 3x3 pad 1 with `stride` (1|2) and optional nearest-2x `up`sample.
+ *   Source is the virtual channel concat [p1 (C1) | p2 (C2)];  C1, C2 multiples of 64.
+ *   geglu != 0: Wt/bias rows are pre-interleaved in 16-row groups [u16 | g16 | ...]; output has N/2 columns:
+ *     out = (u + bu) * gelu_erf(g + bg).
+ */
+typedef struct lr_gemm_args {
+  const lr_half* p1; int32_t C1;
+  const lr_half* p2; int32_t C2;
+  int32_t B, H, W;          /* output grid; M = B*H*W */
+  int32_t Hs, Ws;           /* source grid */
+  int32_t taps, stride, up;
+  const lr_half* wt; int32_t N;      /* weights [N][taps*(C1+C2)] */
+  const float* bias;                 /* [N] or NULL */
+  const lr_half* rowvec; int32_t ld_rowvec; /* [B][ld_rowvec] per-sample vector added to every row of sample b, or NULL */
+  const lr_half* resid; int32_t ld_resid;   /* [M][ld_resid] or NULL */
+  lr_half* out; int32_t ld_out;             /* [M][ld_out] */
+  int32_t geglu;
+  int32_t tile_n;           /* 0 = auto; 64 | 128 */
+} lr_gemm_args;
+int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
+
+/* ---- fused scaled-dot-product attention (flash-style, d_head = 64) ---------------------------------------------
+ * replaces: xformers.ops.memory_efficient_attention (attention.py:236) == softmax(q k^T * d^-0.5) v of the vanilla
+ *           path (attention.py:173-195), self (Nkv = HW or view_num*h^2) and cross (Nkv = 77).
+ * q [B][Nq][ldq], k/v [B][Nkv][ldk|ldv], o [B][Nq][ldo]; head h occupies columns [h*64, h*64+64). */
+int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
+                     int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+
+/* ---- re-arranged multi-view token gather / scatter ----------------------------------------------------------------
+ * replaces: multiview_attention.py:436-448 (gather to [target, ref_0..]) and 452-462 (scatter back; target -> every
+ *           canvas) for concat_target=True.  x [b*v][2*s*s][C] canvases (left = ref_i, right = target), seq [b][(v+1)*s*s][C].
+ * (concat_target=False is a pure reshape and needs no kernel.) */
+int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st);
+int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st);
+
+/* ---- fused classifier-free-guidance + DDIM update ----------------------------------------------------------------
+ * replaces: p_sample_ddim's ~15 elementwise kernels (ddim.py:343,366,377-381): e = e_u + s (e_c - e_u);
+ *           pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); x_prev = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-sigma^2) e + sigma*noise.
+ * x, x_prev, pred_x0, noise: fp32 [numel]; eps: fp16 or fp32 [2*numel], uncond half first (ddim.py:317-333).
+ * noise may be NULL (sigma = 0).  Coefficients are host scalars (no device->host sync, cf. ddim.py:359-362). */
+int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev,
+                     float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t,
+                     float sqrt_one_minus_at, lr_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEFTREFILL_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libleftrefill_hip.so (the C ABI declared in include/leftrefill_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises, and every
+op raises RuntimeError on a non-zero return code.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+
+class GemmArgs(ctypes.Structure):
+    """struct lr_gemm_args (include/leftrefill_hip.h)."""
+    _fields_ = [
+        ("p1", c_void_p), ("C1", ctypes.c_int32),
+        ("p2", c_void_p), ("C2", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("Hs", ctypes.c_int32), ("Ws", ctypes.c_int32),
+        ("taps", ctypes.c_int32), ("stride", ctypes.c_int32), ("up", ctypes.c_int32),
+        ("wt", c_void_p), ("N", ctypes.c_int32),
+        ("bias", c_void_p),
+        ("rowvec", c_void_p), ("ld_rowvec", ctypes.c_int32),
+        ("resid", c_void_p), ("ld_resid", ctypes.c_int32),
+        ("out", c_void_p), ("ld_out", ctypes.c_int32),
+        ("geglu", ctypes.c_int32),
+        ("tile_n", ctypes.c_int32),
+    ]
+
+
+# symbol -> argtypes; every function returns int
+SIGNATURES = {
+    "lr_abi_version": [],
+    "lr_nchw_f32_to_nhwc_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_nhwc_f16_to_nchw": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_groupnorm_stats": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "lr_groupnorm_apply": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                           c_int, c_void_p, c_void_p],
+    "lr_layernorm": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
+    "lr_timestep_embedding": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "lr_linear_small_m": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_void_p],
+    "lr_gemm_conv_f16": [ctypes.POINTER(GemmArgs), c_void_p],
+    "lr_attention_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                         c_int, c_float, c_void_p],
+    "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_ddim_cfg_step": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                         c_float, c_float, c_void_p],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it is missing (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m leftrefill_amd.build` (hipcc --offload-arch=gfx950). "
+            "leftrefill_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    v = lib.lr_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libleftrefill_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "alignment", -3: "unsupported"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {kind} (rc={rc})")

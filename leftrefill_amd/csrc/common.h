@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/leftrefill_hip.h"
+
+#define LR_WAVE 64
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 256 B of zeros; target of every padded / out-of-range 16-byte (LDS-DMA) load.  One private copy per
+// translation unit (no relocatable device code needed).
+static __device__ uint4 lr_zero_page[16];
+
+static inline int lr_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+__device__ __forceinline__ float lr_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// exact (erf) GELU, as F.gelu default (attention.py:58)
+__device__ __forceinline__ float lr_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float lr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float lr_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 16-byte vector of 8 halves <-> floats
+__device__ __forceinline__ void lr_unpack8(const uint4& u, float* f) {
+  const f16x8 h = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+}
+__device__ __forceinline__ uint4 lr_pack8(const float* f) {
+  f16x8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
+  return __builtin_bit_cast(uint4, h);
+}

@@ -1,0 +1,279 @@
+// Streaming kernels at the edges of the UNet step: layout converters, timestep embedding, the time-MLP
+// (small-M linear), the re-arranged multi-view token gather/scatter and the fused CFG + DDIM update.
+// All are HBM/launch bound; every global access is vectorised and coalesced.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC fp16 (channel-padded).  One thread per (pixel, octet of output channels): the reads of one
+// channel plane are coalesced across the 64 lanes of a wave (consecutive pixels), the 16-byte writes land in the
+// pixel's row.  Cpad is a multiple of 8.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
+                                    f16* __restrict__ y, int Cpad, int HW, long long total) {
+  const int nOct = Cpad >> 3;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    // idx = (n * nOct + o) * HW + p   (pixel fastest => coalesced plane reads)
+    const int p = (int)(idx % HW);
+    const long long q = idx / HW;
+    const int o = (int)(q % nOct);
+    const long long n = q / nOct;
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = o * 8 + i;
+      float v = 0.f;
+      if (c < C1) v = x1[((size_t)n * C1 + c) * HW + p];
+      else if (c < C1 + C2) v = x2[((size_t)n * C2 + (c - C1)) * HW + p];
+      f[i] = v;
+    }
+    *reinterpret_cast<uint4*>(y + ((size_t)n * HW + p) * Cpad + o * 8) = lr_pack8(f);
+  }
+}
+
+template <typename OutT>
+__global__ void nhwc_to_nchw_kernel(const f16* __restrict__ y, int Cstride, int C, OutT* __restrict__ out, int HW,
+                                    long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % HW);
+    const long long q = idx / HW;
+    const int c = (int)(q % C);
+    const long long n = q / C;
+    out[idx] = (OutT)(float)y[((size_t)n * HW + p) * Cstride + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// timestep_embedding (util.py:154-174): out[n][0:half] = cos(t * f_j), out[n][half:] = sin(t * f_j),
+// f_j = exp(-ln(10000) * j / half), all in fp32 with the exact libm-class functions (t up to 981 rad: no fast-math).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int N, int dim, f16* __restrict__ out) {
+  const int half = dim >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * half) return;
+  const int n = idx / half, j = idx % half;
+  const float freq = expf(-logf(10000.0f) * (float)j / (float)half);
+  const float a = (float)t[n] * freq;
+  out[(size_t)n * dim + j] = (f16)cosf(a);
+  out[(size_t)n * dim + half + j] = (f16)sinf(a);
+  if ((dim & 1) && j == 0) out[(size_t)n * dim + dim - 1] = (f16)0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M linear: out[m][n] = act_out(sum_k act_in(a[m][k]) w[n][k] + b[n]), M <= 16.  Weight-streaming bound:
+// each wave owns output columns n, lanes split K in 16-byte pieces (coalesced 1 KiB per wave load), the (tiny)
+// activation matrix is staged once per block in LDS with act_in applied.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MMAX>
+__global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const f16* __restrict__ w,
+                                      const float* __restrict__ bias, f16* __restrict__ out, int ldo, int M, int N,
+                                      int K, int act_in, int act_out, int cols_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  f16* s_a = reinterpret_cast<f16*>(smem_raw);  // [MMAX][K]
+  const int t = threadIdx.x;
+  for (int idx = t; idx < MMAX * K; idx += blockDim.x) {
+    const int m = idx / K, k = idx % K;
+    float v = 0.f;
+    if (m < M) {
+      v = (float)a[(size_t)m * lda + k];
+      if (act_in) v = lr_silu(v);
+    }
+    s_a[idx] = (f16)v;
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int n_begin = (blockIdx.x * nwaves + wave) * cols_per_wave;
+  for (int n = n_begin; n < min(N, n_begin + cols_per_wave); ++n) {
+    float acc[MMAX];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+      float wf[8];
+      lr_unpack8(*reinterpret_cast<const uint4*>(w + (size_t)n * K + k), wf);
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
+        float af[8];
+        lr_unpack8(*reinterpret_cast<const uint4*>(s_a + m * K + k), af);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[m] = fmaf(af[i], wf[i], acc[m]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) acc[m] = lr_wave_sum(acc[m]);
+    if (lane < M) {
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) if (m == lane) v = acc[m];
+      if (bias) v += bias[n];
+      if (act_out) v = lr_silu(v);
+      out[(size_t)lane * ldo + n] = (f16)v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-view token re-arrangement, concat_target=True (multiview_attention.py:440-446 / 456-460).
+// canvases x [b*v][s rows][2s cols][C]; sequence seq [b][(v+1)][s][s][C] = [target(from canvas 0), ref_0..ref_{v-1}].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void mv_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ seq, int b, int v, int s, int C8,
+                                 long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C8);
+    long long q = idx / C8;
+    const int col = (int)(q % s); q /= s;
+    const int row = (int)(q % s); q /= s;
+    const int j = (int)(q % (v + 1));
+    const long long bi = q / (v + 1);
+    const int canvas = j == 0 ? 0 : j - 1;
+    const int scol = j == 0 ? s + col : col;
+    seq[idx] = x[((((size_t)bi * v + canvas) * s + row) * (2 * s) + scol) * C8 + c];
+  }
+}
+
+__global__ void mv_scatter_kernel(const uint4* __restrict__ seq, uint4* __restrict__ x, int b, int v, int s, int C8,
+                                  long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C8);
+    long long q = idx / C8;
+    const int col = (int)(q % (2 * s)); q /= (2 * s);
+    const int row = (int)(q % s); q /= s;
+    const int canvas = (int)(q % v);
+    const long long bi = q / v;
+    const int j = col >= s ? 0 : canvas + 1;
+    const int scol = col >= s ? col - s : col;
+    x[idx] = seq[((((size_t)bi * (v + 1) + j) * s + row) * s + scol) * C8 + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CFG combine + DDIM update (ddim.py:343-381), fp32 state, 4 elements per thread.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename EpsT>
+__global__ void ddim_cfg_step_kernel(const float* __restrict__ x, const EpsT* __restrict__ eps,
+                                     const float* __restrict__ noise, float* __restrict__ x_prev,
+                                     float* __restrict__ pred_x0, long long numel, float scale, float sqrt_at,
+                                     float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float eu = (float)eps[i];
+    const float ec = (float)eps[numel + i];
+    float e;
+    if (sizeof(EpsT) == 2) {
+      // the reference's CFG combine runs in fp16 (model output dtype under autocast, ddim.py:343)
+      const f16 d = (f16)(ec - eu);
+      const f16 sd = (f16)(scale * (float)d);
+      e = (float)(f16)(eu + (float)sd);
+    } else {
+      e = eu + scale * (ec - eu);
+    }
+    const float xv = x[i];
+    const float p0 = (xv - sqrt_1m_at * e) / sqrt_at;
+    float xp = sqrt_aprev * p0 + dir_coef * e;
+    if (noise) xp += sigma * noise[i];
+    pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
+static inline int grid_for(long long total, int block, int cap = 4096) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int lr_abi_version(void) { return 1; }
+
+extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
+                                       int H, int W, lr_stream_t s) {
+  if (!x1 || !y || N <= 0 || H <= 0 || W <= 0 || C1 <= 0) return LR_E_ARG;
+  if (!x2) C2 = 0;
+  if (Cpad % 8 || Cpad < C1 + C2) return LR_E_ALIGN;
+  const long long total = (long long)N * (Cpad / 8) * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, x1, C1, x2, C2,
+                     (f16*)y, Cpad, H * W, total);
+  return lr_launch_status();
+}
+
+extern "C" int lr_nhwc_f16_to_nchw(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W,
+                                   lr_stream_t s) {
+  if (!y || !out || N <= 0 || C <= 0 || C > Cstride) return LR_E_ARG;
+  const long long total = (long long)N * C * H * W;
+  if (out_is_f32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const f16*)y, Cstride, C, (float*)out, H * W, total);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const f16*)y, Cstride, C, (f16*)out, H * W, total);
+  return lr_launch_status();
+}
+
+extern "C" int lr_timestep_embedding(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s) {
+  if (!t || !out || N <= 0 || dim < 2) return LR_E_ARG;
+  const int total = N * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)s, t, N, dim,
+                     (f16*)out);
+  return lr_launch_status();
+}
+
+extern "C" int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo,
+                                 int M, int N, int K, int act_in, int act_out, lr_stream_t s) {
+  if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) return LR_E_ARG;
+  if (M > 16) return LR_E_UNSUPPORTED;
+  if (K % 8) return LR_E_ALIGN;
+  const int cpw = 4, waves = 4;
+  dim3 grid((N + cpw * waves - 1) / (cpw * waves)), block(64 * waves);
+  hipStream_t st = (hipStream_t)s;
+  if (M <= 4)
+    hipLaunchKernelGGL(linear_small_m_kernel<4>, grid, block, 4 * K * sizeof(f16), st, (const f16*)a, lda,
+                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+  else if (M <= 8)
+    hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, block, 8 * K * sizeof(f16), st, (const f16*)a, lda,
+                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+  else
+    hipLaunchKernelGGL(linear_small_m_kernel<16>, grid, block, 16 * K * sizeof(f16), st, (const f16*)a, lda,
+                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+  return lr_launch_status();
+}
+
+extern "C" int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st) {
+  if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
+  if (C % 8) return LR_E_ALIGN;
+  const long long total = (long long)b * (v + 1) * s * s * (C / 8);
+  hipLaunchKernelGGL(mv_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)x,
+                     (uint4*)seq, b, v, s, C / 8, total);
+  return lr_launch_status();
+}
+
+extern "C" int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st) {
+  if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
+  if (C % 8) return LR_E_ALIGN;
+  const long long total = (long long)b * v * s * 2 * s * (C / 8);
+  hipLaunchKernelGGL(mv_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)seq,
+                     (uint4*)x, b, v, s, C / 8, total);
+  return lr_launch_status();
+}
+
+extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev,
+                                float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t,
+                                float sqrt_one_minus_at, lr_stream_t s) {
+  if (!x || !eps || !x_prev || !pred_x0 || numel <= 0) return LR_E_ARG;
+  // same fp32 scalar arithmetic as the reference's 0-dim fp32 tensors (ddim.py:359-381)
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_coef = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+  dim3 grid(grid_for(numel, 256)), block(256);
+  if (eps_is_f32)
+    hipLaunchKernelGGL(ddim_cfg_step_kernel<float>, grid, block, 0, (hipStream_t)s, x, (const float*)eps, noise, x_prev,
+                       pred_x0, (long long)numel, cfg_scale, sqrt_at, sqrt_one_minus_at, sqrt_aprev, dir_coef,
+                       sigma_t);
+  else
+    hipLaunchKernelGGL(ddim_cfg_step_kernel<f16>, grid, block, 0, (hipStream_t)s, x, (const f16*)eps, noise, x_prev,
+                       pred_x0, (long long)numel, cfg_scale, sqrt_at, sqrt_one_minus_at, sqrt_aprev, dir_coef,
+                       sigma_t);
+  return lr_launch_status();
+}

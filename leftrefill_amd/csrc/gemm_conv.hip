@@ -1,0 +1,272 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+//   C[m][n] = sum_k A[m][k] * Wt[n][k]        m = output pixel / token, n = output channel, k = (tap, in-channel)
+//
+// * A is never materialised: for K-step kt the block gathers, per output row, the 128 contiguous bytes
+//   (64 fp16 channels) of the shifted source pixel of tap kt / (C/64) straight from the NHWC activation into LDS
+//   with 16-byte LDS-DMA (`global_load_lds_dwordx4`); out-of-image taps read a zero page.  Stride-2, the
+//   nearest-2x upsample and the channel concat [p1 | p2] are pure index arithmetic in that gather.
+// * Tile 128 x BN (BN = 64 | 128), BK = 64, 4 waves (2 x 2), each wave owns 64 x BN/2 as 16x16x32 f16 MFMA tiles
+//   with fp32 accumulators; LDS double-buffered, one barrier per K-step.
+// * LDS rows are 128 B; the 16-byte slot of chunk c in row r is c ^ ((r >> 1) & 7).  LDS-DMA writes lane-linear, so
+//   the permutation is applied to the per-lane SOURCE address and again on the ds_read_b128 side: every 16-lane
+//   group of a fragment read touches 16 distinct slots of the 256-byte bank row (conflict-free).
+// * MFMA operands are swapped (A-op = weight rows, B-op = activation rows) so that each lane ends up with four
+//   consecutive output channels of ONE output row: the fp32 tile goes to LDS with 16-byte writes, and the epilogue
+//   (bias, per-sample time-embedding row, residual, GEGLU gate) streams it out as whole fp16 lines.
+#include "common.h"
+
+#define BK 64
+#define GEMM_THREADS 256
+#define BM 128
+
+struct GemmParams {
+  const f16* p1; const f16* p2; const f16* wt; const float* bias; const f16* rowvec; const f16* resid; f16* out;
+  int C1, C2, H, W, Hs, Ws, taps, stride, up, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
+  int ntiles_n, nblocks;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParams P) {
+  constexpr int TM = 4;            // 16-row MFMA tiles per wave along M (64 rows)
+  constexpr int TN = BN / 32;      // 16-col MFMA tiles per wave along N (BN/2 cols)
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware bijective remap: consecutive logical tiles run on the same XCD (shared A rows / halos stay in its L2)
+  int bid = blockIdx.x;
+  {
+    const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % P.ntiles_n, tile_m = bid / P.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread gather metadata: 4 A rows, fixed for the whole K loop
+  const int HW = P.H * P.W;
+  int rb[4], ry[4], rx[4];
+  const int slot = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + w) * 8 + (lane >> 3);
+    const int m = m0 + row;
+    if (m < P.M) {
+      const int b = m / HW, rem = m - b * HW;
+      const int y = rem / P.W, x = rem - y * P.W;
+      rb[i] = b * P.Hs * P.Ws;
+      ry[i] = y * P.stride;
+      rx[i] = x * P.stride;
+    } else {
+      rb[i] = 0; ry[i] = -(1 << 20); rx[i] = -(1 << 20);
+    }
+  }
+  const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
+  const int cpt = (P.C1 + P.C2) >> 6;   // 64-channel chunks per tap
+  const int nk = P.taps * cpt;
+  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
+
+  auto stage = [&](int buf, int kt) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_BYTES;
+    const int tap = kt / cpt, cc = kt - tap * cpt;
+    int dy = 0, dx = 0;
+    if (P.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    const f16* src; int cs, coff;
+    if (cc * 64 < P.C1) { src = P.p1; cs = P.C1; coff = cc * 64; } else { src = P.p2; cs = P.C2; coff = cc * 64 - P.C1; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = (i * 4 + w) * 8;
+      const int row = rbase + (lane >> 3);
+      const int iy = ry[i] + dy, ix = rx[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+      const int sy = iy >> P.up, sx = ix >> P.up;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      const f16* g = ok ? src + (size_t)(rb[i] + sy * P.Ws + sx) * cs + coff + chunk * 8 : zero;
+      glds16(g, As + rbase * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int rbase = (i * 4 + w) * 8;
+      const int row = rbase + (lane >> 3);
+      const int n = n0 + row;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      const f16* g = n < P.N ? P.wt + (size_t)n * P.K + kt * 64 + chunk * 8 : zero;
+      glds16(g, Bs + rbase * 128);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[TM], wf[TN];
+      const int kc = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        xf[i] = *reinterpret_cast<const f16x8*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();  // all reads of buf[cur] done; all LDS-DMA into buf[cur^1] landed (vmcnt(0) precedes the barrier)
+    cur ^= 1;
+  }
+
+  // ---- epilogue phase 1: accumulators (+bias, GEGLU) -> fp32 tile in LDS.  Lane holds D[n = fq*4 + r][m = fr].
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int BNo = P.geglu ? BN / 2 : BN;
+  const int ldc = BNo + 4;
+  if (!P.geglu) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * (BN / 2) + j * 16 + fq * 4;
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * 64 + i * 16 + fr;
+        *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jp = 0; jp < TN / 2; ++jp) {
+      const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;   // packed row of u; g is 16 rows further
+      f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
+      if (P.bias && n0 + nl_u + 16 < P.N) {
+        bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
+        bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
+      }
+      const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * 64 + i * 16 + fr;
+        const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
+        *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue phase 2: whole-line stores with the fused per-sample row vector and residual
+  const int n_out0 = P.geglu ? n0 / 2 : n0;
+  const int N_out = P.geglu ? P.N / 2 : P.N;
+  const int cpr = BNo >> 3;  // 16-byte chunks per tile row
+  for (int id = t; id < BM * cpr; id += GEMM_THREADS) {
+    const int row = id / cpr, cch = id - row * cpr;
+    const int m = m0 + row, n = n_out0 + cch * 8;
+    if (m >= P.M || n >= N_out) continue;
+    float v[8];
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
+    v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+    if (P.rowvec) {
+      float e[8];
+      lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += e[i];
+    }
+    if (P.resid) {
+      float e[8];
+      lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += e[i];
+    }
+    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+  }
+}
+
+template <int BN>
+static int launch_gemm(const GemmParams& P0, hipStream_t st) {
+  GemmParams P = P0;
+  P.ntiles_n = (P.N + BN - 1) / BN;
+  const int ntm = (P.M + BM - 1) / BM;
+  P.nblocks = P.ntiles_n * ntm;
+  const int BNo = P.geglu ? BN / 2 : BN;
+  size_t smem = 2 * (size_t)(BM + BN) * 128;
+  const size_t epi = (size_t)BM * (BNo + 4) * sizeof(float);
+  if (epi > smem) smem = epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)(2 * (size_t)(BM + BN) * 128 > (size_t)BM * (BN + 4) * 4 ? 2 * (size_t)(BM + BN) * 128
+                                                                                      : (size_t)BM * (BN + 4) * 4));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks), dim3(GEMM_THREADS), smem, st, P);
+  return lr_launch_status();
+}
+
+extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
+  if (!a || !a->p1 || !a->wt || !a->out) return LR_E_ARG;
+  GemmParams P;
+  P.p1 = (const f16*)a->p1; P.C1 = a->C1;
+  P.p2 = (const f16*)a->p2; P.C2 = a->p2 ? a->C2 : 0;
+  if (P.C1 <= 0 || P.C1 % 64 || P.C2 % 64) return LR_E_ALIGN;
+  if (a->taps != 1 && a->taps != 9) return LR_E_UNSUPPORTED;
+  if (a->stride != 1 && a->stride != 2) return LR_E_UNSUPPORTED;
+  if (a->up != 0 && a->up != 1) return LR_E_UNSUPPORTED;
+  if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Hs <= 0 || a->Ws <= 0 || a->N <= 0) return LR_E_ARG;
+  P.H = a->H; P.W = a->W; P.Hs = a->Hs; P.Ws = a->Ws;
+  P.taps = a->taps; P.stride = a->stride; P.up = a->up;
+  P.wt = (const f16*)a->wt; P.N = a->N; P.bias = a->bias;
+  P.M = a->B * a->H * a->W;
+  P.K = a->taps * (P.C1 + P.C2);
+  P.rowvec = (const f16*)a->rowvec; P.ld_rowvec = a->ld_rowvec;
+  P.resid = (const f16*)a->resid; P.ld_resid = a->ld_resid;
+  P.out = (f16*)a->out; P.ld_out = a->ld_out;
+  P.geglu = a->geglu ? 1 : 0;
+  P.rows_per_batch = a->H * a->W;
+  const int N_out = P.geglu ? P.N / 2 : P.N;
+  if (P.N % 8 || N_out % 8 || P.ld_out % 8 || (P.resid && P.ld_resid % 8) || (P.rowvec && P.ld_rowvec % 8))
+    return LR_E_ALIGN;
+  if (P.geglu && P.N % 32) return LR_E_ALIGN;
+  if (((uintptr_t)P.p1 | (uintptr_t)P.p2 | (uintptr_t)P.wt | (uintptr_t)P.out | (uintptr_t)P.resid |
+       (uintptr_t)P.rowvec | (uintptr_t)P.bias) & 15)
+    return LR_E_ALIGN;
+  int tn = a->tile_n;
+  if (tn == 0) tn = (P.N % 128 == 0) ? 128 : 64;
+  if (P.geglu && tn == 64 && false) return LR_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)s;
+  if (tn == 128) return launch_gemm<128>(P, st);
+  if (tn == 64) return launch_gemm<64>(P, st);
+  return LR_E_UNSUPPORTED;
+}

@@ -1,0 +1,223 @@
+// GroupNorm(32)[+SiLU] and LayerNorm for NHWC fp16 activations -- HBM-bound streaming kernels.
+//
+// Layout: x [N][HW][C] fp16, channels contiguous (one pixel = one row).  Every global access is a 16-byte
+// (8 x fp16) vector, consecutive lanes read consecutive 16-byte pieces of a row => full-line coalescing.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics.  grid = (LR_GN_CHUNKS, N); block = nOct * R threads where nOct = C/8 octets per pixel and
+// R = pixel rows per sweep.  Thread (o, r) always owns octet o and keeps per-channel fp32 (sum, sumsq); the block
+// combines them per group in a FIXED order through LDS (no atomics => bitwise reproducible reruns) and writes
+// partials[n][chunk][32][2].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+                                float* __restrict__ partials, int nOct, int R) {
+  extern __shared__ float s_part[];  // [R][C][2]
+  const int C = C1 + C2;
+  const int Cg = C / 32;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int t = threadIdx.x;
+  const int o = t % nOct, r = t / nOct;
+  const int per = (HW + LR_GN_CHUNKS - 1) / LR_GN_CHUNKS;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const int c0 = o * 8;
+  const f16* src;
+  int cs, coff;
+  if (c0 < C1) { src = x1; cs = C1; coff = c0; } else { src = x2; cs = C2; coff = c0 - C1; }
+  float sm[8], sq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sm[i] = 0.f; sq[i] = 0.f; }
+  const f16* base = src + ((size_t)n * HW) * cs + coff;
+  int p = p0 + r;
+  // two pixels in flight per thread
+  for (; p + R < p1; p += 2 * R) {
+    const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)p * cs);
+    const uint4 u1 = *reinterpret_cast<const uint4*>(base + (size_t)(p + R) * cs);
+    float f[8], g[8];
+    lr_unpack8(u0, f);
+    lr_unpack8(u1, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sm[i] += f[i] + g[i]; sq[i] = fmaf(f[i], f[i], fmaf(g[i], g[i], sq[i])); }
+  }
+  for (; p < p1; p += R) {
+    const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)p * cs);
+    float f[8];
+    lr_unpack8(u0, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sm[i] += f[i]; sq[i] = fmaf(f[i], f[i], sq[i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s_part[((size_t)r * C + c0 + i) * 2 + 0] = sm[i];
+    s_part[((size_t)r * C + c0 + i) * 2 + 1] = sq[i];
+  }
+  __syncthreads();
+  if (t < 32) {
+    float s = 0.f, q = 0.f;
+    for (int c = t * Cg; c < (t + 1) * Cg; ++c)
+      for (int rr = 0; rr < R; ++rr) { s += s_part[((size_t)rr * C + c) * 2]; q += s_part[((size_t)rr * C + c) * 2 + 1]; }
+    float* dst = partials + (((size_t)n * LR_GN_CHUNKS + chunk) * 32 + t) * 2;
+    dst[0] = s;
+    dst[1] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm apply (+ optional SiLU).  grid = (pixel blocks, N).  Each block first finalises mean/rstd of its sample
+// (fp64 combine of LR_GN_CHUNKS partials per group), builds per-channel scale/shift in LDS, then streams pixels.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+                                const float* __restrict__ partials, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int silu, f16* __restrict__ y,
+                                int pix_per_block) {
+  extern __shared__ float s_ab[];  // [C] scale, [C] shift
+  __shared__ float s_mean[32], s_rstd[32];
+  const int C = C1 + C2;
+  const int Cg = C / 32;
+  const int n = blockIdx.y;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    double s = 0.0, q = 0.0;
+    const float* src = partials + ((size_t)n * LR_GN_CHUNKS * 32 + t) * 2;
+    for (int c = 0; c < LR_GN_CHUNKS; ++c) { s += (double)src[c * 64]; q += (double)src[c * 64 + 1]; }
+    const double cnt = (double)HW * (double)Cg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[t] = (float)mean;
+    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += blockDim.x) {
+    const int g = c / Cg;
+    const float a = s_rstd[g] * gamma[c];
+    s_ab[c] = a;
+    s_ab[C + c] = beta[c] - s_mean[g] * a;
+  }
+  __syncthreads();
+  const int nOct = C / 8;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  const int total = (p1 - p0) * nOct;
+  for (int idx = t; idx < total; idx += blockDim.x) {
+    const int p = p0 + idx / nOct;
+    const int o = idx % nOct;
+    const int c0 = o * 8;
+    const f16* src;
+    if (c0 < C1) src = x1 + ((size_t)n * HW + p) * C1 + c0;
+    else src = x2 + ((size_t)n * HW + p) * C2 + (c0 - C1);
+    const uint4 u = *reinterpret_cast<const uint4*>(src);
+    float f[8];
+    lr_unpack8(u, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = fmaf(f[i], s_ab[c0 + i], s_ab[C + c0 + i]);
+      f[i] = silu ? lr_silu(v) : v;
+    }
+    *reinterpret_cast<uint4*>(y + ((size_t)n * HW + p) * C + c0) = lr_pack8(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 2048), two-pass mean / variance like ATen.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV>  // 16-byte vectors per lane
+__global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, f16* __restrict__ y, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nOct = C >> 3;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)row * C + o * 8);
+      lr_unpack8(u, v[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[j][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[j][i] = 0.f;
+    }
+  }
+  const float mean = lr_wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; sq = fmaf(d, d, sq); }
+    }
+  }
+  const float rstd = rsqrtf(lr_wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + o * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + o * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + o * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(beta + o * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fmaf((v[j][i] - mean) * rstd, g[i], b[i]);
+      *reinterpret_cast<uint4*>(y + (size_t)row * C + o * 8) = lr_pack8(f);
+    }
+  }
+}
+
+extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
+                                  lr_stream_t s) {
+  if (!x1 || !partials || N <= 0 || HW <= 0) return LR_E_ARG;
+  if (!x2) C2 = 0;
+  const int C = C1 + C2;
+  if (C % 32 || C1 % 8 || C2 % 8) return LR_E_ALIGN;
+  const int nOct = C / 8;
+  int R = 256 / nOct;
+  if (R < 1) R = 1;
+  const int threads = nOct * R;
+  if (threads > 1024) return LR_E_UNSUPPORTED;
+  dim3 grid(LR_GN_CHUNKS, N);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)R * C * 2 * sizeof(float), (hipStream_t)s,
+                     (const f16*)x1, C1, (const f16*)x2, C2, HW, partials, nOct, R);
+  return lr_launch_status();
+}
+
+extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
+                                  const float* partials, const float* gamma, const float* beta, float eps, int silu,
+                                  lr_half* y, lr_stream_t s) {
+  if (!x1 || !partials || !gamma || !beta || !y || N <= 0 || HW <= 0) return LR_E_ARG;
+  if (!x2) C2 = 0;
+  const int C = C1 + C2;
+  if (C % 32 || C1 % 8 || C2 % 8) return LR_E_ALIGN;
+  // ~2048 blocks over the whole tensor, at least 8 pixels per block
+  int ppb = (int)(((long long)N * HW + 2047) / 2048);
+  if (ppb < 8) ppb = 8;
+  if (ppb > HW) ppb = HW;
+  dim3 grid((HW + ppb - 1) / ppb, N);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const f16*)x1, C1,
+                     (const f16*)x2, C2, HW, partials, gamma, beta, eps, silu, (f16*)y, ppb);
+  return lr_launch_status();
+}
+
+extern "C" int lr_layernorm(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C,
+                            lr_stream_t s) {
+  if (!x || !gamma || !beta || !y || M <= 0) return LR_E_ARG;
+  if (C % 8 || C > 2048) return LR_E_ALIGN;
+  const int nv = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)s;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
+  }
+  return lr_launch_status();
+}

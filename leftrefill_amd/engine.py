@@ -1,0 +1,237 @@
+"""Functional execution engine of the UNet step on the HIP kernels.
+
+Every function works on token-major fp16 activations (`tok` = [N*H*W, C]) and on *packed* weights
+(leftrefill_amd.packing) held in small `Packed*` records that the drop-in nn.Modules build once from their
+reference-shaped parameters.  No torch math runs on the hot path -- torch only allocates buffers.
+
+Reference semantics implemented here (file:line in the reference repo):
+  ResBlock._forward              ldm/modules/diffusionmodules/openaimodel.py:254-274
+  Downsample / Upsample          openaimodel.py:90-159
+  SpatialTransformer.forward     ldm/modules/attention.py:393-419
+  BasicTransformerBlock._forward attention.py:279-283
+  CrossAttention.forward         attention.py:165-196 / 218-250
+  FeedForward / GEGLU            attention.py:51-78
+  MultiViewBasicTransformerBlock._forward  ldm/modules/multiview_attention.py:431-468
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops, packing
+
+
+@dataclass
+class Act:
+    """NHWC fp16 activation: tok [N*H*W, C] (+ optional second tensor = virtual channel concat)."""
+    tok: torch.Tensor
+    N: int
+    H: int
+    W: int
+    tok2: Optional[torch.Tensor] = None
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    def materialize(self):
+        if self.tok2 is None:
+            return self.tok
+        return torch.cat([self.tok, self.tok2], dim=1).contiguous()
+
+
+def f32(p):
+    return p.detach().float().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# packed parameter records
+# ---------------------------------------------------------------------------------------------------------------
+class PackedConv:
+    def __init__(self, conv, cin_pad=None):
+        w = conv.weight.detach()
+        self.cout = w.shape[0]
+        self.taps = w.shape[2] * w.shape[3]
+        self.w = packing.pack_conv(w, cin_pad=cin_pad)
+        self.b = packing.pack_bias(conv.bias.detach(), self.w.shape[0]) if conv.bias is not None else None
+        self.stride = conv.stride[0]
+
+
+class PackedLinear:
+    def __init__(self, lin=None, weight=None, bias=None):
+        if lin is not None:
+            weight, bias = lin.weight, lin.bias
+        w = weight.detach()
+        if w.dim() == 4:  # 1x1 conv used as a linear (use_linear_in_transformer=False)
+            w = w.reshape(w.shape[0], w.shape[1])
+        self.w = packing.pack_linear(w)
+        self.b = f32(bias) if bias is not None else None
+
+
+class PackedNorm:
+    def __init__(self, norm):
+        self.g = f32(norm.weight)
+        self.b = f32(norm.bias)
+        self.eps = float(norm.eps)
+
+
+class PackedRes:
+    def __init__(self, blk):
+        self.n1 = PackedNorm(blk.in_layers[0])
+        self.c1 = PackedConv(blk.in_layers[2])
+        self.emb = PackedLinear(blk.emb_layers[1])
+        self.n2 = PackedNorm(blk.out_layers[0])
+        self.c2 = PackedConv(blk.out_layers[3])
+        self.skip = None
+        sk = blk.skip_connection
+        if isinstance(sk, torch.nn.Conv2d):
+            self.skip = PackedConv(sk)
+        self.cout = self.c1.cout
+
+
+class PackedAttn:
+    """attn1: fused [q;k;v] projection; attn2: q projection + fused [k;v] projection of the context."""
+
+    def __init__(self, attn, is_self):
+        self.heads = attn.heads
+        self.is_self = is_self
+        if is_self:
+            self.qkv = PackedLinear(weight=torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0))
+        else:
+            self.q = PackedLinear(weight=attn.to_q.weight)
+            self.kv = PackedLinear(weight=torch.cat([attn.to_k.weight, attn.to_v.weight], 0))
+        self.out = PackedLinear(attn.to_out[0])
+        self.dim_head = attn.to_q.weight.shape[0] // attn.heads
+        if self.dim_head != 64:
+            raise RuntimeError(f"attention kernel is specialised for d_head=64 (got {self.dim_head})")
+
+
+class PackedTBlock:
+    def __init__(self, blk):
+        if getattr(blk, "disable_self_attn", False):
+            raise RuntimeError("disable_self_attn=True is not used by LeftRefill configs and is unsupported")
+        self.attn1 = PackedAttn(blk.attn1, True)
+        self.attn2 = PackedAttn(blk.attn2, False)
+        self.n1, self.n2, self.n3 = PackedNorm(blk.norm1), PackedNorm(blk.norm2), PackedNorm(blk.norm3)
+        proj = blk.ff.net[0].proj
+        self.geglu_w, self.geglu_b = packing.pack_geglu(proj.weight.detach(), proj.bias.detach())
+        self.ff2 = PackedLinear(blk.ff.net[2])
+        # multi-view attributes (None for the single-view block)
+        self.view_num = getattr(blk, "view_num", None)
+        self.concat_target = getattr(blk, "concat_target", False)
+        self.no_rearrange = getattr(blk, "no_rearrange_selfattn", False)
+
+
+class PackedST:
+    def __init__(self, st):
+        self.norm = PackedNorm(st.norm)
+        self.proj_in = PackedLinear(st.proj_in)
+        self.blocks = [PackedTBlock(b) for b in st.transformer_blocks]
+        self.proj_out = PackedLinear(st.proj_out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# functional blocks
+# ---------------------------------------------------------------------------------------------------------------
+def linear(x, pl: PackedLinear, resid=None, M=None):
+    M = x.shape[0] if M is None else M
+    return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid)
+
+
+def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0):
+    """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample) or 1x1 conv over an Act."""
+    if pc.taps == 9:
+        if up:
+            H, W = act.H * 2, act.W * 2
+        elif pc.stride == 2:
+            H, W = act.H // 2, act.W // 2
+        else:
+            H, W = act.H, act.W
+    else:
+        H, W = act.H, act.W
+    y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
+                      x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid)
+    return Act(y, act.N, H, W)
+
+
+def gn(act: Act, pn: PackedNorm, silu):
+    y = ops.group_norm(act.tok, act.N, act.HW, pn.g, pn.b, pn.eps, silu, act.tok2)
+    return Act(y, act.N, act.H, act.W)
+
+
+def resblock(act: Act, pr: PackedRes, emb_out):
+    """emb_out: [N, Cout] fp16 (row stride may exceed Cout) = emb_layers(emb), added to every pixel of sample n."""
+    h = gn(act, pr.n1, True)
+    h = conv(h, pr.c1, rowvec=emb_out)
+    h = gn(h, pr.n2, True)
+    if pr.skip is not None:
+        resid = conv(act, pr.skip).tok
+    else:
+        resid = act.materialize()
+    return conv(h, pr.c2, resid=resid)
+
+
+def self_attention(x, pa: PackedAttn, B, L, resid):
+    C = x.shape[1]
+    qkv = linear(x, pa.qkv)
+    a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, pa.heads, L, L, pa.dim_head ** -0.5)
+    return linear(a, pa.out, resid=resid)
+
+
+def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid):
+    C = x.shape[1]
+    q = linear(x, pa.q)
+    kv = linear(ctx, pa.kv)
+    a = ops.attention(q, kv[:, :C], kv[:, C:], B, pa.heads, L, Lc, pa.dim_head ** -0.5)
+    return linear(a, pa.out, resid=resid)
+
+
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc):
+    """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468."""
+    if pt.view_num is None:
+        x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, N, L, x)
+    elif pt.concat_target and not pt.no_rearrange:
+        v = pt.view_num - 1
+        b = N // v
+        s = int(math.sqrt(L / 2))
+        assert 2 * s * s == L and b * v == N, "concat_target needs square halves and batch = b*(view_num-1)"
+        seq = ops.mv_gather(x, b, v, s)
+        Ls = pt.view_num * s * s
+        seq = self_attention(ops.layer_norm(seq, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, b, Ls, seq)
+        x = ops.mv_scatter(seq, b, v, s)
+    else:
+        v = pt.view_num - 1 if pt.concat_target else pt.view_num
+        b = N // v
+        assert b * v == N
+        x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, b, v * L, x)
+    x = cross_attention(ops.layer_norm(x, pt.n2.g, pt.n2.b, pt.n2.eps), ctx, pt.attn2, N, L, Lc, x)
+    n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
+    g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
+    return linear(g, pt.ff2, resid=x)
+
+
+def spatial_transformer(act: Act, ctx, Lc, ps: PackedST):
+    x_in = act.materialize()
+    h = gn(Act(x_in, act.N, act.H, act.W), ps.norm, False).tok
+    h = linear(h, ps.proj_in)
+    for pt in ps.blocks:
+        h = transformer_block(h, ctx, pt, act.N, act.HW, Lc)
+    y = linear(h, ps.proj_out, resid=x_in)
+    return Act(y, act.N, act.H, act.W)
+
+
+def to_tokens(x):
+    """[B, L, C] any float dtype -> ([B*L, C] fp16 contiguous, B, L)"""
+    B, L, C = x.shape
+    return x.reshape(B * L, C).to(torch.float16).contiguous(), B, L
+
+
+def act_from_nchw(x, cpad=None):
+    N, C, H, W = x.shape
+    return Act(ops.nchw_to_nhwc(x, cpad=cpad), N, H, W)
+
+
+def act_to_nchw(act: Act, C=None, dtype=torch.float16):
+    tok = act.materialize()
+    return ops.nhwc_to_nchw(tok, act.N, act.H, act.W, C or tok.shape[1], dtype)

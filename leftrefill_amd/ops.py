@@ -1,0 +1,180 @@
+"""Torch-tensor front end of the C ABI: shape/dtype checks, output allocation, current-stream plumbing.
+
+PyTorch is used only for device memory and streams (`torch.cuda.current_stream()` is the HIP stream on ROCm).
+Activations are NHWC / token-major fp16: a tensor [M, C] with M = N*H*W rows.
+"""
+import torch
+
+from . import _lib
+from ._lib import GemmArgs
+
+GN_CHUNKS = 16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk16(t, name):
+    assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous(), f"{name}: need contiguous cuda fp16"
+
+
+def nchw_to_nhwc(x1, x2=None, cpad=None):
+    """[N,C1,H,W] fp32 (+ optional [N,C2,H,W]) -> [N*H*W, cpad] fp16."""
+    lib = _lib.load()
+    N, C1, H, W = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    cpad = cpad or ((C1 + C2 + 7) // 8) * 8
+    x1 = x1.float().contiguous()
+    x2 = None if x2 is None else x2.float().contiguous()
+    y = torch.empty(N * H * W, cpad, device=x1.device, dtype=torch.float16)
+    _lib.check(lib.lr_nchw_f32_to_nhwc_f16(_p(x1), C1, _p(x2), C2, _p(y), cpad, N, H, W, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
+    lib = _lib.load()
+    _chk16(y, "y")
+    out = torch.empty(N, C, H, W, device=y.device, dtype=out_dtype)
+    _lib.check(lib.lr_nhwc_f16_to_nchw(_p(y), y.shape[-1], C, _p(out), int(out_dtype == torch.float32), N, H, W,
+                                       _stream()), "nhwc_to_nchw")
+    return out
+
+
+def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None):
+    """GroupNorm(32)(+SiLU) over the virtual concat [x1 | x2]; x* are [N*HW, C*] fp16 -> [N*HW, C1+C2] fp16."""
+    lib = _lib.load()
+    _chk16(x1, "x1")
+    C1 = x1.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _chk16(x2, "x2")
+        C2 = x2.shape[-1]
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C1 + C2
+    partials = torch.empty(N * GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
+    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+    st = _stream()
+    _lib.check(lib.lr_groupnorm_stats(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
+    _lib.check(lib.lr_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
+                                      int(bool(silu)), _p(y), st), "groupnorm_apply")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    _chk16(x, "x")
+    M, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.lr_layernorm(_p(x), _p(gamma), _p(beta), float(eps), _p(y), M, C, _stream()), "layernorm")
+    return y
+
+
+def timestep_embedding(t, dim):
+    lib = _lib.load()
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float16)
+    _lib.check(lib.lr_timestep_embedding(_p(t), t.shape[0], dim, _p(out), _stream()), "timestep_embedding")
+    return out
+
+
+def linear_small_m(a, w, bias, act_in=False, act_out=False):
+    """a [M<=16, K] fp16, w [N, K] fp16, bias [N] fp32 or None -> [M, N] fp16."""
+    lib = _lib.load()
+    _chk16(a, "a")
+    _chk16(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.float16)
+    _lib.check(lib.lr_linear_small_m(_p(a), K, _p(w), _p(bias), _p(out), N, M, N, K, int(act_in), int(act_out),
+                                     _stream()), "linear_small_m")
+    return out
+
+
+def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=None, bias=None, rowvec=None,
+              resid=None, geglu=False, out=None, tile_n=0):
+    """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
+    lib = _lib.load()
+    _chk16(x1, "x1")
+    _chk16(wt, "wt")
+    Hs = H if Hs is None else Hs
+    Ws = W if Ws is None else Ws
+    C1 = x1.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _chk16(x2, "x2")
+        C2 = x2.shape[-1]
+    Nw = wt.shape[0]
+    assert wt.shape[1] == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+    assert x1.shape[0] == B * Hs * Ws, (x1.shape, B, Hs, Ws)
+    M = B * H * W
+    n_out = Nw // 2 if geglu else Nw
+    if out is None:
+        out = torch.empty(M, n_out, device=x1.device, dtype=torch.float16)
+    a = GemmArgs()
+    a.p1, a.C1, a.p2, a.C2 = _p(x1), C1, _p(x2), C2
+    a.B, a.H, a.W, a.Hs, a.Ws = B, H, W, Hs, Ws
+    a.taps, a.stride, a.up = taps, stride, up
+    a.wt, a.N = _p(wt), Nw
+    a.bias = _p(bias)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Nw
+    a.rowvec, a.ld_rowvec = _p(rowvec), (rowvec.stride(0) if rowvec is not None else 0)
+    a.resid, a.ld_resid = _p(resid), (resid.stride(0) if resid is not None else 0)
+    if resid is not None:
+        assert resid.shape[0] == M and resid.dtype == torch.float16
+    a.out, a.ld_out = _p(out), out.stride(0)
+    a.geglu = int(geglu)
+    a.tile_n = tile_n
+    _lib.check(lib.lr_gemm_conv_f16(a, _stream()), "gemm_conv")
+    return out
+
+
+def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None):
+    """q [B*Nq, >=heads*64] (row stride = ldq), k/v [B*Nkv, ...]; returns [B*Nq, heads*64] fp16.
+
+    q/k/v may be column slices of a fused projection (strided rows, unit column stride)."""
+    lib = _lib.load()
+    for t_ in (q, k, v):
+        assert t_.is_cuda and t_.dtype == torch.float16 and t_.stride(1) == 1
+    if out is None:
+        out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+    _lib.check(lib.lr_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                    B, heads, Nq, Nkv, float(scale), _stream()), "attention")
+    return out
+
+
+def mv_gather(x, b, v, s):
+    lib = _lib.load()
+    _chk16(x, "x")
+    C = x.shape[-1]
+    seq = torch.empty(b * (v + 1) * s * s, C, device=x.device, dtype=torch.float16)
+    _lib.check(lib.lr_mv_gather(_p(x), _p(seq), b, v, s, C, _stream()), "mv_gather")
+    return seq
+
+
+def mv_scatter(seq, b, v, s):
+    lib = _lib.load()
+    _chk16(seq, "seq")
+    C = seq.shape[-1]
+    x = torch.empty(b * v * s * 2 * s, C, device=seq.device, dtype=torch.float16)
+    _lib.check(lib.lr_mv_scatter(_p(seq), _p(x), b, v, s, C, _stream()), "mv_scatter")
+    return x
+
+
+def ddim_cfg_step(x, eps, noise, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at):
+    """x [B,...] fp32; eps [2B,...] fp16|fp32 (uncond first); returns (x_prev, pred_x0) fp32."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
+    assert eps.numel() == 2 * x.numel() and eps.dtype in (torch.float16, torch.float32)
+    if noise is not None:
+        noise = noise.float().contiguous()
+    x_prev = torch.empty_like(x)
+    pred = torch.empty_like(x)
+    _lib.check(lib.lr_ddim_cfg_step(_p(x), _p(eps), int(eps.dtype == torch.float32), _p(noise), _p(x_prev), _p(pred),
+                                    x.numel(), float(cfg_scale), float(a_t), float(a_prev), float(sigma_t),
+                                    float(sqrt_one_minus_at), _stream()), "ddim_cfg_step")
+    return x_prev, pred

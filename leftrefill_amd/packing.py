@@ -1,0 +1,48 @@
+"""Weight re-layout from the reference's state-dict shapes to the kernels' layouts (done once after loading).
+
+conv  OIHW [Cout, Cin, kh, kw] fp32  ->  [Cout_pad, kh*kw*Cin_pad] fp16, K index = (kh*3 + kw) * Cin_pad + c
+linear [out, in]                    ->  [out, in] fp16 (already K-contiguous)
+GEGLU proj [8C, C] (u rows then g rows, attention.py:56-57) -> rows interleaved in 16-row groups [u16 | g16 | ...]
+"""
+import torch
+
+
+def pad_to(n, m):
+    return ((n + m - 1) // m) * m
+
+
+def pack_conv(w, cin_pad=None, cout_pad=None):
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin_pad or pad_to(cin, 64)
+    cout_pad = cout_pad or pad_to(cout, 64)
+    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
+    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin).to(torch.float16)
+    return out.reshape(cout_pad, kh * kw * cin_pad).contiguous()
+
+
+def pack_bias(b, n_pad=None):
+    n_pad = n_pad or pad_to(b.numel(), 64)
+    out = torch.zeros(n_pad, dtype=torch.float32, device=b.device)
+    out[: b.numel()] = b.float()
+    return out
+
+
+def pack_linear(w):
+    return w.to(torch.float16).contiguous()
+
+
+def geglu_perm(n_half, device=None):
+    """Row permutation: packed row p -> original row of the [2*n_half, K] GEGLU projection."""
+    assert n_half % 16 == 0
+    c = torch.arange(n_half, device=device)
+    grp, within = c // 16, c % 16
+    perm = torch.empty(2 * n_half, dtype=torch.long, device=device)
+    perm[grp * 32 + within] = c                 # u rows
+    perm[grp * 32 + 16 + within] = n_half + c   # gate rows
+    return perm
+
+
+def pack_geglu(w, b):
+    n_half = w.shape[0] // 2
+    perm = geglu_perm(n_half, w.device)
+    return w[perm].to(torch.float16).contiguous(), b[perm].float().contiguous()
