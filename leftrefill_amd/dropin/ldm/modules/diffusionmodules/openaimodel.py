@@ -1,0 +1,392 @@
+"""`ldm.modules.diffusionmodules.openaimodel` on the MI355X kernels.
+
+Same public surface as the reference (ldm/modules/diffusionmodules/openaimodel.py): TimestepBlock 60-70,
+TimestepEmbedSequential 73-87, Upsample 90-118, Downsample 133-159, ResBlock 162-274, UNetModel 412-787 -- identical
+constructor kwargs, forward signatures and the 686 state-dict keys of the SD2-inpainting UNet, so checkpoints load
+unchanged.  Internally the network runs on NHWC fp16 activations:
+
+  * the whole forward is a flat plan of HIP kernel launches (leftrefill_amd.engine) -- implicit-GEMM convs on MFMA
+    with the time-embedding add / residual add fused in the epilogue, GroupNorm+SiLU streaming kernels reading the
+    skip concat virtually, fused transformer blocks, one batched GEMV for the 22 emb_layers projections;
+  * shapes are static across the 50 DDIM steps, so the plan is captured once per input shape into a hipGraph
+    (torch.cuda.CUDAGraph on ROCm) and replayed: one graph launch per UNet step instead of ~450 kernel launches.
+
+The product path has no PyTorch-eager fallback; a missing HIP library raises.
+"""
+from abc import abstractmethod
+
+import torch
+import torch as th
+import torch.nn as nn
+
+from leftrefill_amd import engine, ops
+from ldm.modules.attention import SpatialTransformer
+from ldm.modules.diffusionmodules.util import (checkpoint, conv_nd, linear, normalization, timestep_embedding,
+                                               zero_module)
+from ldm.util import exists
+
+
+class TimestepBlock(nn.Module):
+    """Any module whose forward takes the timestep embedding as second argument."""
+
+    @abstractmethod
+    def forward(self, x, emb):
+        ...
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Routes `emb` to TimestepBlocks and `context` to SpatialTransformers (reference 73-87)."""
+
+    def forward(self, x, emb, context=None, **kwargs):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context)
+            else:
+                x = layer(x)
+        return x
+
+
+class Upsample(nn.Module):
+    """Nearest x2 followed by conv3x3: the upsample is index arithmetic inside the conv's gather (no copy)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv or dims != 2 or padding != 1:
+            raise NotImplementedError("only the learned 2-D upsample (conv_resample=True) is used by LeftRefill")
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+
+    def _fwd(self, act):
+        pc = engine_cache(self, "conv", lambda: engine.PackedConv(self.conv))
+        return engine.conv(act, pc, up=1)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return engine.act_to_nchw(self._fwd(engine.act_from_nchw(x)), self.out_channels).to(x.dtype)
+
+
+class Downsample(nn.Module):
+    """conv3x3 stride 2, symmetric pad 1 (reference 150-152)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv or dims != 2 or padding != 1:
+            raise NotImplementedError("only the learned 2-D downsample (conv_resample=True) is used by LeftRefill")
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def _fwd(self, act):
+        pc = engine_cache(self, "op", lambda: engine.PackedConv(self.op))
+        return engine.conv(act, pc)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return engine.act_to_nchw(self._fwd(engine.act_from_nchw(x)), self.out_channels).to(x.dtype)
+
+
+def engine_cache(module, key, build):
+    from ldm.modules.attention import _cached
+    return _cached(module, key, build)
+
+
+class ResBlock(TimestepBlock):
+    """GN+SiLU -> conv3x3 (+emb) -> GN+SiLU -> conv3x3 -> + skip(x)   (reference 254-274)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or use_conv:
+            raise NotImplementedError("scale-shift norm / resblock_updown / conv skip are not used by LeftRefill")
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.use_checkpoint = use_checkpoint
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.updown = False
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+                                       conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def _packed(self):
+        return engine_cache(self, "res", lambda: engine.PackedRes(self))
+
+    def _fwd(self, act, emb_out):
+        return engine.resblock(act, self._packed(), emb_out)
+
+    def forward(self, x, emb):
+        pr = self._packed()
+        e = ops.linear_small_m(emb.to(torch.float16).contiguous(), pr.emb.w, pr.emb.b, act_in=True)
+        out = self._fwd(engine.act_from_nchw(x), e)
+        return engine.act_to_nchw(out, self.out_channels).to(x.dtype)
+
+
+class UNetModel(nn.Module):
+    """SD UNet with spatial transformers; constructor kwargs as in the reference (openaimodel.py:442-472)."""
+
+    st_cls = SpatialTransformer
+    st_kwargs = {}
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 disable_self_attentions=None, num_attention_blocks=None, disable_middle_self_attn=False,
+                 use_linear_in_transformer=False):
+        super().__init__()
+        if not use_spatial_transformer or context_dim is None:
+            raise NotImplementedError("LeftRefill's UNet always uses the spatial transformer with a context_dim")
+        if num_classes is not None or n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
+            raise NotImplementedError("class-conditional / codebook / resblock_updown variants are out of scope")
+        if disable_self_attentions is not None or num_attention_blocks is not None or disable_middle_self_attn:
+            raise NotImplementedError("disable_self_attentions / num_attention_blocks are unused by LeftRefill")
+        if not isinstance(context_dim, int):
+            context_dim = list(context_dim)
+            assert len(context_dim) == 1 or transformer_depth == len(context_dim)
+        if num_heads == -1 and num_head_channels == -1:
+            raise AssertionError("Either num_heads or num_head_channels has to be set")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.transformer_depth = transformer_depth
+        self.num_res_blocks = len(channel_mult) * [num_res_blocks] if isinstance(num_res_blocks, int) \
+            else list(num_res_blocks)
+        if len(self.num_res_blocks) != len(channel_mult):
+            raise ValueError("provide num_res_blocks either as an int or as a per-level list")
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = th.float16 if use_fp16 else th.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.predict_codebook_ids = False
+
+        mc = model_channels
+        ted = mc * 4
+        self.time_embed = nn.Sequential(linear(mc, ted), nn.SiLU(), linear(ted, ted))
+
+        def heads_for(ch):
+            if num_head_channels == -1:
+                nh = num_heads
+                dh = ch // nh
+            else:
+                nh = ch // num_head_channels
+                dh = num_head_channels
+            if legacy:
+                dh = ch // nh
+            return nh, dh
+
+        def make_st(ch):
+            nh, dh = heads_for(ch)
+            return self.st_cls(ch, nh, dh, depth=transformer_depth, context_dim=context_dim,
+                               use_linear=use_linear_in_transformer, use_checkpoint=use_checkpoint, **self.st_kwargs)
+
+        def make_res(cin, cout):
+            return ResBlock(cin, ted, dropout, out_channels=cout, dims=dims, use_checkpoint=use_checkpoint)
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, mc, 3, padding=1))])
+        skip_chans = [mc]
+        ch, ds = mc, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                layers = [make_res(ch, mult * mc)]
+                ch = mult * mc
+                if ds in attention_resolutions:
+                    layers.append(make_st(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                skip_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims,
+                                                                            out_channels=ch)))
+                skip_chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(make_res(ch, ch), make_st(ch), make_res(ch, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(self.num_res_blocks[level] + 1):
+                layers = [make_res(ch + skip_chans.pop(), mc * mult)]
+                ch = mc * mult
+                if ds in attention_resolutions:
+                    layers.append(make_st(ch))
+                if level and i == self.num_res_blocks[level]:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(),
+                                 zero_module(conv_nd(dims, mc, out_channels, 3, padding=1)))
+        # engine state
+        self.use_hip_graph = True
+        self._plan = None
+        self._graphs = {}
+
+    # ------------------------------------------------------------------------------------------------------
+    # weight preparation: reference-shaped nn.Parameters -> packed fp16 kernel layouts (once, after loading)
+    # ------------------------------------------------------------------------------------------------------
+    def _sig(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def prepare(self, force=False):
+        """Pack all weights for the kernels; call again after (re)loading a state dict."""
+        sig = self._sig()
+        if self._plan is not None and not force and self._plan["sig"] == sig:
+            return self._plan
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("UNetModel runs on the HIP device only: call .to('cuda') first (no CPU fallback)")
+        E = engine
+        plan = {"sig": sig}
+        plan["t0"] = E.PackedLinear(self.time_embed[0])
+        plan["t2"] = E.PackedLinear(self.time_embed[2])
+        cin_pad = max(64, ((self.in_channels + 63) // 64) * 64)
+        plan["cin_pad"] = cin_pad
+        res_list = []
+
+        def pack_seq(seq):
+            steps = []
+            for layer in seq:
+                if isinstance(layer, ResBlock):
+                    pr = E.PackedRes(layer)
+                    res_list.append(pr)
+                    steps.append(("res", pr))
+                elif isinstance(layer, SpatialTransformer):
+                    steps.append(("st", E.PackedST(layer)))
+                elif isinstance(layer, Downsample):
+                    steps.append(("down", E.PackedConv(layer.op)))
+                elif isinstance(layer, Upsample):
+                    steps.append(("up", E.PackedConv(layer.conv)))
+                elif isinstance(layer, nn.Conv2d):
+                    steps.append(("conv", E.PackedConv(layer, cin_pad=cin_pad)))
+                else:
+                    raise TypeError(type(layer))
+            return steps
+
+        plan["input"] = [pack_seq(b) for b in self.input_blocks]
+        plan["middle"] = pack_seq(self.middle_block)
+        plan["output"] = [pack_seq(b) for b in self.output_blocks]
+        plan["out_norm"] = E.PackedNorm(self.out[0])
+        plan["out_conv"] = E.PackedConv(self.out[2])
+        # all emb_layers projections as one [sum Cout, 4*mc] weight (one launch per step instead of 22)
+        plan["emb_w"] = torch.cat([pr.emb.w for pr in res_list], 0).contiguous()
+        plan["emb_b"] = torch.cat([pr.emb.b for pr in res_list], 0).contiguous()
+        off = 0
+        for pr in res_list:
+            pr.emb_off = off
+            off += pr.cout
+        plan["emb_total"] = off
+        self._plan = plan
+        self._graphs = {}
+        return plan
+
+    # ------------------------------------------------------------------------------------------------------
+    def _run_plan(self, x, timesteps, context):
+        """x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,D] fp16 -> eps [N,Cout,H,W] fp16."""
+        P = self._plan
+        E = engine
+        N, _, H, W = x.shape
+        L = context.shape[1]
+        ctx = context.reshape(N * L, context.shape[2])
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels)
+        e = ops.linear_small_m(t_emb, P["t0"].w, P["t0"].b, act_out=True)
+        emb = ops.linear_small_m(e, P["t2"].w, P["t2"].b)
+        emb_all = ops.linear_small_m(emb, P["emb_w"], P["emb_b"], act_in=True)   # [N, sum Cout]
+
+        def run(steps, act):
+            for kind, p in steps:
+                if kind == "res":
+                    act = E.resblock(act, p, emb_all[:, p.emb_off:p.emb_off + p.cout])
+                elif kind == "st":
+                    act = E.spatial_transformer(act, ctx, L, p)
+                elif kind == "down":
+                    act = E.conv(act, p)
+                elif kind == "up":
+                    act = E.conv(act, p, up=1)
+                elif kind == "conv":
+                    act = E.conv(act, p)
+            return act
+
+        taps = self.__dict__.get("_lr_taps")   # debugging hook: {name: NCHW fp32 block output} (eager mode only)
+
+        def tap(name, a):
+            if taps is not None:
+                taps[name] = E.act_to_nchw(a, dtype=torch.float32)
+
+        act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"]), N, H, W)
+        hs = []
+        for i, steps in enumerate(P["input"]):
+            act = run(steps, act)
+            hs.append(act)
+            tap(f"in{i}", act)
+        act = run(P["middle"], act)
+        tap("mid", act)
+        for i, steps in enumerate(P["output"]):
+            skip = hs.pop()
+            act = run(steps, E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok))   # virtual th.cat([h, hs.pop()], 1)
+            tap(f"out{i}", act)
+        act = E.gn(act, P["out_norm"], True)
+        act = E.conv(act, P["out_conv"])
+        return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels, torch.float16)
+
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """eps = UNet(x, t, context).  Returns fp16 (the reference's output dtype under autocast, appendix B)."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        self.prepare()
+        x = x.float().contiguous()
+        timesteps = timesteps.to(torch.int64).contiguous()
+        context = context.to(torch.float16).contiguous()
+        if not self.use_hip_graph:
+            return self._run_plan(x, timesteps, context)
+        key = (tuple(x.shape), tuple(context.shape), x.device.index)
+        g = self._graphs.get(key)
+        if g is None:
+            g = _StepGraph(self, x, timesteps, context)
+            self._graphs[key] = g
+        return g.replay(x, timesteps, context)
+
+
+class _StepGraph:
+    """One captured hipGraph of the UNet forward for a fixed (x, context) shape."""
+
+    def __init__(self, model, x, t, ctx):
+        self.x = x.clone()
+        self.t = t.clone()
+        self.ctx = ctx.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model._run_plan(self.x, self.t, self.ctx)   # warm-up: kernel attributes / allocator pools
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model._run_plan(self.x, self.t, self.ctx)
+
+    def replay(self, x, t, ctx):
+        self.x.copy_(x)
+        self.t.copy_(t)
+        self.ctx.copy_(ctx)
+        self.graph.replay()
+        return self.out.clone()

@@ -89,8 +89,11 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float16)
-    _lib.check(lib.lr_linear_small_m(_p(a), K, _p(w), _p(bias), _p(out), N, M, N, K, int(act_in), int(act_out),
-                                     _stream()), "linear_small_m")
+    st = _stream()
+    for m0 in range(0, M, 16):   # the kernel keeps <= 16 rows in LDS; larger batches go in row chunks
+        mc = min(16, M - m0)
+        _lib.check(lib.lr_linear_small_m(a[m0:].data_ptr(), K, _p(w), _p(bias), out[m0:].data_ptr(), N, mc, N, K,
+                                         int(act_in), int(act_out), st), "linear_small_m")
     return out
 
 

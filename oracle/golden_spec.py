@@ -139,10 +139,12 @@ def op_oracle(name, kind, p, mode="fp32"):
 UNET_CASES = [
     ("unet_small_32x64", "SMALL", 2, 32, 64, [981, 1]),
     ("unet_small_16x32_b4", "SMALL", 4, 16, 32, [481, 481, 21, 21]),
+    ("unet_mid_16x32", "MID", 2, 16, 32, [981, 1]),
+    ("unet_mid_32x64_b4", "MID", 4, 32, 64, [481, 481, 21, 21]),
     ("unet_full_8x16", "FULL", 2, 8, 16, [981, 1]),
     ("unet_full_16x32", "FULL", 2, 16, 32, [501, 501]),
 ]
-CONFIGS = {"SMALL": unet_ref.SMALL, "FULL": unet_ref.FULL}
+CONFIGS = {"SMALL": unet_ref.SMALL, "MID": unet_ref.MID, "FULL": unet_ref.FULL}
 
 
 def unet_inputs(case, cfg, N, H, W, ts):
@@ -167,7 +169,7 @@ MV_CASES = [
 
 
 def mv_config(view_num, concat_target):
-    return unet_ref.UNetConfig(model_channels=64, num_head_channels=32, context_dim=128, multiview=True,
+    return unet_ref.UNetConfig(model_channels=128, num_head_channels=64, context_dim=256, multiview=True,
                                view_num=view_num, concat_target=concat_target)
 
 
@@ -175,3 +177,4 @@ def mv_config(view_num, concat_target):
 STEP_CASES = [("step_eta0", 50, 0.0, 17), ("step_eta1", 50, 1.0, 49), ("step_eta1_last", 10, 1.0, 0)]  # (case,S,eta,index)
 TRAJ_CASES = [("traj_s10", 10, 0.0, 1, 8, 16), ("traj_s50", 50, 0.0, 1, 8, 16), ("traj_s10_eta1_b2", 10, 1.0, 2, 8, 16)]
 CFG_SCALE = 2.5
+TRAJ_CONFIG = "MID"

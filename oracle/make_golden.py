@@ -196,10 +196,10 @@ def gen_sampler(ns):
         out[case + ".x_prev"] = x_prev.numpy()
         out[case + ".pred_x0"] = pred_x0.numpy()
     # G7 trajectories through LatentDiffusion.apply_model + DiffusionWrapper('hybrid') + reference UNet (SMALL)
-    cfg = unet_ref.SMALL
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
     ucfg = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": cfg.kwargs()}
     wrapper = ns.ddpm.DiffusionWrapper(ucfg, "hybrid")
-    _load(wrapper.diffusion_model, G.unet_state("SMALL"))
+    _load(wrapper.diffusion_model, G.unet_state(G.TRAJ_CONFIG))
     for case, S, eta, B, h, w in G.TRAJ_CASES:
         x_T = G.T(case + ".x_T", (B, 4, h, w))
         c_concat = G.T(case + ".c_concat", (B, 5, h, w))

@@ -62,8 +62,10 @@ class UNetConfig:
 
 
 FULL = UNetConfig()
-# reduced-width model used for whole-network / trajectory goldens
+# reduced-width models used for whole-network / trajectory goldens.  SMALL (d_head 32) is CPU-only; MID keeps the
+# kernels' constraints (channels multiple of 64, d_head 64) so the HIP path can run it too.
 SMALL = UNetConfig(model_channels=64, num_head_channels=32, context_dim=128)
+MID = UNetConfig(model_channels=128, num_head_channels=64, context_dim=256)
 
 
 # --------------------------------------------------------------------------------------

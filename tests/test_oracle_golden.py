@@ -63,8 +63,8 @@ def test_single_ddim_step(golden, case, S, eta, index):
 @pytest.mark.parametrize("case,S,eta,B,h,w", G.TRAJ_CASES, ids=[c[0] for c in G.TRAJ_CASES])
 def test_ddim_trajectory(golden, case, S, eta, B, h, w):
     g = golden("sampler")
-    cfg = unet_ref.SMALL
-    sd = G.unet_state("SMALL")
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    sd = G.unet_state(G.TRAJ_CONFIG)
     x_T = G.T(case + ".x_T", (B, 4, h, w))
     c_concat = G.T(case + ".c_concat", (B, 5, h, w))
     c_cross = G.T(case + ".c_cross", (B, 77, cfg.context_dim))
@@ -116,10 +116,11 @@ def _check_unet(golden, case, cname, N, H, W, ts, sd):
         assert abs(v.std().item() - std) < 1e-4 * std + 1e-5, k
 
 
-def test_unet_small(golden):
-    sd = G.unet_state("SMALL")
+@pytest.mark.parametrize("which", ["SMALL", "MID"])
+def test_unet_reduced_width(golden, which):
+    sd = G.unet_state(which)
     for case, cname, N, H, W, ts in G.UNET_CASES:
-        if cname == "SMALL":
+        if cname == which:
             _check_unet(golden, case, cname, N, H, W, ts, sd)
 
 
