@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Benchmark of LeftRefill's diffusion-sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+
+One "step" = one pass of the hot path over one batch: a full DDIM sampling run (S=50 steps, classifier-free guidance
+2.5, eta=1) of B=4 stitched 512x1024 canvases (latent 64x128, UNet batch 2B=8, fp16) through the drop-in entry point
+`inpainting_ldm.ref_inpainting_ldm.RefInpaintLDM.sample_log` -> `DDIMSampler.sample` -> hipGraph-replayed UNet step +
+fused CFG/DDIM update.  That is BASELINE.json configs[1].  With N GPUs every rank samples its own B=4 batch (weak
+scaling, no collective on the data path -- SURVEY.md section 8e); value = all images of all ranks / wall time.
+
+Synthetic data (no dataset, no SD2 weights in the reference): seeded normal weights with fan-in scaling, x_T ~ N(0,1),
+c_concat = [blocky right-half mask | 4 latent channels ~ N(0, 0.18215^2)], contexts ~ N(0,1) [77,1024].  The VAE and
+prompt encoder are outside the path (host PyTorch code) and outside the timed region.
+
+The printed JSON line also carries
+  roofline     : the dominant kernel family (implicit-GEMM conv/linear `gemm_conv_kernel`) timed live with HIP events on
+                 its launch stream in one instrumented eager UNet step: achieved = algorithmic FLOPs / sum of durations;
+  cpu_baseline : the CPU oracle (oracle/, fp32 torch, this box's host cores) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+UNET_PARAMS = dict(use_checkpoint=True, image_size=32, in_channels=9, out_channels=4, model_channels=320,
+                   attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64,
+                   use_spatial_transformer=True, use_linear_in_transformer=True, transformer_depth=1, context_dim=1024,
+                   legacy=False)  # check_points/ref_guided_inpainting/model_config.yaml:20-36
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+S_DDIM, CFG, ETA = 50, 2.5, 1.0
+
+
+def build_model(device):
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
+    model = RefInpaintLDM(first_stage_config={"target": "torch.nn.Identity"},
+                          cond_stage_config={"target": "torch.nn.Identity"},
+                          unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                       "params": dict(UNET_PARAMS)},
+                          conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
+                          timesteps=1000, channels=4, image_size=64, first_stage_key="image", cond_stage_key="txt",
+                          data_config={"img_size": 512})
+    model = model.to(device).eval()
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.model.diffusion_model.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, device=device, generator=g) * (1.0 / fan_in) ** 0.5)
+            elif name.endswith(".weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, device=device, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, device=device, generator=g))
+    model.model.diffusion_model.prepare()
+    return model
+
+
+def synthetic_batch(B, h, w, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    mask = torch.zeros(B, 1, h, w, device=device)
+    blocks = (torch.rand(B, 1, h // 8, w // 16, device=device, generator=g) < 0.5).float()
+    mask[:, :, :, w // 2:] = torch.nn.functional.interpolate(blocks, size=(h, w // 2), mode="nearest")
+    lat = torch.randn(B, 4, h, w, device=device, generator=g) * 0.18215
+    c_concat = torch.cat([mask, lat], dim=1)
+    c_cross = torch.randn(B, 77, 1024, device=device, generator=g)
+    uc_cross = torch.randn(B, 77, 1024, device=device, generator=g)
+    x_T = torch.randn(B, 4, h, w, device=device, generator=g)
+    return c_concat, c_cross, uc_cross, x_T
+
+
+def sample_once(model, batch, B):
+    c_concat, c_cross, uc_cross, x_T = batch
+    cond = {"c_concat": [c_concat], "c_crossattn": [c_cross]}
+    uc = {"c_concat": [c_concat], "c_crossattn": [uc_cross]}
+    samples, _ = model.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=S_DDIM, eta=ETA,
+                                  unconditional_guidance_scale=CFG, unconditional_conditioning=uc, x_T=x_T)
+    return samples
+
+
+def kernel_roofline(model, batch, B):
+    """One instrumented eager UNet step: HIP events around every gemm_conv / attention launch on the launch stream."""
+    from leftrefill_amd import ops
+    from leftrefill_amd.flops import unet_flops
+    unet = model.model.diffusion_model
+    c_concat, c_cross, uc_cross, x_T = batch
+    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+    t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
+    ctx = torch.cat([uc_cross, c_cross]).half()
+    rec = {"gemm_conv": [], "attention": []}
+    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention}
+
+    def wrap(name):
+        def f(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()          # torch.cuda.current_stream() == the stream the kernel is launched on (ops._stream)
+            out = orig[name](*a, **k)
+            e1.record()
+            rec[name].append((e0, e1))
+            return out
+        return f
+
+    unet.use_hip_graph = False
+    try:
+        for _ in range(2):
+            for k in rec:
+                rec[k].clear()
+            ops.gemm_conv, ops.attention = wrap("gemm_conv"), wrap("attention")
+            with torch.no_grad():
+                unet(x, t, ctx)
+            torch.cuda.synchronize()
+    finally:
+        ops.gemm_conv, ops.attention = orig["gemm_conv"], orig["attention"]
+        unet.use_hip_graph = True
+    fl = unet_flops(unet, x.shape[2], x.shape[3])
+    n = 2 * B
+    out = {}
+    for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
+        ms = sum(a.elapsed_time(b) for a, b in rec[name])
+        out[name] = {"launches": len(rec[name]), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(rec[name])),
+                     "tflops": n * fl[key] / (ms * 1e-3) / 1e12}
+    return out, fl
+
+
+def cpu_baseline():
+    """Oracle (fp32 torch CPU restatement) on a bounded sample: ONE CFG UNet step (N=2) at latent 64x128."""
+    from oracle import unet_ref
+    cfg = unet_ref.FULL
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in unet_ref.param_shapes(cfg).items():
+        if len(shp) >= 2:
+            fan = 1
+            for s in shp[1:]:
+                fan *= s
+            sd[k] = torch.randn(shp, generator=g) * (1.0 / fan) ** 0.5
+        elif k.endswith(".weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = 0.02 * torch.randn(shp, generator=g)
+    x = torch.randn(2, 9, 64, 128, generator=g)
+    ctx = torch.randn(2, 77, 1024, generator=g)
+    t = torch.tensor([501, 501])
+    t0 = time.time()
+    unet_ref.unet_forward(sd, cfg, x, t, ctx)
+    dt = time.time() - t0
+    return {"value": 1.0 / (S_DDIM * dt), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 CFG UNet step (batch 2) at latent 64x128 with the fp32 torch CPU oracle: {dt:.2f} s/step, "
+                      f"extrapolated x{S_DDIM} steps per image",
+            "s_per_unet_step_b2": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="user batch B per GPU (UNet batch 2B under CFG)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    B, h, w = a.batch, 64, 128
+
+    model = build_model(device)
+    batch = synthetic_batch(B, h, w, device, 1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sample_once(model, batch, B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = sample_once(model, batch, B)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(out).all()
+    ms_per_step = 1e3 * dt / a.steps
+    images_per_s = world * B * a.steps / dt
+    unet_step_ms = ms_per_step / S_DDIM     # per DDIM iteration (UNet step at batch 2B + fused update), incl. host loop
+
+    res = {"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": images_per_s,
+           "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "configs[1]: 1-ref inpainting, 512x1024 canvas (latent 64x128), B=4 per GPU "
+                                  "(UNet batch 8 under CFG), 50 DDIM steps, cfg=2.5, eta=1.0, fp16",
+                      "global_batch": world * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
+                      "parallelism": f"dp{world} (sample-sharded, no data-path collective)"},
+           "per_unet_step_ms": unet_step_ms}
+
+    if rank == 0 and not a.no_roofline:
+        kern, fl = kernel_roofline(model, batch, B)
+        g = kern["gemm_conv"]
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> (implicit-GEMM conv3x3/1x1/linear)",
+                           "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                           "launches_per_unet_step": g["launches"], "avg_launch_us": g["avg_us"],
+                           "algorithmic_gflop_per_unet_step": 2 * B * fl["gemm"] / 1e9}
+        step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
+        res["kernels"] = {"attention_kernel": kern["attention"],
+                          "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
+                                        "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

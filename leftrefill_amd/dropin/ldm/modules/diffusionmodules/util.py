@@ -48,9 +48,11 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     a32 = ac32[ddim_timesteps]
     alphas = a32.astype(np.float64)
     alphas_prev = np.concatenate([ac32[:1], ac32[ddim_timesteps[:-1]]]).astype(np.float64)
-    one_minus_a = (np.float32(1) - a32).astype(np.float64)
-    ratio = (a32.astype(np.float64) / alphas_prev)
-    sigmas = eta * np.sqrt((1 - alphas_prev) / one_minus_a * (1 - ratio))
+    # The reference evaluates (1 - a_prev) / (1 - a_t) with a_t an fp32 *tensor*: numpy defers to
+    # Tensor.__rtruediv__, i.e. an fp32 reciprocal of (1 - a_t) times the float64 numerator.  Reproduced bit for bit.
+    recip32 = (np.float32(1) / (np.float32(1) - a32)).astype(np.float32)
+    ratio = a32.astype(np.float64) / alphas_prev
+    sigmas = eta * np.sqrt((1 - alphas_prev) * recip32.astype(np.float64) * (1 - ratio))
     if verbose:
         print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
         print(f"For the chosen value of eta, which is {eta}, this results in the following sigma_t schedule "
