@@ -87,7 +87,7 @@ def sample_once(model, batch, B):
     return samples
 
 
-def kernel_roofline(model, batch, B):
+def kernel_roofline(model, batch, B, dump=None):
     """One instrumented eager UNet step: HIP events around every gemm_conv / attention launch on the launch stream."""
     from leftrefill_amd import ops
     from leftrefill_amd.flops import unet_flops
@@ -105,7 +105,13 @@ def kernel_roofline(model, batch, B):
             e0.record()          # torch.cuda.current_stream() == the stream the kernel is launched on (ops._stream)
             out = orig[name](*a, **k)
             e1.record()
-            rec[name].append((e0, e1))
+            if name == "gemm_conv":
+                desc = dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[0], K=a[1].shape[1], taps=k.get("taps", 1),
+                            stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
+                            cat=k.get("x2") is not None)
+            else:
+                desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
+            rec[name].append((e0, e1, desc))
             return out
         return f
 
@@ -125,9 +131,22 @@ def kernel_roofline(model, batch, B):
     n = 2 * B
     out = {}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
-        ms = sum(a.elapsed_time(b) for a, b in rec[name])
+        ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
         out[name] = {"launches": len(rec[name]), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(rec[name])),
                      "tflops": n * fl[key] / (ms * 1e-3) / 1e12}
+    if dump:
+        rows = []
+        for name in rec:
+            for a, b, d in rec[name]:
+                us = 1e3 * a.elapsed_time(b)
+                if name == "gemm_conv":
+                    fl_ = 2.0 * d["M"] * d["N"] * d["K"]
+                else:
+                    fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
+                rows.append(dict(kernel=name, us=us, tflops=fl_ / us / 1e6, **d))
+        with open(dump, "w") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
     return out, fl
 
 
@@ -167,6 +186,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="user batch B per GPU (UNet batch 2B under CFG)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -219,7 +239,7 @@ def main():
            "per_unet_step_ms": unet_step_ms}
 
     if rank == 0 and not a.no_roofline:
-        kern, fl = kernel_roofline(model, batch, B)
+        kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)
         g = kern["gemm_conv"]
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> (implicit-GEMM conv3x3/1x1/linear)",
                            "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

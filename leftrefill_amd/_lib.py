@@ -60,6 +60,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) and owns the
+    # streams we launch on; loading our library afterwards binds its libamdhip64 dependency to that same runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m leftrefill_amd.build` (hipcc --offload-arch=gfx950). "

@@ -1,0 +1,230 @@
+"""CPU: C-ABI surface, host-side logic of the drop-in (schedules, packing, state-dict contract, sharding)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "leftrefill_hip.h")).read()
+    return sorted(set(re.findall(r"^int (lr_\w+)\(", src, flags=re.M)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from leftrefill_amd import _lib, build
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/leftrefill_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
+    assert _lib.load().lr_abi_version() == _lib.ABI_VERSION
+
+
+def test_gemm_args_struct_layout_matches_header():
+    """sizeof/offsets of lr_gemm_args as the C compiler lays it out vs the ctypes mirror."""
+    import subprocess, tempfile
+    from leftrefill_amd._lib import GemmArgs
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "leftrefill_hip.h"
+int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lr_gemm_args), offsetof(lr_gemm_args, wt),
+  offsetof(lr_gemm_args, bias), offsetof(lr_gemm_args, resid), offsetof(lr_gemm_args, out), offsetof(lr_gemm_args, tile_n)); }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")],
+                       check=True)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
+    got = [ctypes.sizeof(GemmArgs), GemmArgs.wt.offset, GemmArgs.bias.offset, GemmArgs.resid.offset,
+           GemmArgs.out.offset, GemmArgs.tile_n.offset]
+    assert [int(v) for v in out] == got
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from leftrefill_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libleftrefill_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.load()
+
+
+def test_ops_reject_cpu_tensors():
+    from leftrefill_amd import ops
+    with pytest.raises(AssertionError):
+        ops.layer_norm(torch.zeros(4, 64, dtype=torch.float16), torch.ones(64), torch.zeros(64))
+
+
+def test_dropin_schedule_tables_bit_exact(golden):
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ddpm import DDPM
+    g = golden("sampler")
+    m = DDPM({"target": "torch.nn.Identity"}, conditioning_key="hybrid", linear_start=0.00085, linear_end=0.0120)
+    assert np.array_equal(m.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    assert m.num_timesteps == 1000 and m.parameterization == "eps"
+    for S in (10, 50):
+        for eta in (0.0, 1.0):
+            s = DDIMSampler(m)
+            s.make_schedule(S, ddim_eta=eta, verbose=False)
+            tag = f"sched_S{S}_eta{int(eta)}"
+            assert np.array_equal(s.ddim_timesteps, g[tag + ".timesteps"])
+            for k, a in (("alphas", s.ddim_alphas), ("alphas_prev", s.ddim_alphas_prev), ("sigmas", s.ddim_sigmas),
+                         ("sqrt_one_minus_alphas", s.ddim_sqrt_one_minus_alphas)):
+                assert np.array_equal(np.asarray(a, dtype=np.float64), g[f"{tag}.{k}"]), (tag, k)
+
+
+def test_dropin_timestep_embedding_host_branch(golden):
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    out = timestep_embedding(torch.tensor([1, 21, 481, 981]), 320).numpy()
+    np.testing.assert_allclose(out, golden("ops")["timestep_embedding_320"], rtol=0, atol=2e-6)
+
+
+def test_state_dict_contract_full_config():
+    """686 tensors, reference names and shapes -- built on the meta device."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    with torch.device("meta"):
+        m = UNetModel(**unet_ref.FULL.kwargs())
+    sd = m.state_dict()
+    shapes = unet_ref.param_shapes(unet_ref.FULL)
+    assert len(sd) == 686 and set(sd) == set(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert sd["input_blocks.0.0.weight"].shape == (320, 9, 3, 3)
+    assert sd["input_blocks.4.0.skip_connection.weight"].shape == (640, 320, 1, 1)
+    assert sum(v.numel() for v in sd.values()) == 865_925_124
+    from leftrefill_amd.flops import unet_flops
+    f = unet_flops(m, 64, 128)
+    assert abs(f["total"] / 1e9 - 1849.75) < 0.01 and abs(f["attn"] / 1e9 - 497.09) < 0.01
+
+
+def test_pack_conv_layout():
+    from leftrefill_amd import packing
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(8, 5, 3, 3, generator=g)
+    x = torch.randn(2, 5, 6, 7, generator=g)
+    wp = packing.pack_conv(w, cin_pad=8, cout_pad=8).float()          # [8, 9*8], k = tap*8 + c
+    cols = F.unfold(F.pad(x, (0, 0, 0, 0, 0, 3)), 3, padding=1)        # [2, 8*9, 42], row = c*9 + tap
+    cols = cols.reshape(2, 8, 9, 42).permute(0, 2, 1, 3).reshape(2, 72, 42)   # -> tap*8 + c
+    y = torch.einsum("nk,bkp->bnp", wp, cols.half().float()).reshape(2, 8, 6, 7)
+    ref = F.conv2d(x.half().float(), w.half().float(), padding=1)
+    assert torch.allclose(y, ref, atol=1e-4)
+
+
+def test_geglu_permutation():
+    from leftrefill_amd import packing
+    perm = packing.geglu_perm(64)
+    assert sorted(perm.tolist()) == list(range(128))
+    assert perm[:16].tolist() == list(range(16)) and perm[16:32].tolist() == list(range(64, 80))
+    assert perm[32:48].tolist() == list(range(16, 32))
+
+
+def test_dropin_rejects_unsupported_variants():
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.openaimodel import ResBlock, UNetModel
+    with pytest.raises(NotImplementedError):
+        ResBlock(64, 256, 0, use_scale_shift_norm=True)
+    kw = unet_ref.MID.kwargs()
+    kw["num_classes"] = 10
+    with pytest.raises(NotImplementedError):
+        UNetModel(**kw)
+
+
+def test_create_model_from_yaml(tmp_path):
+    """inpainting_ldm.model.create_model on a YAML with dotted-path targets (the plugin mechanism)."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.model import create_model
+    cfg = tmp_path / "m.yaml"
+    cfg.write_text("""
+model:
+  target: inpainting_ldm.ref_inpainting_ldm.RefInpaintLDM
+  params:
+    linear_start: 0.00085
+    linear_end: 0.0120
+    timesteps: 1000
+    first_stage_key: image
+    cond_stage_key: txt
+    channels: 4
+    conditioning_key: hybrid
+    scale_factor: 0.18215
+    use_ema: False
+    unet_config:
+      target: ldm.modules.diffusionmodules.openaimodel.UNetModel
+      params: {use_checkpoint: True, image_size: 32, in_channels: 9, out_channels: 4, model_channels: 64,
+               attention_resolutions: [2, 1], num_res_blocks: 1, channel_mult: [1, 2], num_head_channels: 64,
+               use_spatial_transformer: True, use_linear_in_transformer: True, transformer_depth: 1,
+               context_dim: 128, legacy: False}
+    first_stage_config: {target: torch.nn.Identity}
+    cond_stage_config: {target: torch.nn.Identity, params: {}}
+    data_config: {img_size: 512, cfg: 2.5}
+    save_prompt_only: True
+""")
+    m = create_model(str(cfg))
+    assert type(m).__name__ == "RefInpaintLDM" and m.save_prompt_only and m.img_size == 512
+    assert m.concat_keys == ("mask", "masked_image") and m.masked_image_key == "masked_image" and m.channels == 4
+    assert any(k.startswith("model.diffusion_model.input_blocks.0.0") for k in m.state_dict())
+
+
+# ---- world_size-2 gloo test of the sample sharding ---------------------------------------------------------------
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from leftrefill_amd import dist as lrd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 5   # ragged: 3 + 2
+    cond = {"c_concat": [torch.arange(B * 2.).reshape(B, 2)], "c_crossattn": [torch.arange(B * 3.).reshape(B, 3) + 100]}
+    x_T = torch.arange(B * 4.).reshape(B, 4)
+
+    def fake_sampler(c, uc, xt, b):
+        assert c["c_concat"][0].shape[0] == b == xt.shape[0] == uc["c_crossattn"][0].shape[0]
+        return xt * 2 + c["c_concat"][0].sum(1, keepdim=True) + c["c_crossattn"][0].sum(1, keepdim=True)
+
+    out = lrd.sample_sharded(fake_sampler, cond, cond, x_T, B)
+    full = fake_sampler(cond, cond, x_T, B)
+    q.put((rank, bool(torch.equal(out, full)), lrd.shard_range(B, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_sample_sharding_gloo_world2():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res[0] == (0, True, (0, 3)) and res[1] == (1, True, (3, 5))
+
+
+def test_shard_range_partitions():
+    from leftrefill_amd.dist import shard_range
+    for total in (1, 4, 7, 32):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
