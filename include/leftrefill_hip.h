@@ -93,7 +93,14 @@ typedef struct lr_gemm_args {
   lr_half* out; int32_t ld_out;             /* [M][ld_out] */
   int32_t geglu;
   int32_t tile_n;           /* 0 = auto; 64 | 128 */
+  /* split-K (small-M shapes that cannot fill 256 CUs): fp32 partial tiles go to `workspace`
+   * [splits][M][N] and a second launch reduces them in a fixed order and applies the epilogue.
+   * splits: 0 = auto, 1 = off.  workspace may be NULL (=> no split).  Not available with geglu. */
+  int32_t splits;
+  float* workspace; int64_t workspace_bytes;
 } lr_gemm_args;
+/* bytes of workspace lr_gemm_conv_f16 would like for this problem (0 if it will not split) */
+int64_t lr_gemm_workspace_bytes(const lr_gemm_args* args);
 int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
 
 /* ---- fused scaled-dot-product attention (flash-style, d_head = 64) ---------------------------------------------

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -28,6 +28,8 @@ class GemmArgs(ctypes.Structure):
         ("out", c_void_p), ("ld_out", ctypes.c_int32),
         ("geglu", ctypes.c_int32),
         ("tile_n", ctypes.c_int32),
+        ("splits", ctypes.c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -43,6 +45,7 @@ SIGNATURES = {
     "lr_timestep_embedding": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "lr_linear_small_m": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_void_p],
+    "lr_gemm_workspace_bytes": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_conv_f16": [ctypes.POINTER(GemmArgs), c_void_p],
     "lr_attention_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_float, c_void_p],
@@ -71,7 +74,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name == "lr_gemm_workspace_bytes" else c_int
     v = lib.lr_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libleftrefill_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")

@@ -24,6 +24,7 @@ struct GemmParams {
   const f16* p1; const f16* p2; const f16* wt; const float* bias; const f16* rowvec; const f16* resid; f16* out;
   int C1, C2, H, W, Hs, Ws, taps, stride, up, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
   int ntiles_n, nblocks;
+  int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
   }
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
   const int cpt = (P.C1 + P.C2) >> 6;   // 64-channel chunks per tap
-  const int nk = P.taps * cpt;
+  const int nk_all = P.taps * cpt;
+  const int k_per = (nk_all + P.splits - 1) / P.splits;
+  const int k_begin = blockIdx.y * k_per;
+  const int nk = min(nk_all, k_begin + k_per);   // this block runs K-steps [k_begin, nk)
   const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
 
   auto stage = [&](int buf, int kt) {
@@ -115,11 +119,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  if (k_begin < nk) stage(0, k_begin);
   __syncthreads();
   int cur = 0;
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = k_begin; kt < nk; ++kt) {
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* As = smem + cur * STAGE;
     const char* Bs = As + A_BYTES;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * (BN / 2) + j * 16 + fq * 4;
       f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+      if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int ml = wm * 64 + i * 16 + fr;
@@ -197,7 +201,48 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
     float v[8];
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
+    if (P.splits > 1) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
+      float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
+      *reinterpret_cast<f32x4*>(dst) = c0;
+      *reinterpret_cast<f32x4*>(dst + 4) = c1;
+      continue;
+    }
     v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+    if (P.rowvec) {
+      float e[8];
+      lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += e[i];
+    }
+    if (P.resid) {
+      float e[8];
+      lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += e[i];
+    }
+    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+  }
+}
+
+// Fixed-order reduction of the split-K partials + the fused epilogue (deterministic: no atomics).
+__global__ void splitk_reduce_kernel(const GemmParams P) {
+  const int cpr = P.N >> 3;
+  const long long total = (long long)P.M * cpr;
+  for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total;
+       id += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(id / cpr), n = (int)(id - (long long)m * cpr) * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    for (int sidx = 0; sidx < P.splits; ++sidx) {
+      const float* src = P.ws + ((size_t)sidx * P.M + m) * P.N + n;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    if (P.bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += P.bias[n + i];
+    }
     if (P.rowvec) {
       float e[8];
       lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
@@ -231,8 +276,36 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
                                                                                       : (size_t)BM * (BN + 4) * 4));
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks), dim3(GEMM_THREADS), smem, st, P);
+  hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
+  int rc = lr_launch_status();
+  if (rc || P.splits == 1) return rc;
+  long long chunks = (long long)P.M * (P.N >> 3);
+  int grid = (int)((chunks + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P);
   return lr_launch_status();
+}
+
+// split-K heuristic: only when the tile grid cannot fill the chip (256 CUs x 2 resident blocks) and K is long.
+static int choose_splits(int M, int N, int K, int tn, int geglu) {
+  if (geglu) return 1;
+  const int tiles = ((M + BM - 1) / BM) * ((N + tn - 1) / tn);
+  const int nk = K / BK;
+  if (tiles >= 256 || nk < 32) return 1;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > 8) s = 8;
+  if (s > nk / 8) s = nk / 8;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
+  if (!a) return 0;
+  const int M = a->B * a->H * a->W;
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  int tn = a->tile_n;
+  if (tn == 0) tn = (a->N % 128 == 0) ? 128 : 64;
+  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tn, a->geglu);
+  return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
@@ -264,7 +337,18 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     return LR_E_ALIGN;
   int tn = a->tile_n;
   if (tn == 0) tn = (P.N % 128 == 0) ? 128 : 64;
-  if (P.geglu && tn == 64 && false) return LR_E_UNSUPPORTED;
+  int splits = a->splits;
+  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tn, P.geglu);
+  if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
+  if (splits > 1) {
+    const int64_t need = (int64_t)splits * P.M * P.N * (int64_t)sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) {
+      if (a->splits > 1) return LR_E_ARG;   // explicitly requested but no room
+      splits = 1;
+    }
+  }
+  P.splits = splits;
+  P.ws = a->workspace;
   hipStream_t st = (hipStream_t)s;
   if (tn == 128) return launch_gemm<128>(P, st);
   if (tn == 64) return launch_gemm<64>(P, st);

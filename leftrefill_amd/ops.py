@@ -98,7 +98,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, out=None, tile_n=0):
+              resid=None, geglu=False, out=None, tile_n=0, splits=0):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
     lib = _lib.load()
     _chk16(x1, "x1")
@@ -132,6 +132,12 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=N
     a.out, a.ld_out = _p(out), out.stride(0)
     a.geglu = int(geglu)
     a.tile_n = tile_n
+    a.splits = splits
+    a.workspace, a.workspace_bytes = 0, 0
+    need = lib.lr_gemm_workspace_bytes(a)
+    if need > 0:   # split-K partials (small-M shapes); the caller owns the workspace
+        ws = torch.empty(need // 4, device=x1.device, dtype=torch.float32)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
     _lib.check(lib.lr_gemm_conv_f16(a, _stream()), "gemm_conv")
     return out
 

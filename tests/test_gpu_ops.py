@@ -175,6 +175,21 @@ def test_conv3x3_variants():
     _conv_case("c3_m_tail", 1, 128, 64, 5, 9)  # M = 45 < tile
 
 
+def test_conv_split_k():
+    """Small-M / long-K shapes take the split-K path (fp32 partials + fixed-order reduce)."""
+    from leftrefill_amd import ops
+    _conv_case("c3_splitk_auto", 2, 1280, 1280, 8, 16, rowvec=True, resid=True)       # M=256, K=11520 -> auto split
+    _conv_case("c3_splitk_cat", 1, 1280, 640, 8, 16, C2=1280)                          # K=23040
+    d = dev()
+    x = h16(G.T("sk.x", (256, 2560))).half().to(d)
+    w = h16(torch.from_numpy(weights.fill_like("sk.w", (256, 2560)))).half().to(d)
+    ys = [ops.gemm_conv(x, w, B=1, H=1, W=256, taps=1, splits=s_) for s_ in (1, 2, 5)]
+    ref = F.linear(x.float().cpu(), w.float().cpu())
+    for y in ys:
+        report("splitk explicit", y, ref)
+    assert torch.equal(ops.gemm_conv(x, w, B=1, H=1, W=256, taps=1, splits=5), ys[2]), "split-K must be deterministic"
+
+
 def test_conv_golden_cases(golden):
     """The reference-generated operator goldens (G3) for the conv family."""
     from leftrefill_amd import ops, packing

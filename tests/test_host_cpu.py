@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "leftrefill_hip.h")).read()
-    return sorted(set(re.findall(r"^int (lr_\w+)\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t) (lr_\w+)\(", src, flags=re.M)))
 
 
 def test_abi_library_exports_every_declared_symbol():
