@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -28,6 +28,7 @@ class GemmArgs(ctypes.Structure):
         ("out", c_void_p), ("ld_out", ctypes.c_int32),
         ("geglu", ctypes.c_int32),
         ("tile_n", ctypes.c_int32),
+        ("tile_m", ctypes.c_int32),
         ("splits", ctypes.c_int32),
         ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]

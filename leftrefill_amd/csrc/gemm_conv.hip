@@ -224,6 +224,266 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
   }
 }
 
+// =====================================================================================================================
+// 256 x BN tile, 8 waves (4 x 2), 3-stage LDS-DMA pipeline with counted vmcnt and raw barriers.
+//
+// Why: at 128 x 128 x 64 the block moves 32 KB L2->LDS per 2.1 MFLOP; at full MFMA rate that is ~36 TB/s chip-wide,
+// i.e. the per-XCD L2s, not the matrix cores, are the roof.  256 x 160 moves 52 KB per 5.2 MFLOP (1.55x less traffic
+// per flop; 2.3x less than the 128 x 64 tile used for N = 320) and BN = 160 divides every channel count of the model.
+// One 8-wave block per CU cannot hide a vmcnt(0)+barrier drain behind another block, so the loads run two K-steps ahead:
+//   wait(vmcnt = loads of the NEXT stage still in flight) -> s_barrier -> issue stage kt+2 -> ds_read/MFMA on stage kt.
+// The gather addresses are kept per row as a base pointer + validity bit and only recomputed when the tap or the
+// concat source changes (every C/64 K-steps); inside a tap the K-step offset is a scalar add.
+// =====================================================================================================================
+#define BM2 256
+#define GEMM2_THREADS 512
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN>
+__global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
+  constexpr int TM = 4;                 // wave tile 64 rows
+  constexpr int TN = BN / 32;           // wave tile BN/2 cols  (4 for 128, 5 for 160)
+  constexpr int A_BYTES = BM2 * 128;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NB_FULL = BN / 64;      // B staging instructions issued by every wave
+  constexpr bool B_TAIL = (BN % 64) != 0;  // one more instruction for waves 0..3 (rows 128..159 when BN = 160)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % P.ntiles_n, tile_m = bid / P.ntiles_n;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN;
+
+  const int HW = P.H * P.W;
+  int rb[4], ry[4], rx[4];
+  const int slot = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 8 + w) * 8 + (lane >> 3);
+    const int m = m0 + row;
+    if (m < P.M) {
+      const int b = m / HW, rem = m - b * HW;
+      const int y = rem / P.W, x = rem - y * P.W;
+      rb[i] = b * P.Hs * P.Ws;
+      ry[i] = y * P.stride;
+      rx[i] = x * P.stride;
+    } else {
+      rb[i] = 0; ry[i] = -(1 << 20); rx[i] = -(1 << 20);
+    }
+  }
+  const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
+  const int cpt = (P.C1 + P.C2) >> 6;
+  const int cpt1 = P.C1 >> 6;
+  const int nk_all = P.taps * cpt;
+  const int k_per = (nk_all + P.splits - 1) / P.splits;
+  const int k_begin = blockIdx.y * k_per;
+  const int nk = min(nk_all, k_begin + k_per);
+  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
+
+  // weight row pointers (fixed over K): instr i covers rows (i*8 + w)*8 + lane/8
+  const f16* wrow[NB_FULL + 1];
+#pragma unroll
+  for (int i = 0; i < NB_FULL + 1; ++i) {
+    const int row = (i * 8 + w) * 8 + (lane >> 3);
+    const int n = n0 + row;
+    const int chunk = slot ^ ((row >> 1) & 7);
+    wrow[i] = (row < BN && n < P.N) ? P.wt + (size_t)n * P.K + chunk * 8 : nullptr;
+  }
+
+  // gather state: per-row base pointer of the current (tap, source) segment
+  const f16* aptr[4];
+  unsigned amask = 0;
+  int seg_tap = -1, seg_src = -1;
+  auto stage = [&](int buf, int kt) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_BYTES;
+    const int tap = kt / cpt, cc = kt - tap * cpt;
+    const int srcsel = cc < cpt1 ? 0 : 1;
+    if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing the concat boundary
+      seg_tap = tap; seg_src = srcsel;
+      int dy = 0, dx = 0;
+      if (P.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      const f16* src = srcsel ? P.p2 : P.p1;
+      const int cs = srcsel ? P.C2 : P.C1;
+      amask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + w) * 8 + (lane >> 3);
+        const int iy = ry[i] + dy, ix = rx[i] + dx;
+        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+        const int sy = iy >> P.up, sx = ix >> P.up;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        aptr[i] = src + (size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8;
+        amask |= ok ? (1u << i) : 0u;
+      }
+    }
+    const int coff = (srcsel ? cc - cpt1 : cc) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16* g = (amask >> i) & 1 ? aptr[i] + coff : zero;
+      glds16(g, As + ((i * 8 + w) * 8) * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < NB_FULL; ++i) {
+      const f16* g = wrow[i] ? wrow[i] + kt * 64 : zero;
+      glds16(g, Bs + ((i * 8 + w) * 8) * 128);
+    }
+    if (B_TAIL && w < 4) {
+      const f16* g = wrow[NB_FULL] ? wrow[NB_FULL] + kt * 64 : zero;
+      glds16(g, Bs + ((NB_FULL * 8 + w) * 8) * 128);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (k_begin < nk) stage(0, k_begin);
+  if (k_begin + 1 < nk) stage(1, k_begin + 1);
+  const int fr = lane & 15, fq = lane >> 4;
+  int cur = 0;
+  for (int kt = k_begin; kt < nk; ++kt) {
+    // retire stage kt (this wave's part); stage kt+1 may stay in flight across the barrier
+    if (kt + 1 < nk) {
+      if (B_TAIL && w < 4) wait_vmcnt<4 + NB_FULL + 1>(); else wait_vmcnt<4 + NB_FULL>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);   // buffer (cur + 2) % 3, last read in iteration kt-1
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[TM], wf[TN];
+      const int kc = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        xf[i] = *reinterpret_cast<const f16x8*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();   // every wave is done with the stage buffers before they become the epilogue tile
+
+  // ---- epilogue in two passes of 128 rows (fp32 tile in LDS: 128 x (BNo + 4) floats <= 84 KB)
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int BNo = P.geglu ? BN / 2 : BN;
+  const int ldc = BNo + 4;
+  const int n_out0 = P.geglu ? n0 / 2 : n0;
+  const int N_out = P.geglu ? P.N / 2 : P.N;
+  const int cpr = BNo >> 3;
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((wm >> 1) == pass) {
+      const int wml = wm & 1;
+      if (!P.geglu) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nl = wn * (BN / 2) + j * 16 + fq * 4;
+          f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ml = wml * 64 + i * 16 + fr;
+            *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
+          }
+        }
+      } else if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+          const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;
+          f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
+          if (P.bias && n0 + nl_u + 16 < P.N) {
+            bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
+            bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
+          }
+          const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ml = wml * 64 + i * 16 + fr;
+            const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
+            *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int id = t; id < 128 * cpr; id += GEMM2_THREADS) {
+      const int row = id / cpr, cch = id - row * cpr;
+      const int m = m0 + pass * 128 + row, n = n_out0 + cch * 8;
+      if (m >= P.M || n >= N_out) continue;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
+      if (P.splits > 1) {
+        float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
+        *reinterpret_cast<f32x4*>(dst) = c0;
+        *reinterpret_cast<f32x4*>(dst + 4) = c1;
+        continue;
+      }
+      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      if (P.rowvec) {
+        float e[8];
+        lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      if (P.resid) {
+        float e[8];
+        lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+    }
+    __syncthreads();
+  }
+}
+
+template <int BN>
+static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
+  GemmParams P = P0;
+  P.ntiles_n = (P.N + BN - 1) / BN;
+  const int ntm = (P.M + BM2 - 1) / BM2;
+  P.nblocks = P.ntiles_n * ntm;
+  size_t smem = 3 * (size_t)(BM2 + BN) * 128;
+  const size_t epi = (size_t)128 * (BN + 4) * sizeof(float);
+  if (epi > smem) smem = epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_conv256_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
+  return lr_launch_status();
+}
+
 // Fixed-order reduction of the split-K partials + the fused epilogue (deterministic: no atomics).
 __global__ void splitk_reduce_kernel(const GemmParams P) {
   const int cpr = P.N >> 3;
@@ -277,8 +537,10 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
-  int rc = lr_launch_status();
-  if (rc || P.splits == 1) return rc;
+  return lr_launch_status();
+}
+
+static int launch_reduce(const GemmParams& P, hipStream_t st) {
   long long chunks = (long long)P.M * (P.N >> 3);
   int grid = (int)((chunks + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -287,12 +549,29 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
 }
 
 // split-K heuristic: only when the tile grid cannot fill the chip (256 CUs x 2 resident blocks) and K is long.
-static int choose_splits(int M, int N, int K, int tn, int geglu) {
+static void choose_tile(int M, int N, int geglu, int* tm, int* tn) {
+  // explicit requests win; otherwise: the 256-row 8-wave kernel for large M when BN divides N, else the 128-row one
+  if (*tm == 0 && *tn == 0) {
+    // static fallback (the Python front end normally autotunes): the 256-row kernel needs >= ~1 block per CU
+    const int t160 = ((M + 255) / 256) * ((N + 159) / 160), t128 = ((M + 255) / 256) * ((N + 127) / 128);
+    if (!geglu && N % 160 == 0 && t160 >= 224) { *tm = 256; *tn = 160; }
+    else if (!geglu && N % 128 == 0 && t128 >= 224) { *tm = 256; *tn = 128; }
+    else { *tm = 128; *tn = (N % 128 == 0) ? 128 : 64; }
+  } else if (*tm == 0) {
+    *tm = (*tn == 160) ? 256 : 128;
+  } else if (*tn == 0) {
+    if (*tm == 256) *tn = (!geglu && N % 160 == 0) ? 160 : 128;
+    else *tn = (N % 128 == 0) ? 128 : 64;
+  }
+}
+
+static int choose_splits(int M, int N, int K, int tm, int tn, int geglu) {
   if (geglu) return 1;
-  const int tiles = ((M + BM - 1) / BM) * ((N + tn - 1) / tn);
+  const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
   const int nk = K / BK;
-  if (tiles >= 256 || nk < 32) return 1;
-  int s = (512 + tiles - 1) / tiles;
+  const int slots = tm == 256 ? 256 : 512;   // resident blocks on the chip
+  if (tiles * 10 > slots * 6 || nk < 32) return 1;   // > 60 % of the resident slots filled: do not split
+  int s = (slots + tiles / 2) / tiles;               // round to the nearest whole number of waves
   if (s > 8) s = 8;
   if (s > nk / 8) s = nk / 8;
   return s < 1 ? 1 : s;
@@ -302,9 +581,9 @@ extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   if (!a) return 0;
   const int M = a->B * a->H * a->W;
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
-  int tn = a->tile_n;
-  if (tn == 0) tn = (a->N % 128 == 0) ? 128 : 64;
-  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tn, a->geglu);
+  int tn = a->tile_n, tm = a->tile_m;
+  choose_tile(M, a->N, a->geglu, &tm, &tn);
+  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu);
   return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
@@ -335,10 +614,10 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (((uintptr_t)P.p1 | (uintptr_t)P.p2 | (uintptr_t)P.wt | (uintptr_t)P.out | (uintptr_t)P.resid |
        (uintptr_t)P.rowvec | (uintptr_t)P.bias) & 15)
     return LR_E_ALIGN;
-  int tn = a->tile_n;
-  if (tn == 0) tn = (P.N % 128 == 0) ? 128 : 64;
+  int tn = a->tile_n, tm = a->tile_m;
+  choose_tile(P.M, P.N, P.geglu, &tm, &tn);
   int splits = a->splits;
-  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tn, P.geglu);
+  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu);
   if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
   if (splits > 1) {
     const int64_t need = (int64_t)splits * P.M * P.N * (int64_t)sizeof(float);
@@ -350,7 +629,12 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.splits = splits;
   P.ws = a->workspace;
   hipStream_t st = (hipStream_t)s;
-  if (tn == 128) return launch_gemm<128>(P, st);
-  if (tn == 64) return launch_gemm<64>(P, st);
-  return LR_E_UNSUPPORTED;
+  int rc;
+  if (tm == 128 && tn == 128) rc = launch_gemm<128>(P, st);
+  else if (tm == 128 && tn == 64) rc = launch_gemm<64>(P, st);
+  else if (tm == 256 && tn == 128) rc = launch_gemm256<128>(P, st);
+  else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160>(P, st);
+  else return LR_E_UNSUPPORTED;
+  if (rc || P.splits == 1) return rc;
+  return launch_reduce(P, st);
 }

@@ -3,12 +3,26 @@
 PyTorch is used only for device memory and streams (`torch.cuda.current_stream()` is the HIP stream on ROCm).
 Activations are NHWC / token-major fp16: a tensor [M, C] with M = N*H*W rows.
 """
+import os
+
 import torch
 
 from . import _lib
 from ._lib import GemmArgs
 
 GN_CHUNKS = 16
+
+# ---- tile autotuner for lr_gemm_conv_f16 ------------------------------------------------------------------------
+# The UNet has ~50 distinct static GEMM shapes.  On first sight of a shape (eager warm-up before hipGraph capture) every
+# tile configuration is timed with HIP events and the fastest is cached.  All tile configurations accumulate K in the
+# same order, so the choice never changes results bit-wise (split-K stays a deterministic function of the shape).
+AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "1") != "0"
+TILE_CANDIDATES = ((128, 64), (128, 128), (256, 128), (256, 160))
+_tile_cache = {}
+
+
+def tile_cache():
+    return _tile_cache
 
 
 def _stream():
@@ -98,7 +112,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, out=None, tile_n=0, splits=0):
+              resid=None, geglu=False, out=None, tile_n=0, tile_m=0, splits=0):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
     lib = _lib.load()
     _chk16(x1, "x1")
@@ -132,14 +146,55 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=N
     a.out, a.ld_out = _p(out), out.stride(0)
     a.geglu = int(geglu)
     a.tile_n = tile_n
+    a.tile_m = tile_m
     a.splits = splits
     a.workspace, a.workspace_bytes = 0, 0
-    need = lib.lr_gemm_workspace_bytes(a)
-    if need > 0:   # split-K partials (small-M shapes); the caller owns the workspace
-        ws = torch.empty(need // 4, device=x1.device, dtype=torch.float32)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), need
-    _lib.check(lib.lr_gemm_conv_f16(a, _stream()), "gemm_conv")
+    st = _stream()
+    if tile_m == 0 and tile_n == 0 and AUTOTUNE:
+        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index)
+        best = _tile_cache.get(key)
+        if best is None and not torch.cuda.is_current_stream_capturing():
+            best = _tune_tiles(lib, a, x1.device, geglu)
+            _tile_cache[key] = best
+        if best is not None:
+            a.tile_m, a.tile_n = best
+    ws = _workspace(lib, a, x1.device)
+    _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
     return out
+
+
+def _workspace(lib, a, device):
+    """split-K partials (small-M shapes); the caller owns the workspace."""
+    a.workspace, a.workspace_bytes = 0, 0
+    need = lib.lr_gemm_workspace_bytes(a)
+    if need <= 0:
+        return None
+    ws = torch.empty(need // 4, device=device, dtype=torch.float32)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    return ws
+
+
+def _tune_tiles(lib, a, device, geglu, reps=3):
+    st = _stream()
+    best, best_t = None, float("inf")
+    for tm, tn in TILE_CANDIDATES:
+        if geglu and tn == 160:
+            continue
+        a.tile_m, a.tile_n = tm, tn
+        ws = _workspace(lib, a, device)
+        if lib.lr_gemm_conv_f16(a, st) != 0:
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.lr_gemm_conv_f16(a, st)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        del ws
+        if t < best_t:
+            best, best_t = (tm, tn), t
+    return best
 
 
 def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None):

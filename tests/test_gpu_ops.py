@@ -123,7 +123,7 @@ def test_timestep_embedding_and_time_mlp(golden):
 
 
 def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True, rowvec=False, resid=False,
-               tile_n=0, wscale=1.0):
+               tile_n=0, wscale=1.0, tile_m=0, splits=0):
     from leftrefill_amd import ops, packing
     d = dev()
     Ct = Cin + C2
@@ -152,7 +152,8 @@ def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True
     x1 = to_tok(x[:, :Cin])
     x2 = to_tok(x[:, Cin:]) if C2 else None
     y = ops.gemm_conv(x1, wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, x2=x2, bias=bp,
-                      rowvec=rv.half().to(d) if rowvec else None, resid=to_tok(rs) if resid else None, tile_n=tile_n)
+                      rowvec=rv.half().to(d) if rowvec else None, resid=to_tok(rs) if resid else None, tile_n=tile_n,
+                      tile_m=tile_m, splits=splits)
     y = y[:, :Cout]
     # fp32 accumulation over K = taps*Ct products of fp16 values: the error is one final fp16 rounding
     report(name, from_tok(y, N, H, W), ref)
@@ -173,6 +174,37 @@ def test_conv3x3_variants():
     _conv_case("c1_cat", 2, 640, 320, 8, 8, taps=1, C2=320)
     _conv_case("c3_in", 2, 64, 320, 16, 32)   # padded input conv (9 -> 64 channels handled by caller)
     _conv_case("c3_m_tail", 1, 128, 64, 5, 9)  # M = 45 < tile
+
+
+@pytest.mark.parametrize("tile_n", [128, 160])
+def test_conv_tile256(tile_n):
+    """The 256-row, 8-wave, 3-stage counted-vmcnt kernel: every gather mode, tails in M and N, split-K."""
+    k = dict(tile_m=256, tile_n=tile_n)
+    co = 320 if tile_n == 160 else 384
+    _conv_case(f"t256_{tile_n}_c3", 2, 320, co, 16, 24, **k)                       # M = 768
+    _conv_case(f"t256_{tile_n}_tail", 1, 128, co, 9, 13, rowvec=True, resid=True, **k)   # M = 117 (< one tile)
+    _conv_case(f"t256_{tile_n}_cat", 2, 320, 640, 12, 20, C2=640, rowvec=True, resid=True, **k)
+    _conv_case(f"t256_{tile_n}_s2", 2, 320, co, 10, 14, stride=2, **k)
+    _conv_case(f"t256_{tile_n}_up", 1, 640, 640, 16, 24, up=1, **k)
+    _conv_case(f"t256_{tile_n}_lin", 1, 320, 960, 1, 700, taps=1, **k)              # short K (5 steps), M tail
+    _conv_case(f"t256_{tile_n}_lin1", 1, 64, 320, 1, 300, taps=1, **k)             # single K-step
+    _conv_case(f"t256_{tile_n}_lin2", 1, 128, 320, 1, 300, taps=1, **k)            # two K-steps
+    _conv_case(f"t256_{tile_n}_splitk", 2, 1280, 640, 8, 16, splits=3, **k)
+    _conv_case(f"t256_{tile_n}_c1cat", 2, 640, 320, 16, 16, taps=1, C2=320, **k)
+
+
+def test_geglu_tile256():
+    from leftrefill_amd import ops, packing
+    d = dev()
+    C, M = 320, 700
+    x = h16(G.T("geglu2.x", (M, C)))
+    w = h16(torch.from_numpy(weights.fill_like("geglu2.w", (8 * C, C))))
+    b = torch.from_numpy(weights.fill_like("geglu2.b", (8 * C,)))
+    u, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = u * F.gelu(gate)
+    wp, bp = packing.pack_geglu(w, b)
+    y = ops.gemm_conv(x.half().to(d), wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=256, tile_n=128)
+    report("geglu tile256", y, ref)
 
 
 def test_conv_split_k():
