@@ -16,6 +16,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libleftrefill_hip.so")
 SOURCES = ["norm.hip", "elementwise.hip", "gemm_conv.hip", "attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# attention: keep MFMA accumulators in VGPRs -- the softmax VALU stream reads every S^T value and rescales O, and
+# AGPR accumulators cost ~150 v_accvgpr_read/write per 64-key tile.
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():
@@ -43,7 +46,7 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + headers):
-            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([cc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
     if jobs:
         def run(cmd):
             if verbose:

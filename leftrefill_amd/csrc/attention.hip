@@ -13,6 +13,9 @@
 // * V tile is transposed on the way in: [64 d][64 keys] with a 136-byte pitch, written as packed key pairs
 //   (ds_write_b32), read as two ds_read_b64 per fragment (conflict-free at this pitch).
 // * Q fragments live in registers for the whole kernel; K/V double-buffered, one barrier per tile.
+// * Software pipeline inside each wave: the QK^T MFMAs of tile j+1 are issued ahead of the softmax VALU stream of
+//   tile j, so the matrix pipe is busy while exp2 / max / fp16 convert run; the running-max rescale of O is deferred
+//   until a row max grows by more than 2^8 (exp2 domain).
 #include "common.h"
 
 #define ATT_THREADS 256
@@ -103,40 +106,34 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  {
-    uint4 v0, v1;
-    stage_k(0, 0);
-    load_v(0, v0, v1);
-    write_v(0, v0, v1);
-  }
-  __syncthreads();
-
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
-    const bool more = tile + 1 < ntiles;
-    if (more) {
-      stage_k(cur ^ 1, tile + 1);
-      load_v(tile + 1, nv0, nv1);
-    }
-    const char* Ks = Ksm + cur * (ATT_KB * 128);
-    const char* Vs = Vsm + cur * (64 * VT_PITCH);
-
-    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
-    f32x16 sacc[2];
+  // S^T[key][q] = sum_d K[key][d] Q[q][d] for one 64-key tile held in K buffer `buf`
+  auto qk = [&](f32x16 (&sacc)[2], int buf) {
+    const char* Ks = Ksm + buf * (ATT_KB * 128);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
       const int row = kb * 32 + ql;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kc = s * 2 + hi;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int kc = s4 * 2 + hi;
         const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s4], s4 == 0 ? zero16 : sacc[kb], 0, 0, 0);
       }
     }
+  };
+
+  // One pipeline step: the QK^T MFMAs of tile+1 are issued BEFORE the softmax VALU work of `tile` (independent
+  // registers), so the matrix pipe runs under the exp/max/convert stream of the same wave; then P V of `tile`.
+  //   K ring: K[tile+1] is read here, K[tile+2] is loaded into the buffer K[tile] vacated (its reads finished before
+  //   the barrier that ended the previous step).  V ring: V[tile] read, V[tile+1] written after the P V MFMAs.
+  auto step = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int tile) {
+    const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
+    uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
+    if (more2) stage_k(tile & 1, tile + 2);
+    if (more1) load_v(tile + 1, nv0, nv1);
+    if (more1) qk(sn, (tile + 1) & 1);
+
     // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
     if (tile * ATT_KB + ATT_KB > P.Nkv) {
 #pragma unroll
@@ -144,45 +141,52 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = tile * ATT_KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= P.Nkv) sacc[kb][r] = -INFINITY;
+          if (key >= P.Nkv) sc[kb][r] = -INFINITY;
         }
     }
-    // ---- online softmax (one query per lane; the partner lane ^ 32 holds the other half of the keys)
-    float mx = sacc[0][0];
+    // ---- online softmax, one query per lane (partner lane ^ 32 holds the other half of the keys).
+    // The running max is only raised (and O, l rescaled) when some row's max grew by more than 2^8 in the exp2
+    // domain: P stays <= 256, exactly representable headroom in fp16, and the common path skips 32 accumulator
+    // multiplies per lane.  m_run starts at -inf, so the first tile always takes the rescale path.
+    float mx = sc[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * P.c);
-    const float mc = m_new * P.c;
+    if (!__all((mx - m_run) * P.c <= 8.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * P.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = m_run * P.c;
     float psum = 0.f;
     f16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], P.c, -mc));
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], P.c, -mc));
         psum += p;
         pf[kb][r >> 3][r & 7] = (f16)p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; k-slot (hi*8 + jj) of MFMA (kb, tt) is key
     //      kb*32 + 16*tt + 4*hi + jj (jj < 4) and kb*32 + 16*tt + 8 + 4*hi + (jj - 4) (jj >= 4)
+    const char* Vs = Vsm + (tile & 1) * (64 * VT_PITCH);
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int drow = db * 32 + ql;
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int db = 0; db < 2; ++db) {
+          const int drow = db * 32 + ql;
           const int key0 = kb * 32 + 16 * tt + 4 * hi;
           const f16x4 va = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + key0 * 2);
           const f16x4 vb = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + (key0 + 8) * 2);
@@ -191,9 +195,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][tt], oacc[db], 0, 0, 0);
         }
-    }
-    if (more) write_v(cur ^ 1, nv0, nv1);
+    if (more1) write_v((tile + 1) & 1, nv0, nv1);
     __syncthreads();
+  };
+
+  {
+    uint4 v0, v1;
+    stage_k(0, 0);
+    if (ntiles > 1) stage_k(1, 1);
+    load_v(0, v0, v1);
+    write_v(0, v0, v1);
+  }
+  __syncthreads();
+  f32x16 sA[2], sB[2];
+  qk(sA, 0);
+  __syncthreads();   // nobody may overwrite K buffer 0 (tile 2) before every wave has finished its first QK^T
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    step(sA, sB, tile);
+    if (tile + 1 < ntiles) step(sB, sA, tile + 1);
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi
