@@ -29,15 +29,18 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
   for (int i = 0; i < 8; ++i) { sm[i] = 0.f; sq[i] = 0.f; }
   const f16* base = src + ((size_t)n * HW) * cs + coff;
   int p = p0 + r;
-  // two pixels in flight per thread
-  for (; p + R < p1; p += 2 * R) {
-    const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)p * cs);
-    const uint4 u1 = *reinterpret_cast<const uint4*>(base + (size_t)(p + R) * cs);
-    float f[8], g[8];
-    lr_unpack8(u0, f);
-    lr_unpack8(u1, g);
+  // four pixels in flight per thread
+  for (; p + 3 * R < p1; p += 4 * R) {
+    uint4 u[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { sm[i] += f[i] + g[i]; sq[i] = fmaf(f[i], f[i], fmaf(g[i], g[i], sq[i])); }
+    for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const uint4*>(base + (size_t)(p + k * R) * cs);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f[8];
+      lr_unpack8(u[k], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sm[i] += f[i]; sq[i] = fmaf(f[i], f[i], sq[i]); }
+    }
   }
   for (; p < p1; p += R) {
     const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)p * cs);
@@ -63,59 +66,97 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GroupNorm apply (+ optional SiLU).  grid = (pixel blocks, N).  Each block first finalises mean/rstd of its sample
-// (fp64 combine of LR_GN_CHUNKS partials per group), builds per-channel scale/shift in LDS, then streams pixels.
+// GroupNorm apply (+ optional SiLU).  grid = (pixel blocks, N); block = nOct * R threads like the stats kernel, so
+// thread (o, r) owns channel octet o for its whole life: the 8 scale / shift coefficients sit in registers and the
+// streaming loop is pure load -> 8 fma (+SiLU) -> store with four 16-byte loads in flight (no LDS table, no
+// per-element index division).  Each block first finalises mean/rstd of its sample from the LR_GN_CHUNKS partials
+// (fp64, fixed order => deterministic).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
                                 const float* __restrict__ partials, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, f16* __restrict__ y,
-                                int pix_per_block) {
-  extern __shared__ float s_ab[];  // [C] scale, [C] shift
+                                int pix_per_block, int nOct, int R) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = C1 + C2;
   const int Cg = C / 32;
   const int n = blockIdx.y;
   const int t = threadIdx.x;
-  if (t < 32) {
-    double s = 0.0, q = 0.0;
-    const float* src = partials + ((size_t)n * LR_GN_CHUNKS * 32 + t) * 2;
-    for (int c = 0; c < LR_GN_CHUNKS; ++c) { s += (double)src[c * 64]; q += (double)src[c * 64 + 1]; }
-    const double cnt = (double)HW * (double)Cg;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[t] = (float)mean;
-    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  for (int c = t; c < C; c += blockDim.x) {
-    const int g = c / Cg;
-    const float a = s_rstd[g] * gamma[c];
-    s_ab[c] = a;
-    s_ab[C + c] = beta[c] - s_mean[g] * a;
-  }
-  __syncthreads();
-  const int nOct = C / 8;
+  const int o = t % nOct, r = t / nOct;
+  const int c0 = o * 8;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
-  const int total = (p1 - p0) * nOct;
-  for (int idx = t; idx < total; idx += blockDim.x) {
-    const int p = p0 + idx / nOct;
-    const int o = idx % nOct;
-    const int c0 = o * 8;
-    const f16* src;
-    if (c0 < C1) src = x1 + ((size_t)n * HW + p) * C1 + c0;
-    else src = x2 + ((size_t)n * HW + p) * C2 + (c0 - C1);
-    const uint4 u = *reinterpret_cast<const uint4*>(src);
+  const f16* src;
+  int cs;
+  if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; cs = C1; }
+  else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
+  f16* dst = y + ((size_t)n * HW) * C + c0;
+
+  // request the first pixels before the statistics prologue (their latency hides under it)
+  int p = p0 + r;
+  uint4 u[4];
+  const bool first = p + 3 * R < p1;
+  if (first) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const uint4*>(src + (size_t)(p + k * R) * cs);
+  }
+  float ga[8], be[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i]; }
+  if (t < 128) {   // 4 lanes per group split the partials (blockDim >= 128 always)
+    const int g = t >> 2, sub = t & 3;
+    double s = 0.0, q = 0.0;
+    const float* ps = partials + ((size_t)n * LR_GN_CHUNKS * 32 + g) * 2;
+#pragma unroll 4
+    for (int c = sub; c < LR_GN_CHUNKS; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+#pragma unroll
+    for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+    if (sub == 0) {
+      const double cnt = (double)HW * (double)Cg;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int g = (c0 + i) / Cg;
+    a[i] = s_rstd[g] * ga[i];
+    b[i] = be[i] - s_mean[g] * a[i];
+  }
+  auto emit = [&](int pp, const uint4& v) {
     float f[8];
-    lr_unpack8(u, f);
+    lr_unpack8(v, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float v = fmaf(f[i], s_ab[c0 + i], s_ab[C + c0 + i]);
-      f[i] = silu ? lr_silu(v) : v;
+      const float z = fmaf(f[i], a[i], b[i]);
+      f[i] = silu ? z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)) : z;
     }
-    *reinterpret_cast<uint4*>(y + ((size_t)n * HW + p) * C + c0) = lr_pack8(f);
+    *reinterpret_cast<uint4*>(dst + (size_t)pp * C) = lr_pack8(f);
+  };
+  if (r >= R) return;   // spare threads when blockDim was rounded up (never with nOct * R sizing)
+  bool have = first;
+  while (have) {
+    const int np = p + 4 * R;
+    const bool more = np + 3 * R < p1;
+    uint4 w[4];
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = *reinterpret_cast<const uint4*>(src + (size_t)(np + k * R) * cs);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) emit(p + k * R, u[k]);
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = w[k];
+    }
+    p = np;
+    have = more;
   }
+  for (; p < p1; p += R) emit(p, *reinterpret_cast<const uint4*>(src + (size_t)p * cs));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -196,13 +237,20 @@ extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, 
   if (!x2) C2 = 0;
   const int C = C1 + C2;
   if (C % 32 || C1 % 8 || C2 % 8) return LR_E_ALIGN;
-  // ~2048 blocks over the whole tensor, at least 8 pixels per block
-  int ppb = (int)(((long long)N * HW + 2047) / 2048);
-  if (ppb < 8) ppb = 8;
+  // ~1024 blocks over the whole tensor (4 per CU), at least 16 pixels per block so the per-block finalisation of
+  // mean/rstd and the scale/shift table amortise
+  int ppb = (int)(((long long)N * HW + 1023) / 1024);
+  if (ppb < 16) ppb = 16;
   if (ppb > HW) ppb = HW;
+  const int nOct = C / 8;
+  int R = 256 / nOct;
+  if (R < 1) R = 1;
+  const int threads = nOct * R;
+  ppb = ((ppb + 4 * R - 1) / (4 * R)) * (4 * R);   // whole 4-deep load batches per thread (no serial tail)
   dim3 grid((HW + ppb - 1) / ppb, N);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const f16*)x1, C1,
-                     (const f16*)x2, C2, HW, partials, gamma, beta, eps, silu, (f16*)y, ppb);
+  if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, (hipStream_t)s, (const f16*)x1, C1, (const f16*)x2, C2,
+                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R);
   return lr_launch_status();
 }
 
