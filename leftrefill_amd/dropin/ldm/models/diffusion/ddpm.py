@@ -44,7 +44,9 @@ class DiffusionWrapper(nn.Module):
         if key == 'hybrid':
             # channel order [noisy z 0-3 | mask 4 | masked-image latent 5-8] (reference 1348-1351, 1662, 1679-1690)
             xc = torch.cat([x] + c_concat, dim=1)
-            cc = torch.cat(c_crossattn, 1)
+            # a single context tensor is passed through as-is (torch.cat would copy it every step and defeat the
+            # UNet's per-context K/V cache); the value is identical
+            cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
             return self.diffusion_model(xc, t, context=cc)
         raise NotImplementedError(f"conditioning_key {key!r} is not used by the inpainting path")
 

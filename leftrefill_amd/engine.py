@@ -118,6 +118,7 @@ class PackedTBlock:
         self.geglu_w, self.geglu_b = packing.pack_geglu(proj.weight.detach(), proj.bias.detach())
         self.ff2 = PackedLinear(blk.ff.net[2])
         # multi-view attributes (None for the single-view block)
+        self.kv_slot = None   # index into the per-context K/V projection cache (set by UNetModel.prepare)
         self.view_num = getattr(blk, "view_num", None)
         self.concat_target = getattr(blk, "concat_target", False)
         self.no_rearrange = getattr(blk, "no_rearrange_selfattn", False)
@@ -179,15 +180,17 @@ def self_attention(x, pa: PackedAttn, B, L, resid):
     return linear(a, pa.out, resid=resid)
 
 
-def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid):
+def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid, kv=None):
+    """kv: optional precomputed [B*Lc, 2C] = ctx @ [Wk; Wv]^T (constant over the DDIM steps, see UNetModel)."""
     C = x.shape[1]
     q = linear(x, pa.q)
-    kv = linear(ctx, pa.kv)
+    if kv is None:
+        kv = linear(ctx, pa.kv)
     a = ops.attention(q, kv[:, :C], kv[:, C:], B, pa.heads, L, Lc, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=resid)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc):
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468."""
     if pt.view_num is None:
         x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, N, L, x)
@@ -205,18 +208,19 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc):
         b = N // v
         assert b * v == N
         x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, b, v * L, x)
-    x = cross_attention(ops.layer_norm(x, pt.n2.g, pt.n2.b, pt.n2.eps), ctx, pt.attn2, N, L, Lc, x)
+    x = cross_attention(ops.layer_norm(x, pt.n2.g, pt.n2.b, pt.n2.eps), ctx, pt.attn2, N, L, Lc, x, kv)
     n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
     g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
     return linear(g, pt.ff2, resid=x)
 
 
-def spatial_transformer(act: Act, ctx, Lc, ps: PackedST):
+def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):
     x_in = act.materialize()
     h = gn(Act(x_in, act.N, act.H, act.W), ps.norm, False).tok
     h = linear(h, ps.proj_in)
     for pt in ps.blocks:
-        h = transformer_block(h, ctx, pt, act.N, act.HW, Lc)
+        kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
+        h = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv)
     y = linear(h, ps.proj_out, resid=x_in)
     return Act(y, act.N, act.H, act.W)
 

@@ -152,3 +152,25 @@ def test_unet_full_width(golden, case, cname, N, H, W, ts):
 def test_multiview_unet(golden, case, V, concat, b, H, W):
     n = b * (V - 1 if concat else V)
     check_unet(golden, case, "MV", n, H, W, [501] * n, fname="multiview", multiview=(V, concat))
+
+
+def test_context_kv_cache_is_invalidated_correctly():
+    """The step graph caches the cross-attention K/V projections per context tensor (constant over the DDIM loop)."""
+    m, sd, cfg = get_model("MID")
+    x, t, ctx = G.unet_inputs("kvcache", cfg, 2, 16, 32, [981, 1])
+    x, t = x.to(dev()), t.to(dev())
+    ctx_a = ctx.to(dev())
+    ctx_b = (ctx * 0.5 + 0.1).to(dev())
+    m.use_hip_graph = False
+    with torch.no_grad():
+        ref_a, ref_b = m(x, t, ctx_a), m(x, t, ctx_b)
+    m.use_hip_graph = True
+    with torch.no_grad():
+        a1 = m(x, t, ctx_a)
+        a2 = m(x, t, ctx_a)            # cache hit (same tensor object, same version)
+        b1 = m(x, t, ctx_b)            # different tensor -> recomputed
+        ctx_a.copy_(ctx_b)             # in-place modification bumps _version -> recomputed
+        a3 = m(x, t, ctx_a)
+    assert torch.equal(a1, ref_a) and torch.equal(a2, ref_a)
+    assert torch.equal(b1, ref_b) and torch.equal(a3, ref_b)
+    assert not torch.equal(ref_a, ref_b)

@@ -1,0 +1,59 @@
+"""Micro-benchmark of lr_gemm_conv_f16 for one shape across tile configurations (MI355X only).
+
+    python tools/bench_gemm.py M N K taps [tile_m tile_n splits] [--reps 20]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from leftrefill_amd import ops  # noqa: E402
+
+
+def run(M, N, K, taps, tm, tn, splits, reps, H=None):
+    dev = torch.device("cuda:0")
+    C = K // taps
+    if taps == 9:
+        B = 8
+        HW = M // B
+        W = int((HW * 2) ** 0.5)
+        Hh = HW // W
+    else:
+        B, Hh, W = 1, 1, M
+    x = torch.randn(M, C, device=dev).half()
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    e1.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dims", type=int, nargs="+")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    M, N, K, taps = a.dims[:4]
+    ops.AUTOTUNE = False
+    if len(a.dims) >= 6:
+        cfgs = [(a.dims[4], a.dims[5], a.dims[6] if len(a.dims) > 6 else 0)]
+    else:
+        cfgs = [(128, 64, 0), (128, 128, 0), (256, 128, 0), (256, 160, 0)]
+    for tm, tn, sp in cfgs:
+        try:
+            us, tf = run(M, N, K, taps, tm, tn, sp, a.reps)
+            print(f"M={M} N={N} K={K} taps={taps} tile {tm}x{tn} splits={sp}: {us:8.1f} us  {tf:7.1f} TFLOP/s")
+        except Exception as e:  # noqa: BLE001
+            print(f"tile {tm}x{tn}: {e}")
