@@ -162,76 +162,84 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
     cur ^= 1;
   }
 
-  // ---- epilogue phase 1: accumulators (+bias, GEGLU) -> fp32 tile in LDS.  Lane holds D[n = fq*4 + r][m = fr].
+  // ---- epilogue: accumulators (+bias, GEGLU) -> fp32 tile in LDS -> whole-line stores with the fused per-sample row
+  // vector and residual.  Lane holds D[n = fq*4 + r][m = fr].  BN = 160 runs two passes of 64 rows so the staging tile
+  // (64 x 164 floats) stays inside the 72 KB of the two K-stages and two blocks fit on a CU.
+  constexpr int NPASS = BN > 128 ? 2 : 1;
+  constexpr int ROWS = BM / NPASS;
   float* Cs = reinterpret_cast<float*>(smem);
   const int BNo = P.geglu ? BN / 2 : BN;
   const int ldc = BNo + 4;
-  if (!P.geglu) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nl = wn * (BN / 2) + j * 16 + fq * 4;
-      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = wm * 64 + i * 16 + fr;
-        *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int jp = 0; jp < TN / 2; ++jp) {
-      const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;   // packed row of u; g is 16 rows further
-      f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
-      if (P.bias && n0 + nl_u + 16 < P.N) {
-        bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
-        bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
-      }
-      const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = wm * 64 + i * 16 + fr;
-        const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
-        *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- epilogue phase 2: whole-line stores with the fused per-sample row vector and residual
   const int n_out0 = P.geglu ? n0 / 2 : n0;
   const int N_out = P.geglu ? P.N / 2 : P.N;
   const int cpr = BNo >> 3;  // 16-byte chunks per tile row
-  for (int id = t; id < BM * cpr; id += GEMM_THREADS) {
-    const int row = id / cpr, cch = id - row * cpr;
-    const int m = m0 + row, n = n_out0 + cch * 8;
-    if (m >= P.M || n >= N_out) continue;
-    float v[8];
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
-    if (P.splits > 1) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
-      float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
-      *reinterpret_cast<f32x4*>(dst) = c0;
-      *reinterpret_cast<f32x4*>(dst + 4) = c1;
-      continue;
-    }
-    v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
-    if (P.rowvec) {
-      float e[8];
-      lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += e[i];
-    }
-    if (P.resid) {
-      float e[8];
-      lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (NPASS == 1 || wm == pass) {
+      const int wml = NPASS == 1 ? wm : 0;
+      if (!P.geglu) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += e[i];
+        for (int j = 0; j < TN; ++j) {
+          const int nl = wn * (BN / 2) + j * 16 + fq * 4;
+          f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ml = wml * 64 + i * 16 + fr;
+            *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
+          }
+        }
+      } else if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+          const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;   // packed row of u; g is 16 rows further
+          f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
+          if (P.bias && n0 + nl_u + 16 < P.N) {
+            bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
+            bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
+          }
+          const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ml = wml * 64 + i * 16 + fr;
+            const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
+            *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
+          }
+        }
+      }
     }
-    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+    __syncthreads();
+    for (int id = t; id < ROWS * cpr; id += GEMM_THREADS) {
+      const int row = id / cpr, cch = id - row * cpr;
+      const int m = m0 + pass * ROWS + row, n = n_out0 + cch * 8;
+      if (m >= P.M || n >= N_out) continue;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
+      if (P.splits > 1) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
+        float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
+        *reinterpret_cast<f32x4*>(dst) = c0;
+        *reinterpret_cast<f32x4*>(dst + 4) = c1;
+        continue;
+      }
+      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      if (P.rowvec) {
+        float e[8];
+        lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      if (P.resid) {
+        float e[8];
+        lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+    }
+    if (NPASS > 1) __syncthreads();
   }
 }
 
@@ -541,15 +549,14 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
   P.ntiles_m = ntm;
   P.m_fastest = 0;   // measured on MI355X: n-fastest wins even for 3.7 MB weight slices (1038 vs 928 TFLOP/s)
   P.nblocks = P.ntiles_n * ntm;
-  const int BNo = P.geglu ? BN / 2 : BN;
+  constexpr int NPASS = BN > 128 ? 2 : 1;
   size_t smem = 2 * (size_t)(BM + BN) * 128;
-  const size_t epi = (size_t)BM * (BNo + 4) * sizeof(float);
+  const size_t epi = (size_t)(BM / NPASS) * (BN + 4) * sizeof(float);
   if (epi > smem) smem = epi;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)(2 * (size_t)(BM + BN) * 128 > (size_t)BM * (BN + 4) * 4 ? 2 * (size_t)(BM + BN) * 128
-                                                                                      : (size_t)BM * (BN + 4) * 4));
+                        (int)smem);
     attr_done = true;
   }
   hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
@@ -574,7 +581,7 @@ static void choose_tile(int M, int N, int geglu, int* tm, int* tn) {
     else if (!geglu && N % 128 == 0 && t128 >= 224) { *tm = 256; *tn = 128; }
     else { *tm = 128; *tn = (N % 128 == 0) ? 128 : 64; }
   } else if (*tm == 0) {
-    *tm = (*tn == 160) ? 256 : 128;
+    *tm = 128;
   } else if (*tn == 0) {
     if (*tm == 256) *tn = (!geglu && N % 160 == 0) ? 160 : 128;
     else *tn = (N % 128 == 0) ? 128 : 64;
@@ -648,6 +655,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   int rc;
   if (tm == 128 && tn == 128) rc = launch_gemm<128>(P, st);
   else if (tm == 128 && tn == 64) rc = launch_gemm<64>(P, st);
+  else if (tm == 128 && tn == 160 && !P.geglu) rc = launch_gemm<160>(P, st);
   else if (tm == 256 && tn == 128) rc = launch_gemm256<128>(P, st);
   else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160>(P, st);
   else return LR_E_UNSUPPORTED;

@@ -193,6 +193,14 @@ def test_conv_tile256(tile_n):
     _conv_case(f"t256_{tile_n}_c1cat", 2, 640, 320, 16, 16, taps=1, C2=320, **k)
 
 
+def test_conv_tile128x160():
+    k = dict(tile_m=128, tile_n=160)
+    _conv_case("t128x160_c3", 2, 320, 320, 12, 20, rowvec=True, resid=True, **k)
+    _conv_case("t128x160_tail", 1, 128, 480, 9, 13, **k)
+    _conv_case("t128x160_lin", 1, 320, 960, 1, 300, taps=1, **k)
+    _conv_case("t128x160_splitk", 2, 1280, 640, 8, 16, splits=3, **k)
+
+
 def test_geglu_tile256():
     from leftrefill_amd import ops, packing
     d = dev()
