@@ -223,6 +223,24 @@ def gen_sampler(ns):
     np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
 
 
+VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+                    num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def gen_vae(ns):
+    """Host-side KL-VAE (reference ldm/models/autoencoder.py + diffusionmodules/model.py), reduced width."""
+    from ldm.models.autoencoder import AutoencoderKL
+    ref = AutoencoderKL(dict(VAE_DDCONFIG), {"target": "torch.nn.Identity"}, 4).eval()
+    sd = {k: torch.from_numpy(weights.fill_like("vae." + k, v.shape)) for k, v in ref.state_dict().items()}
+    ref.load_state_dict(sd)
+    x = G.T("vae.x", (1, 3, 32, 64))
+    with torch.no_grad():
+        post = ref.encode(x)
+        z = post.mode()
+        np.savez_compressed(os.path.join(OUT, "vae.npz"), z=z.numpy(), dec=ref.decode(z).numpy(),
+                            sample=post.sample().numpy(), keys=np.array(list(sd.keys())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -231,11 +249,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ns = ref_import.import_reference()
-    todo = [a.only] if a.only else ["ops", "sampler", "mv", "unet"]
+    todo = [a.only] if a.only else ["ops", "sampler", "mv", "vae", "unet"]
     for what in todo:
         print(f"[{what}]")
         t0 = time.time()
-        {"ops": gen_ops, "unet": lambda n: gen_unet(n, a.skip_full), "mv": gen_mv, "sampler": gen_sampler}[what](ns)
+        {"ops": gen_ops, "unet": lambda n: gen_unet(n, a.skip_full), "mv": gen_mv, "sampler": gen_sampler,
+         "vae": gen_vae}[what](ns)
         print(f"[{what}] done in {time.time() - t0:.1f}s")
 
 

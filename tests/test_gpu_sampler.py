@@ -98,3 +98,73 @@ def test_sample_is_deterministic_and_graph_reused():
         outs.append(s)
     assert torch.equal(outs[0], outs[1])
     assert len(m.model.diffusion_model._graphs) >= 1
+
+
+def test_log_images_end_to_end_glue():
+    """RefInpaintLDM.log_images (ref_inpainting_ldm.py:37-72): VAE encode of image / masked image, nearest mask
+    down-sampling, channel order [z | mask | masked latent], unconditional prompt, 50->5 step CFG sampling, VAE decode.
+    The VAE (host PyTorch) is shared with the expected-value computation, so this pins the GLUE, not the VAE."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
+    from oracle import weights
+    dev = torch.device("cuda:0")
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    m = RefInpaintLDM(first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                          "params": {"ddconfig": dd, "embed_dim": 4,
+                                                     "lossconfig": {"target": "torch.nn.Identity"}}},
+                      cond_stage_config={"target": "torch.nn.Identity"},
+                      unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                   "params": cfg.kwargs()},
+                      conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
+                      timesteps=1000, channels=4, first_stage_key="image", cond_stage_key="txt",
+                      cond_stage_trainable=True, data_config={"img_size": 64})
+    m.model.diffusion_model.load_state_dict(G.unet_state(G.TRAJ_CONFIG), strict=True)
+    m.first_stage_model.load_state_dict({k: torch.from_numpy(weights.fill_like("vae2." + k, v.shape))
+                                         for k, v in m.first_stage_model.state_dict().items()})
+    B, S = 2, 64
+    ctx_c = G.T("e2e.c", (B, 77, cfg.context_dim))
+    ctx_u = G.T("e2e.u", (B, 77, cfg.context_dim))
+
+    class Prompt(torch.nn.Module):
+        def encode(self, txt):
+            assert isinstance(txt, list) and len(txt) == B
+            return (ctx_u if txt[0] == "" else ctx_c).to(dev)
+
+    m.cond_stage_model = Prompt()
+    m = m.to(dev).eval()
+    img = G.T("e2e.img", (B, S, 2 * S, 3), "unit")
+    mask = torch.zeros(B, S, 2 * S, 1)
+    mask[:, 16:48, S + 8:S + 40] = 1.0
+    batch = {"image": img.to(dev), "mask": mask.to(dev), "masked_image": (img * (mask < 0.5)).to(dev), "txt": ["p"] * B}
+    x_T = G.T("e2e.x_T", (B, 4, S // 8, 2 * S // 8))
+    import ldm.models.diffusion.ddim as ddim_mod
+    orig_sampling = ddim_mod.DDIMSampler.ddim_sampling
+
+    def with_xT(self, cond, shape, **kw):
+        kw["x_T"] = x_T.to(dev)
+        return orig_sampling(self, cond, shape, **kw)
+
+    ddim_mod.DDIMSampler.ddim_sampling = with_xT
+    try:
+        out = m.log_images(batch, B, ddim_steps=5, ddim_eta=0.0, unconditional_guidance_scale=2.5)
+    finally:
+        ddim_mod.DDIMSampler.ddim_sampling = orig_sampling
+    assert set(out) == {"masked_image", "origin_image", "pred"}
+    assert out["pred"].shape == (B, 3, S, 2 * S) and torch.isfinite(out["pred"]).all()
+    assert torch.equal(out["origin_image"], batch["image"].permute(0, 3, 1, 2))
+    # expected value: same VAE (host torch) + CPU oracle for the sampler/UNet
+    vae = m.first_stage_model
+    with torch.no_grad():
+        lat = vae.encode(batch["masked_image"].permute(0, 3, 1, 2).float()).sample() * 0.18215
+        mk = torch.nn.functional.interpolate(batch["mask"].permute(0, 3, 1, 2).float(), size=lat.shape[-2:])
+        c_concat = torch.cat([mk, lat], 1).cpu()
+        sd = G.unet_state(G.TRAJ_CONFIG)
+        z, _ = ddim_ref.ddim_sample(lambda xc, t, c: unet_ref.unet_forward(sd, cfg, xc, t, c), 5, x_T, c_concat, ctx_c,
+                                    ctx_u, 2.5, eta=0.0)
+        ref = vae.decode((z / 0.18215).to(dev)).cpu()
+    err = (out["pred"].float().cpu() - ref).abs().max().item()
+    print(f"[log_images] max|pred - expected| = {err:.3e} (ref absmax {ref.abs().max().item():.2f})")
+    assert err <= 5e-2 * max(1.0, ref.abs().max().item())

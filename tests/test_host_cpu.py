@@ -228,3 +228,37 @@ def test_shard_range_partitions():
             spans = [shard_range(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_dropin_vae_matches_reference_golden(golden):
+    """Host-side KL-VAE drop-in (PyTorch code, off the hot path): same 248-key naming scheme and outputs as the reference."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.autoencoder import AutoencoderKL
+    from oracle import golden_spec as G, weights
+    from oracle.make_golden import VAE_DDCONFIG
+    g = golden("vae")
+    m = AutoencoderKL(dict(VAE_DDCONFIG), {"target": "torch.nn.Identity"}, 4).eval()
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    m.load_state_dict({k: torch.from_numpy(weights.fill_like("vae." + k, v.shape)) for k, v in m.state_dict().items()})
+    x = G.T("vae.x", (1, 3, 32, 64))
+    with torch.no_grad():
+        post = m.encode(x)
+        z = post.mode()
+        np.testing.assert_allclose(z.numpy(), g["z"], atol=1e-5)
+        np.testing.assert_allclose(m.decode(z).numpy(), g["dec"], atol=5e-5)
+        np.testing.assert_allclose(post.sample().numpy(), g["sample"], atol=1e-5)   # RNG re-seeded to 42 inside
+
+
+def test_full_vae_key_count():
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.autoencoder import AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)   # model_config.yaml:44-58
+    with torch.device("meta"):
+        m = AutoencoderKL(dd, {"target": "torch.nn.Identity"}, 4)
+    sd = m.state_dict()
+    assert len(sd) == 248 and sd["encoder.conv_out.weight"].shape == (8, 512, 3, 3)
+    assert sd["decoder.up.3.upsample.conv.weight"].shape == (512, 512, 3, 3)
+    assert abs(sum(v.numel() for v in sd.values()) / 1e6 - 83.65) < 0.01
