@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ldm.modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
+from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
 from ldm.util import default, exists, instantiate_from_config
 
 
@@ -144,10 +145,12 @@ class LatentDiffusion(DDPM):
 
     # ---- first stage (KL-VAE; PyTorch-ROCm host code) -----------------------------------------------------------
     def get_first_stage_encoding(self, encoder_posterior):
-        if hasattr(encoder_posterior, "sample"):
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
             z = encoder_posterior.sample()
-        else:
+        elif isinstance(encoder_posterior, torch.Tensor):
             z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
         return self.scale_factor * z
 
     @torch.no_grad()
@@ -163,7 +166,7 @@ class LatentDiffusion(DDPM):
         if self.cond_stage_forward is None:
             if hasattr(m, 'encode') and callable(m.encode):
                 c = m.encode(c)
-                if hasattr(c, "mode"):
+                if isinstance(c, DiagonalGaussianDistribution):
                     c = c.mode()
             else:
                 c = m(c)
