@@ -105,25 +105,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_run = -INFINITY;
-  // Row sums l = sum_k P[q][k] ride on the (under-used) matrix pipe: one more 32x32x16 MFMA per 16 keys with an all-ones
-  // A operand accumulates sum_k P^T[k][q] into every row of `lacc` -- 4 MFMAs per tile instead of 32 VALU adds per lane
-  // (the kernel is VALU-bound: exp2 + fma + convert per score).  The sum is over the fp16-rounded P, i.e. exactly the
-  // weights that multiply V.
-  f32x16 lacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-  const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+  float m_run = -INFINITY, l_run = 0.f;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // S^T[key][q] = sum_d K[key][d] Q[q][d] for one 64-key tile held in K buffer `buf`
   auto qk = [&](f32x16 (&sacc)[2], int buf) {
     const char* Ks = Ksm + buf * (ATT_KB * 128);
+    // the two 32-key blocks are independent accumulator chains: alternate them so consecutive MFMAs never wait on
+    // each other's 16-pass latency
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int row = kb * 32 + ql;
+    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + ql;
         const int kc = s4 * 2 + hi;
         const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s4], s4 == 0 ? zero16 : sacc[kb], 0, 0, 0);
@@ -166,21 +160,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * P.c);
       m_run = m_new;
-      lacc[0] *= alpha;   // every row of lacc holds the same sum; only row 0 (lane-local reg 0) is read at the end
+      l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
     const float mc = m_run * P.c;
+    float psum = 0.f;
     f16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], P.c, -mc));
+        psum += p;
         pf[kb][r >> 3][r & 7] = (f16)p;
       }
+    l_run += psum;
 
     // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; k-slot (hi*8 + jj) of MFMA (kb, tt) is key
     //      kb*32 + 16*tt + 4*hi + jj (jj < 4) and kb*32 + 16*tt + 8 + 4*hi + (jj - 4) (jj >= 4)
@@ -200,10 +197,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][tt], oacc[db], 0, 0, 0);
         }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf[kb][tt], lacc, 0, 0, 0);
     if (more1) write_v((tile + 1) & 1, nv0, nv1);
     __syncthreads();
   };
@@ -225,8 +218,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi
-  // lacc[r] = sum over ALL 64 keys of each tile (the MFMA already reduced both half-waves' k-slots): no lane exchange
-  const float inv = 1.0f / lacc[0];
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
   if (qrow < P.Nq) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
