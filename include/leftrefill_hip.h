@@ -45,9 +45,10 @@ int lr_nhwc_f16_to_nchw(const lr_half* y, int Cstride, int C, void* out_nchw, in
  * replaces: GroupNorm32 / normalization (util.py:202-219, eps 1e-5) followed by nn.SiLU in ResBlock.in_layers /
  *           out_layers / UNetModel.out (openaimodel.py:200-231,726-731) and Normalize (attention.py:90-91, eps 1e-6).
  * Input is the virtual concat [x1 (C1 ch) | x2 (C2 ch)] (th.cat([h, hs.pop()], 1), openaimodel.py:781); x2 may be NULL.
- * Two launches: stats writes per-chunk partial (sum, sumsq) to `partials` [N][LR_GN_CHUNKS][32][2] fp32 (deterministic,
- * no atomics); apply finalises mean/rstd in fp64 from the partials and writes y [N*HW][C1+C2] fp16. */
-#define LR_GN_CHUNKS 64
+ * Two launches: stats writes per-chunk partial (sum, sumsq) to `partials` (caller provides N*LR_GN_CHUNKS*64 floats; the
+ * number of chunks actually used is a deterministic function of N and HW) -- no atomics, bitwise reproducible; apply
+ * finalises mean/rstd in fp64 from the partials and writes y [N*HW][C1+C2] fp16. */
+#define LR_GN_CHUNKS 256
 int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
                        lr_stream_t s);
 int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,

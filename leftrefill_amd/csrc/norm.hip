@@ -4,6 +4,8 @@
 // (8 x fp16) vector, consecutive lanes read consecutive 16-byte pieces of a row => full-line coalescing.
 #include "common.h"
 
+#include <stdlib.h>
+
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm statistics.  grid = (LR_GN_CHUNKS, N); block = nOct * R threads where nOct = C/8 octets per pixel and
 // R = pixel rows per sweep.  Thread (o, r) always owns octet o and keeps per-channel fp32 (sum, sumsq); the block
@@ -11,14 +13,14 @@
 // partials[n][chunk][32][2].
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
-                                float* __restrict__ partials, int nOct, int R) {
+                                float* __restrict__ partials, int nOct, int R, int nchunks) {
   extern __shared__ float s_part[];  // [R][C][2]
   const int C = C1 + C2;
   const int Cg = C / 32;
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int t = threadIdx.x;
   const int o = t % nOct, r = t / nOct;
-  const int per = (HW + LR_GN_CHUNKS - 1) / LR_GN_CHUNKS;
+  const int per = (HW + nchunks - 1) / nchunks;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   const int c0 = o * 8;
   const f16* src;
@@ -59,7 +61,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
     float s = 0.f, q = 0.f;
     for (int c = t * Cg; c < (t + 1) * Cg; ++c)
       for (int rr = 0; rr < R; ++rr) { s += s_part[((size_t)rr * C + c) * 2]; q += s_part[((size_t)rr * C + c) * 2 + 1]; }
-    float* dst = partials + (((size_t)n * LR_GN_CHUNKS + chunk) * 32 + t) * 2;
+    float* dst = partials + (((size_t)n * nchunks + chunk) * 32 + t) * 2;
     dst[0] = s;
     dst[1] = q;
   }
@@ -75,7 +77,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
 __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
                                 const float* __restrict__ partials, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, f16* __restrict__ y,
-                                int pix_per_block, int nOct, int R) {
+                                int pix_per_block, int nOct, int R, int nchunks) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = C1 + C2;
   const int Cg = C / 32;
@@ -105,9 +107,9 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* _
   if (t < 128) {   // 4 lanes per group split the partials (blockDim >= 128 always)
     const int g = t >> 2, sub = t & 3;
     double s = 0.0, q = 0.0;
-    const float* ps = partials + ((size_t)n * LR_GN_CHUNKS * 32 + g) * 2;
+    const float* ps = partials + ((size_t)n * nchunks * 32 + g) * 2;
 #pragma unroll 4
-    for (int c = sub; c < LR_GN_CHUNKS; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+    for (int c = sub; c < nchunks; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
 #pragma unroll
     for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
     if (sub == 0) {
@@ -213,6 +215,22 @@ __global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restr
   }
 }
 
+// Number of pixel chunks actually used for a tensor of HW pixels per sample (both kernels derive it the same way).
+// Measured on MI355X inside a hipGraph (tools/bench_gn.py): ~256 stats blocks / ~512 apply blocks is the sweet spot --
+// more blocks lose to the per-block prologue, fewer starve the 256 CUs.  Env overrides are for experiments only.
+static int gn_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int gn_nchunks(int N, int HW) {
+  static const int target_blocks = gn_env("LR_GN_STAT_BLOCKS", 256);
+  int c = (target_blocks + N - 1) / N;
+  if (c > LR_GN_CHUNKS) c = LR_GN_CHUNKS;
+  if (c > HW / 8) c = HW / 8;
+  if (c < 1) c = 1;
+  return c;
+}
+
 extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
                                   lr_stream_t s) {
   if (!x1 || !partials || N <= 0 || HW <= 0) return LR_E_ARG;
@@ -224,9 +242,10 @@ extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, 
   if (R < 1) R = 1;
   const int threads = nOct * R;
   if (threads > 1024) return LR_E_UNSUPPORTED;
-  dim3 grid(LR_GN_CHUNKS, N);
+  const int nchunks = gn_nchunks(N, HW);
+  dim3 grid(nchunks, N);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)R * C * 2 * sizeof(float), (hipStream_t)s,
-                     (const f16*)x1, C1, (const f16*)x2, C2, HW, partials, nOct, R);
+                     (const f16*)x1, C1, (const f16*)x2, C2, HW, partials, nOct, R, nchunks);
   return lr_launch_status();
 }
 
@@ -246,11 +265,15 @@ extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, 
   int R = 256 / nOct;
   if (R < 1) R = 1;
   const int threads = nOct * R;
+  static const int apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 512);
+  ppb = (int)(((long long)N * HW + apply_blocks - 1) / apply_blocks);
+  if (ppb < 16) ppb = 16;
+  if (ppb > HW) ppb = HW;
   ppb = ((ppb + 4 * R - 1) / (4 * R)) * (4 * R);   // whole 4-deep load batches per thread (no serial tail)
   dim3 grid((HW + ppb - 1) / ppb, N);
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, (hipStream_t)s, (const f16*)x1, C1, (const f16*)x2, C2,
-                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R);
+                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, gn_nchunks(N, HW));
   return lr_launch_status();
 }
 

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import GemmArgs
 
-GN_CHUNKS = 64
+GN_CHUNKS = 256
 
 # ---- tile autotuner for lr_gemm_conv_f16 ------------------------------------------------------------------------
 # The UNet has ~50 distinct static GEMM shapes.  On first sight of a shape (eager warm-up before hipGraph capture) every
