@@ -54,3 +54,49 @@ def sample_sharded(sample_fn, cond, uncond, x_T, batch_size):
     out = sample_fn(shard_tree(cond, rank, world, batch_size), shard_tree(uncond, rank, world, batch_size),
                     None if x_T is None else x_T[s:e], e - s)
     return all_gather_cat(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Multi-view inference, one stitched canvas [ref_i | target] per rank.
+#
+# Reference semantics (ldm/modules/multiview_attention.py:440-460, concat_target=True): the self-attention sequence of a
+# sample is [target(canvas 0), ref_0, ..., ref_{v-1}] ((v+1) s^2 tokens); afterwards the target rows are written to the
+# right half of EVERY canvas and ref_i to canvas i's left half.  Sharded form: every rank all-gathers the raw canvases
+# (one collective per transformer block), forms K/V for the whole sequence, computes Q / attention / out-projection only
+# for its own rows [target, ref_rank] (the target rows are replicated work, bit-identical on every rank, so no second
+# exchange is needed for the write-back), and rebuilds its own canvas.  Everything else in the UNet is canvas-local.
+# The helpers below are device-agnostic (torch + torch.distributed only) so the index logic is covered by gloo tests.
+# ---------------------------------------------------------------------------------------------------------------
+def mv_group_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def mv_all_gather_canvases(x_local):
+    """x_local [b, T, C] (this rank's canvas of each of the b local sample groups) -> [b, v, T, C] in rank order."""
+    world = mv_group_size()
+    if world == 1:
+        return x_local[:, None]
+    bufs = [torch.empty_like(x_local) for _ in range(world)]
+    dist.all_gather(bufs, x_local.contiguous())
+    return torch.stack(bufs, dim=1)
+
+
+def mv_sequence_from_canvases(x_all, s):
+    """[b, v, s*2s, C] canvases -> [b, (v+1)*s*s, C] sequence [target(canvas 0), ref_0 .. ref_{v-1}] (pure torch)."""
+    b, v, T, C = x_all.shape
+    g = x_all.reshape(b, v, s, 2 * s, C)
+    seq = torch.cat([g[:, 0:1, :, s:, :], g[:, :, :, :s, :]], dim=1)
+    return seq.reshape(b, (v + 1) * s * s, C)
+
+
+def mv_own_rows(seq, rank, s):
+    """Rows this rank owns as queries: the target block and its own reference block -> [b, 2*s*s, C]."""
+    s2 = s * s
+    return torch.cat([seq[:, :s2], seq[:, (1 + rank) * s2:(2 + rank) * s2]], dim=1)
+
+
+def mv_canvas_from_own(y, s):
+    """[b, 2*s*s, C] rows [target', ref'] -> canvas tokens [b, s*2s, C] (left = ref', right = target')."""
+    b, _, C = y.shape
+    t, r = y[:, :s * s].reshape(b, s, s, C), y[:, s * s:].reshape(b, s, s, C)
+    return torch.cat([r, t], dim=2).reshape(b, 2 * s * s, C)

@@ -194,6 +194,8 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468."""
     if pt.view_num is None:
         x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, N, L, x)
+    elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
+        x = _mv_sharded_self_attention(x, pt, N, L)
     elif pt.concat_target and not pt.no_rearrange:
         v = pt.view_num - 1
         b = N // v
@@ -212,6 +214,34 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None):
     n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
     g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
     return linear(g, pt.ff2, resid=x)
+
+
+# One canvas per rank (torch.distributed world == view_num - 1): set by UNetModel when `mv_shard=True`.
+MV_SHARDED = False
+
+
+def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
+    """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (one RCCL all-gather
+    per block; see leftrefill_amd.dist).  x [N*L, C] = this rank's canvas for each of its N local samples."""
+    import torch.distributed as tdist
+    from . import dist as lrd
+    C = x.shape[1]
+    s = int(math.sqrt(L / 2))
+    assert 2 * s * s == L
+    v = pt.view_num - 1
+    world = lrd.mv_group_size()
+    assert world == v, f"multi-view sharding needs world_size == view_num - 1 ({world} vs {v})"
+    rank = tdist.get_rank() if world > 1 else 0
+    x_all = lrd.mv_all_gather_canvases(x.reshape(N, L, C))                    # [N, v, L, C]
+    seq = ops.mv_gather(x_all.reshape(N * v * L, C), N, v, s)                 # [N*(v+1)*s*s, C]
+    Ls = (v + 1) * s * s
+    n_seq = ops.layer_norm(seq, pt.n1.g, pt.n1.b, pt.n1.eps)
+    qkv = linear(n_seq, pt.attn1.qkv)                                         # K/V needed for all rows; Q is cheap
+    own_q = lrd.mv_own_rows(qkv[:, :C].reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
+    own_x = lrd.mv_own_rows(seq.reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
+    a = ops.attention(own_q, qkv[:, C:2 * C], qkv[:, 2 * C:], N, pt.attn1.heads, L, Ls, pt.attn1.dim_head ** -0.5)
+    y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target', ref_rank']
+    return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
 
 
 def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):

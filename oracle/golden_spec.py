@@ -165,6 +165,7 @@ MV_CASES = [
     ("mv_v5_concat", 5, True, 1, 8, 16),
     ("mv_v2_plain", 2, False, 2, 8, 8),
     ("mv_v4_plain", 4, False, 1, 8, 8),
+    ("mv_v2_concat", 2, True, 2, 8, 16),   # one canvas per sample: the 1-rank case of the canvas-sharded path
 ]
 
 

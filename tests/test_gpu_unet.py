@@ -154,6 +154,25 @@ def test_multiview_unet(golden, case, V, concat, b, H, W):
     check_unet(golden, case, "MV", n, H, W, [501] * n, fname="multiview", multiview=(V, concat))
 
 
+def test_multiview_canvas_sharded_path_single_rank(golden):
+    """`mv_shard=True` code path (all-gather of canvases + own-row attention) in its 1-rank form == the fused path."""
+    case, V, concat, b, H, W = [c for c in G.MV_CASES if c[0] == "mv_v2_concat"][0]
+    m, sd, cfg = get_model("MV", (V, concat))
+    n = b * (V - 1)
+    x, t, ctx = G.unet_inputs(case, cfg, n, H, W, [501] * n)
+    ref = torch.from_numpy(golden("multiview")[case])
+    with torch.no_grad():
+        y_fused = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
+        m.mv_shard = True
+        try:
+            y_shard = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
+        finally:
+            m.mv_shard = False
+    rel, _ = stats("mv sharded (1 rank) " + case, y_shard, ref)
+    assert torch.equal(y_shard, y_fused), "1-rank sharded path must reproduce the fused gather/scatter path bit for bit"
+    assert rel < 4e-3
+
+
 def test_context_kv_cache_is_invalidated_correctly():
     """The step graph caches the cross-attention K/V projections per context tensor (constant over the DDIM loop)."""
     m, sd, cfg = get_model("MID")

@@ -262,3 +262,59 @@ def test_full_vae_key_count():
     assert len(sd) == 248 and sd["encoder.conv_out.weight"].shape == (8, 512, 3, 3)
     assert sd["decoder.up.3.upsample.conv.weight"].shape == (512, 512, 3, 3)
     assert abs(sum(v.numel() for v in sd.values()) / 1e6 - 83.65) < 0.01
+
+
+# ---- canvas-sharded multi-view attention: exchange / row-ownership / write-back logic on a world_size-2 gloo group ----
+def _mv_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from leftrefill_amd import dist as lrd
+    from oracle import golden_spec as G, unet_ref, weights
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, v, s, C, heads = 2, world, 4, 64, 2
+    L = 2 * s * s
+    x_full = G.T("mvd.x", (b * v, L, C))                       # '(b v) hw c' batch of canvases
+    sd = weights.fill_state_dict({"m.attn1.to_q.weight": (C, C), "m.attn1.to_k.weight": (C, C),
+                                  "m.attn1.to_v.weight": (C, C), "m.attn1.to_out.0.weight": (C, C),
+                                  "m.attn1.to_out.0.bias": (C,), "m.norm1.weight": (C,), "m.norm1.bias": (C,)},
+                                 prefix="mvd.")
+    mode = unet_ref._Mode("fp32")
+    # single-process oracle: gather -> LN -> attn1 + residual -> scatter (multiview_attention.py:436-462)
+    seq, info = unet_ref.mv_gather(x_full, v + 1, True, False)
+    n1 = unet_ref.layer_norm(seq, sd["m.norm1.weight"], sd["m.norm1.bias"])
+    ref = unet_ref.mv_scatter(unet_ref.cross_attention(sd, "m.attn1", n1, n1, heads, mode) + seq, v + 1, True, False, info)
+    ref = ref.reshape(b, v, L, C)[:, rank]
+    # sharded: this rank only holds canvas `rank` of every sample
+    x_local = x_full.reshape(b, v, L, C)[:, rank].contiguous()
+    x_all = lrd.mv_all_gather_canvases(x_local)
+    sq = lrd.mv_sequence_from_canvases(x_all, s)
+    assert torch.equal(sq, seq)
+    n = unet_ref.layer_norm(sq, sd["m.norm1.weight"], sd["m.norm1.bias"])
+    qq = torch.nn.functional.linear(n, sd["m.attn1.to_q.weight"])
+    kk = torch.nn.functional.linear(n, sd["m.attn1.to_k.weight"])
+    vv = torch.nn.functional.linear(n, sd["m.attn1.to_v.weight"])
+    a = unet_ref.attention(lrd.mv_own_rows(qq, rank, s), kk, vv, heads, mode)
+    y = torch.nn.functional.linear(a, sd["m.attn1.to_out.0.weight"], sd["m.attn1.to_out.0.bias"]) + lrd.mv_own_rows(sq, rank, s)
+    out = lrd.mv_canvas_from_own(y, s)
+    q.put((rank, float((out - ref).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_multiview_canvas_sharding_gloo_world2():
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert [r for r, _ in res] == [0, 1]
+    assert all(err < 1e-5 for _, err in res), res
