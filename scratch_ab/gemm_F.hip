@@ -257,24 +257,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
 #define BM2 256
 #define GEMM2_THREADS 512
 
-// Buffer descriptor from provably wave-uniform pieces (readfirstlane), otherwise hipcc wraps every buffer op in a
-// waterfall loop (guide T20).  The descriptor type only exists in the device pass of hipcc, hence the guard (the host
-// pass still has to see the kernel declaration to emit its launch stub).
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, size_t bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const int n = __builtin_amdgcn_readfirstlane((int)bytes);
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
-}
-#endif
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BN>
 __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
-#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = 4;                 // wave tile 64 rows
   constexpr int TN = BN / 32;           // wave tile BN/2 cols  (4 for 128, 5 for 160)
   constexpr int A_BYTES = BM2 * 128;
@@ -322,39 +308,34 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   const int k_per = (nk_all + P.splits - 1) / P.splits;
   const int k_begin = blockIdx.y * k_per;
   const int nk = min(nk_all, k_begin + k_per);
+  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
 
-  // LDS-DMA through buffer descriptors: address = SRD base + per-lane voffset (VGPR, fixed within a tap) + soffset
-  // (SGPR, the K-step's channel offset).  A K-step therefore issues its 6-7 `buffer_load_dwordx4 ... lds` with NO
-  // per-lane address arithmetic, and padding / tails need no zero page: an out-of-range voffset reads as 0.
-  const unsigned OOB = 0x80000000u;
-  const size_t a1_bytes = (size_t)P.Hs * P.Ws * P.C1 * 2 * (P.M / HW);
-  const size_t a2_bytes = P.p2 ? (size_t)P.Hs * P.Ws * P.C2 * 2 * (P.M / HW) : 0;
-  const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.wt, (size_t)P.N * P.K * 2);
-
-  // weight rows (fixed over K): instr i covers rows (i*8 + w)*8 + lane/8
-  unsigned wvo[NB_FULL + 1];
+  // weight row pointers (fixed over K): instr i covers rows (i*8 + w)*8 + lane/8
+  const f16* wrow[NB_FULL + 1];
 #pragma unroll
   for (int i = 0; i < NB_FULL + 1; ++i) {
     const int row = (i * 8 + w) * 8 + (lane >> 3);
     const int n = n0 + row;
     const int chunk = slot ^ ((row >> 1) & 7);
-    wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
+    wrow[i] = (row < BN && n < P.N) ? P.wt + (size_t)n * P.K + chunk * 8 : nullptr;
   }
 
-  // gather state: per-row byte offset of the current (tap, source) segment, recomputed only when the tap or the concat
-  // source changes
-  unsigned avo[4] = {OOB, OOB, OOB, OOB};
+  // gather state: per-row base pointer of the current (tap, source) segment
+  const f16* aptr[4];
+  unsigned amask = 0;
   int seg_tap = -1, seg_src = -1;
   auto stage = [&](int buf, int kt) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
     const int tap = kt / cpt, cc = kt - tap * cpt;
     const int srcsel = cc < cpt1 ? 0 : 1;
-    if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform
+    if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing the concat boundary
       seg_tap = tap; seg_src = srcsel;
       int dy = 0, dx = 0;
       if (P.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      const f16* src = srcsel ? P.p2 : P.p1;
       const int cs = srcsel ? P.C2 : P.C1;
+      amask = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (i * 8 + w) * 8 + (lane >> 3);
@@ -362,21 +343,25 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
         const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
         const int sy = iy >> P.up, sx = ix >> P.up;
         const int chunk = slot ^ ((row >> 1) & 7);
-        avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
+        aptr[i] = src + (size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8;
+        amask |= ok ? (1u << i) : 0u;
       }
     }
-    const unsigned coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
-    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(srcsel ? (const void*)P.p2 : (const void*)P.p1,
-                                                    srcsel ? a2_bytes : a1_bytes);
+    const int coff = (srcsel ? cc - cpt1 : cc) * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * 8 + w) * 8) * 128), 16, avo[i], coff, 0, 0);
-    const unsigned koff = (unsigned)(kt * 128);
+    for (int i = 0; i < 4; ++i) {
+      const f16* g = (amask >> i) & 1 ? aptr[i] + coff : zero;
+      glds16(g, As + ((i * 8 + w) * 8) * 128);
+    }
 #pragma unroll
-    for (int i = 0; i < NB_FULL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * 8 + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
-    if (B_TAIL && w < 4)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((NB_FULL * 8 + w) * 8) * 128), 16, wvo[NB_FULL], koff, 0, 0);
+    for (int i = 0; i < NB_FULL; ++i) {
+      const f16* g = wrow[i] ? wrow[i] + kt * 64 : zero;
+      glds16(g, Bs + ((i * 8 + w) * 8) * 128);
+    }
+    if (B_TAIL && w < 4) {
+      const f16* g = wrow[NB_FULL] ? wrow[NB_FULL] + kt * 64 : zero;
+      glds16(g, Bs + ((NB_FULL * 8 + w) * 8) * 128);
+    }
   };
 
   f32x4 acc[TN][TM];
@@ -425,37 +410,56 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     }
   };
 
+  // Staggered two-group schedule.  Each K-step is four barrier-delimited intervals per wave:
+  //   N0: issue LDS-DMA of stage it+2, ds_read fragments (it, k 0..31), lgkmcnt(0)   | barrier
+  //   M0: 20 MFMAs                                                                    | barrier
+  //   N1: wait own LDS-DMA of stage it+1, ds_read fragments (it, k 32..63), lgkmcnt(0)| barrier
+  //   M1: 20 MFMAs                                                                    | barrier
+  // Waves 4..7 (the second wave of every SIMD) execute ONE extra barrier up front and so run exactly one interval
+  // behind waves 0..3: while one wave of a SIMD issues MFMAs the other does its LDS / address / wait work, instead of
+  // both idling the matrix pipe at the same time (measured: the lockstep version parks 36 % of wave cycles).
+  // Hazards under the one-interval lag: a stage is read one full K-step after every wave waited for its own part of it
+  // (wait in N1 of step it, first read in N0 of step it+1, at least one barrier after the lagging group's wait); a
+  // buffer is refilled in N0 of step it+1, after the barrier that closes the lagging group's last read (N1 of step it),
+  // and every N interval drains its ds_reads before its barrier.
   const int nsteps = nk - k_begin;
+  const bool lag = w >= 4;
   if (nsteps > 0) stage(0, k_begin);
   if (nsteps > 1) stage(1, k_begin + 1);
-  if (nsteps > 2) stage(2, k_begin + 2);
-  f16x8 xa[TM], wa[TN], xb[TM], wb[TN];
-  if (nsteps > 0) {
-    wait_stages(nsteps > 2 ? 2 : nsteps - 1);
-    __builtin_amdgcn_s_barrier();
-    read_frags(xa, wa, 0, 0);
-  }
+  wait_stages(nsteps > 1 ? 1 : 0);
+  __builtin_amdgcn_s_barrier();                 // stage 0 of every wave has landed (both groups still aligned)
+  if (lag) __builtin_amdgcn_s_barrier();        // start of the stagger
+  f16x8 xa[TM], wa[TN];
   int cur = 0;
   for (int it = 0; it < nsteps; ++it) {
     const int nxt = cur == 2 ? 0 : cur + 1;
-    // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]: left alone, the
-    // machine scheduler sinks the ds_reads next to their consumers and re-serialises LDS latency with the MFMAs
-    read_frags(xb, wb, cur, 1);
+    // ---- N0
+    if (it + 2 < nsteps) stage(nxt == 2 ? 0 : nxt + 1, k_begin + it + 2);
+    read_frags(xa, wa, cur, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- M0
+    __builtin_amdgcn_s_setprio(1);
     mma(xa, wa);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < nsteps) {
-      wait_stages(it + 2 < nsteps ? 1 : 0);            // stage it+1 landed; stage it+2 may stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage `it` are in registers
-      __builtin_amdgcn_s_barrier();
-      if (it + 3 < nsteps) stage(cur, k_begin + it + 3);  // refill the buffer every wave has finished with
-      read_frags(xa, wa, nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mma(xb, wb);
+    __builtin_amdgcn_s_barrier();
+    // ---- N1
+    if (it + 1 < nsteps) wait_stages(it + 2 < nsteps ? 1 : 0);
+    read_frags(xa, wa, cur, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- M1
+    __builtin_amdgcn_s_setprio(1);
+    mma(xa, wa);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
     cur = nxt;
   }
+  if (!lag) __builtin_amdgcn_s_barrier();       // pairs with the lagging group's last barrier
   __syncthreads();   // every wave is done with the stage buffers before they become the epilogue tile
 
   // ---- epilogue in two passes of 128 rows (fp32 tile in LDS: 128 x (BNo + 4) floats <= 84 KB)
@@ -532,7 +536,6 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     }
     __syncthreads();
   }
-#endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <int BN>
