@@ -289,11 +289,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN>
+// WMW = waves along M (the other 8 / WMW along N); NSTAGE = depth of the LDS-DMA ring.  Instances:
+//   <128, 4, 3>, <160, 4, 3>: wave tile 64 x BN/2, 3-stage ring (loads two K-steps ahead)
+//   <320, 2, 2>            : wave tile 128 x 80 (40 accumulator tiles): 28 % fewer LDS bytes per MFMA and 31 % less
+//                            L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
+template <int BN, int WMW, int NSTAGE>
 __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int TM = 4;                 // wave tile 64 rows
-  constexpr int TN = BN / 32;           // wave tile BN/2 cols  (4 for 128, 5 for 160)
+  constexpr int WNW = 8 / WMW;
+  constexpr int TM = BM2 / WMW / 16;    // 16-row MFMA tiles per wave along M
+  constexpr int TN = BN / WNW / 16;     // 16-col MFMA tiles per wave along N
+  constexpr bool DB = TM * TN <= 20;    // double-buffer the fragments in registers when the accumulators leave room
   constexpr int A_BYTES = BM2 * 128;
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WNW, wn = w % WNW;
 
   int bid = blockIdx.x;
   {
@@ -413,12 +419,12 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     const int kc = ks * 4 + fq;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row = wm * 64 + i * 16 + fr;
+      const int row = wm * (TM * 16) + i * 16 + fr;
       xf[i] = *reinterpret_cast<const f16x8*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int row = wn * (BN / 2) + j * 16 + fr;
+      const int row = wn * (TN * 16) + j * 16 + fr;
       wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     }
   };
@@ -443,73 +449,93 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   };
 
   const int nsteps = nk - k_begin;
-  if (nsteps > 0) stage(0, k_begin);
-  if (nsteps > 1) stage(1, k_begin + 1);
-  if (nsteps > 2) stage(2, k_begin + 2);
-  f16x8 xa[TM], wa[TN], xb[TM], wb[TN];
+#pragma unroll
+  for (int sidx = 0; sidx < NSTAGE; ++sidx)
+    if (sidx < nsteps) stage(sidx, k_begin + sidx);
+  f16x8 xa[TM], wa[TN];
   if (nsteps > 0) {
-    wait_stages(nsteps > 2 ? 2 : nsteps - 1);
+    wait_stages(nsteps > NSTAGE - 1 ? NSTAGE - 1 : nsteps - 1);
     __builtin_amdgcn_s_barrier();
-    read_frags(xa, wa, 0, 0);
+    if constexpr (DB) read_frags(xa, wa, 0, 0);
   }
   int cur = 0;
-  for (int it = 0; it < nsteps; ++it) {
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]: left alone, the
-    // machine scheduler sinks the ds_reads next to their consumers and re-serialises LDS latency with the MFMAs
-    read_frags(xb, wb, cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(xa, wa);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < nsteps) {
-      wait_stages(it + 2 < nsteps ? 1 : 0);            // stage it+1 landed; stage it+2 may stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage `it` are in registers
-      __builtin_amdgcn_s_barrier();
-      if (it + 3 < nsteps) stage(cur, k_begin + it + 3);  // refill the buffer every wave has finished with
-      read_frags(xa, wa, nxt, 0);
+  if constexpr (DB) {
+    f16x8 xb[TM], wb[TN];
+    for (int it = 0; it < nsteps; ++it) {
+      const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
+      // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]
+      read_frags(xb, wb, cur, 1);
       __builtin_amdgcn_sched_barrier(0);
+      mma(xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < nsteps) {
+        wait_stages(nsteps - it - 2 < NSTAGE - 2 ? nsteps - it - 2 : NSTAGE - 2);   // stage it+1 landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage `it` are in registers
+        __builtin_amdgcn_s_barrier();
+        if (it + NSTAGE < nsteps) stage(cur, k_begin + it + NSTAGE);  // refill the buffer every wave has finished with
+        read_frags(xa, wa, nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma(xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
-    mma(xb, wb);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = nxt;
+  } else {
+    for (int it = 0; it < nsteps; ++it) {
+      const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
+      read_frags(xa, wa, cur, 0);
+      mma(xa, wa);
+      read_frags(xa, wa, cur, 1);
+      mma(xa, wa);
+      if (it + 1 < nsteps) {
+        wait_stages(nsteps - it - 2 < NSTAGE - 2 ? nsteps - it - 2 : NSTAGE - 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + NSTAGE < nsteps) stage(cur, k_begin + it + NSTAGE);
+      }
+      cur = nxt;
+    }
   }
   __syncthreads();   // every wave is done with the stage buffers before they become the epilogue tile
 
-  // ---- epilogue in two passes of 128 rows (fp32 tile in LDS: 128 x (BNo + 4) floats <= 84 KB)
+  // ---- epilogue in four passes of 64 rows (fp32 tile in LDS: 64 x (BNo + 4) floats <= 83 KB)
   float* Cs = reinterpret_cast<float*>(smem);
   const int BNo = P.geglu ? BN / 2 : BN;
   const int ldc = BNo + 4;
   const int n_out0 = P.geglu ? n0 / 2 : n0;
   const int N_out = P.geglu ? P.N / 2 : P.N;
   const int cpr = BNo >> 3;
-  for (int pass = 0; pass < 2; ++pass) {
-    if ((wm >> 1) == pass) {
-      const int wml = wm & 1;
+  constexpr int UNITS = TM / 4;            // 64-row units per wave tile
+  for (int pass = 0; pass < 4; ++pass) {
+    if (wm == pass / UNITS) {
+      const int i0 = (pass % UNITS) * 4;   // accumulator tile rows i0 .. i0+3 belong to this pass
       if (!P.geglu) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int nl = wn * (BN / 2) + j * 16 + fq * 4;
+          const int nl = wn * (TN * 16) + j * 16 + fq * 4;
           f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const int ml = wml * 64 + i * 16 + fr;
+            if (i < i0 || i >= i0 + 4) continue;
+            const int ml = (i - i0) * 16 + fr;
             *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
           }
         }
       } else if constexpr (TN % 2 == 0) {
 #pragma unroll
         for (int jp = 0; jp < TN / 2; ++jp) {
-          const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;
+          const int nl_u = wn * (TN * 16) + (2 * jp) * 16 + fq * 4;
           f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
           if (P.bias && n0 + nl_u + 16 < P.N) {
             bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
             bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
           }
-          const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
+          const int ol = wn * (TN * 8) + jp * 16 + fq * 4;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const int ml = wml * 64 + i * 16 + fr;
+            if (i < i0 || i >= i0 + 4) continue;
+            const int ml = (i - i0) * 16 + fr;
             const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
             f32x4 o;
 #pragma unroll
@@ -520,9 +546,9 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
       }
     }
     __syncthreads();
-    for (int id = t; id < 128 * cpr; id += GEMM2_THREADS) {
+    for (int id = t; id < 64 * cpr; id += GEMM2_THREADS) {
       const int row = id / cpr, cch = id - row * cpr;
-      const int m = m0 + pass * 128 + row, n = n_out0 + cch * 8;
+      const int m = m0 + pass * 64 + row, n = n_out0 + cch * 8;
       if (m >= P.M || n >= N_out) continue;
       const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
       const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
@@ -552,7 +578,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BN>
+template <int BN, int WMW, int NSTAGE>
 static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
@@ -560,16 +586,16 @@ static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
   P.ntiles_m = ntm;
   P.m_fastest = 0;   // measured on MI355X: n-fastest wins even for 3.7 MB weight slices (1038 vs 928 TFLOP/s)
   P.nblocks = P.ntiles_n * ntm;
-  size_t smem = 3 * (size_t)(BM2 + BN) * 128;
-  const size_t epi = (size_t)128 * (BN + 4) * sizeof(float);
+  size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128;
+  const size_t epi = (size_t)64 * (BN + 4) * sizeof(float);
   if (epi > smem) smem = epi;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_conv256_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
@@ -723,8 +749,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (tm == 128 && tn == 128) rc = launch_gemm<128>(P, st);
   else if (tm == 128 && tn == 64) rc = launch_gemm<64>(P, st);
   else if (tm == 128 && tn == 160 && !P.geglu) rc = launch_gemm<160>(P, st);
-  else if (tm == 256 && tn == 128) rc = launch_gemm256<128>(P, st);
-  else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160>(P, st);
+  else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3>(P, st);
+  else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160, 4, 3>(P, st);
+  else if (tm == 256 && tn == 320 && !P.geglu) rc = launch_gemm256<320, 2, 2>(P, st);
   else return LR_E_UNSUPPORTED;
   if (rc || P.splits == 1) return rc;
   return launch_reduce(P, st);

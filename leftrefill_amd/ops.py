@@ -17,7 +17,7 @@ GN_CHUNKS = 256
 # tile configuration is timed with HIP events and the fastest is cached.  All tile configurations accumulate K in the
 # same order, so the choice never changes results bit-wise (split-K stays a deterministic function of the shape).
 AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "1") != "0"
-TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160))
+TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 320))
 _tile_cache = {}
 
 
@@ -178,7 +178,7 @@ def _tune_tiles(lib, a, device, geglu, reps=3):
     st = _stream()
     best, best_t = None, float("inf")
     for tm, tn in TILE_CANDIDATES:
-        if geglu and tn == 160:
+        if geglu and tn in (160, 320):
             continue
         a.tile_m, a.tile_n = tm, tn
         ws = _workspace(lib, a, device)

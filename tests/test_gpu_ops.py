@@ -176,11 +176,11 @@ def test_conv3x3_variants():
     _conv_case("c3_m_tail", 1, 128, 64, 5, 9)  # M = 45 < tile
 
 
-@pytest.mark.parametrize("tile_n", [128, 160])
+@pytest.mark.parametrize("tile_n", [128, 160, 320])
 def test_conv_tile256(tile_n):
     """The 256-row, 8-wave, 3-stage counted-vmcnt kernel: every gather mode, tails in M and N, split-K."""
     k = dict(tile_m=256, tile_n=tile_n)
-    co = 320 if tile_n == 160 else 384
+    co = 384 if tile_n == 128 else 320
     _conv_case(f"t256_{tile_n}_c3", 2, 320, co, 16, 24, **k)                       # M = 768
     _conv_case(f"t256_{tile_n}_tail", 1, 128, co, 9, 13, rowvec=True, resid=True, **k)   # M = 117 (< one tile)
     _conv_case(f"t256_{tile_n}_cat", 2, 320, 640, 12, 20, C2=640, rowvec=True, resid=True, **k)

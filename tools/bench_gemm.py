@@ -50,7 +50,7 @@ if __name__ == "__main__":
     if len(a.dims) >= 6:
         cfgs = [(a.dims[4], a.dims[5], a.dims[6] if len(a.dims) > 6 else 0)]
     else:
-        cfgs = [(128, 64, 0), (128, 128, 0), (128, 160, 0), (256, 128, 0), (256, 160, 0)]
+        cfgs = [(128, 64, 0), (128, 128, 0), (128, 160, 0), (256, 128, 0), (256, 160, 0), (256, 320, 0)]
     for tm, tn, sp in cfgs:
         try:
             us, tf = run(M, N, K, taps, tm, tn, sp, a.reps)
