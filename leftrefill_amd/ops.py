@@ -178,7 +178,7 @@ def _tune_tiles(lib, a, device, geglu, reps=3):
     st = _stream()
     best, best_t = None, float("inf")
     for tm, tn in TILE_CANDIDATES:
-        if geglu and tn in (160, 320):
+        if geglu and tn == 160:
             continue
         a.tile_m, a.tile_n = tm, tn
         ws = _workspace(lib, a, device)

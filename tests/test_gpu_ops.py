@@ -211,8 +211,10 @@ def test_geglu_tile256():
     u, gate = F.linear(x, w, b).chunk(2, dim=-1)
     ref = u * F.gelu(gate)
     wp, bp = packing.pack_geglu(w, b)
-    y = ops.gemm_conv(x.half().to(d), wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=256, tile_n=128)
-    report("geglu tile256", y, ref)
+    for tn in (128, 320):
+        y = ops.gemm_conv(x.half().to(d), wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=256,
+                          tile_n=tn)
+        report(f"geglu tile256x{tn}", y, ref)
 
 
 def test_conv_split_k():
