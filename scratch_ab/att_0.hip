@@ -1,8 +1,8 @@
 // Fused scaled-dot-product attention forward (flash-style online softmax), d_head = 64, fp16 in / fp32 accumulate.
 //
-// Work split: block = 4 waves = 256 queries of one (batch, head); each wave owns 64 queries (two 32-query blocks that
-// share every K / V fragment read from LDS) and streams the K/V sequence in 64-key tiles.  Per tile and wave:
-// S^T = K Q^T (16 x mfma 32x32x16) -> online softmax in registers -> O^T += V^T P^T (16 x mfma 32x32x16).
+// Work split: block = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries and streams the K/V
+// sequence in 64-key tiles.  Per tile and wave: S^T = K Q^T (8 x mfma 32x32x16) -> online softmax in registers ->
+// O^T += V^T P^T (8 x mfma 32x32x16).
 //
 // * "Swapped" products: computing S^T / O^T puts ONE query per lane (column = lane & 31), so the row-max / row-sum
 //   are in-lane reductions plus a single lane <-> lane+32 exchange, and the P^T B-operand of the second product is
@@ -13,13 +13,13 @@
 // * V tile is transposed on the way in: [64 d][64 keys] with a 136-byte pitch, written as packed key pairs
 //   (ds_write_b32), read as two ds_read_b64 per fragment (conflict-free at this pitch).
 // * Q fragments live in registers for the whole kernel; K/V double-buffered, one barrier per tile.
-// * The two query blocks of a wave are independent instruction streams: the QK^T / PV MFMAs of one overlap the
-//   exp2 / max / convert VALU work of the other.  The running-max rescale of O is deferred until a row max grows by
-//   more than 2^8 (exp2 domain).
+// * Software pipeline inside each wave: the QK^T MFMAs of tile j+1 are issued ahead of the softmax VALU stream of
+//   tile j, so the matrix pipe is busy while exp2 / max / fp16 convert run; the running-max rescale of O is deferred
+//   until a row max grows by more than 2^8 (exp2 domain).
 #include "common.h"
 
 #define ATT_THREADS 256
-#define ATT_QB 256
+#define ATT_QB 128
 #define ATT_KB 64
 #define VT_PITCH 136  // bytes per V^T row (64 keys * 2 B + 8 pad)
 
@@ -55,17 +55,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
 
   const int ql = lane & 31, hi = lane >> 5;
-  // each wave owns 64 queries as two 32-query blocks that share every K / V fragment read from LDS
-  int qrow[2];
-  f16x8 qf[2][4];   // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
+  const int qrow = qt * ATT_QB + w * 32 + ql;
+  const int qrow_c = min(qrow, P.Nq - 1);
+  // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
+  f16x8 qf[4];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    qrow[qb] = qt * ATT_QB + w * 64 + qb * 32 + ql;
-    const int qc = min(qrow[qb], P.Nq - 1);
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-      qf[qb][s4] = *reinterpret_cast<const f16x8*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
-  }
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *reinterpret_cast<const f16x8*>(qp + (size_t)qrow_c * P.ldq + s * 16 + hi * 8);
 
   const int ntiles = (P.Nkv + ATT_KB - 1) / ATT_KB;
 
@@ -104,102 +100,88 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     }
   };
 
-  f32x16 oacc[2][2];
+  f32x16 oacc[2];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int d = 0; d < 2; ++d)
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  {
-    uint4 v0, v1;
-    stage_k(0, 0);
-    load_v(0, v0, v1);
-    write_v(0, v0, v1);
-  }
-  __syncthreads();
-
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    const bool more = tile + 1 < ntiles;
-    uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
-    if (more) {
-      stage_k(cur ^ 1, tile + 1);
-      load_v(tile + 1, nv0, nv1);
-    }
-    const char* Ks = Ksm + cur * (ATT_KB * 128);
-    const char* Vs = Vsm + cur * (64 * VT_PITCH);
-
-    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: four independent accumulator chains (2 query blocks x 2 key blocks),
-    // every K fragment read from LDS feeds both query blocks
-    f32x16 sacc[2][2];
+  // S^T[key][q] = sum_d K[key][d] Q[q][d] for one 64-key tile held in K buffer `buf`
+  auto qk = [&](f32x16 (&sacc)[2], int buf) {
+    const char* Ks = Ksm + buf * (ATT_KB * 128);
+    // the two 32-key blocks are independent accumulator chains: alternate them so consecutive MFMAs never wait on
+    // each other's 16-pass latency
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int row = kb * 32 + ql;
         const int kc = s4 * 2 + hi;
         const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-          sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][kb], 0, 0, 0);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s4], s4 == 0 ? zero16 : sacc[kb], 0, 0, 0);
       }
+    }
+  };
 
-    f16x8 pf[2][2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
-      if (tile * ATT_KB + ATT_KB > P.Nkv) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = tile * ATT_KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= P.Nkv) sacc[qb][kb][r] = -INFINITY;
-          }
-      }
-      // ---- online softmax, one query per lane (partner lane ^ 32 holds the other half of the keys).  The running max
-      // is only raised (and O, l rescaled) when some row's max grew by more than 2^8 in the exp2 domain: P stays
-      // <= 256 and the common path skips 32 accumulator multiplies per lane.  m_run starts at -inf.
-      float mx = sacc[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
-      {  // max across the two half-waves with one VALU lane swap (v_permlane32_swap) instead of an LDS round trip
-        const unsigned u = __builtin_bit_cast(unsigned, mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-      }
-      if (!__all((mx - m_run[qb]) * P.c <= 8.0f)) {
-        const float m_new = fmaxf(m_run[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * P.c);
-        m_run[qb] = m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
-      }
-      const float mc = m_run[qb] * P.c;
-      float psum = 0.f;
+  // One pipeline step: the QK^T MFMAs of tile+1 are issued BEFORE the softmax VALU work of `tile` (independent
+  // registers), so the matrix pipe runs under the exp/max/convert stream of the same wave; then P V of `tile`.
+  //   K ring: K[tile+1] is read here, K[tile+2] is loaded into the buffer K[tile] vacated (its reads finished before
+  //   the barrier that ended the previous step).  V ring: V[tile] read, V[tile+1] written after the P V MFMAs.
+  auto step = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int tile) {
+    const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
+    uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
+    if (more2) stage_k(tile & 1, tile + 2);
+    if (more1) load_v(tile + 1, nv0, nv1);
+    if (more1) qk(sn, (tile + 1) & 1);
+
+    // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
+    if (tile * ATT_KB + ATT_KB > P.Nkv) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], P.c, -mc));
-          psum += p;
-          pf[qb][kb][r >> 3][r & 7] = (f16)p;
+          const int key = tile * ATT_KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= P.Nkv) sc[kb][r] = -INFINITY;
         }
-      l_run[qb] += psum;
     }
+    // ---- online softmax, one query per lane (partner lane ^ 32 holds the other half of the keys).
+    // The running max is only raised (and O, l rescaled) when some row's max grew by more than 2^8 in the exp2
+    // domain: P stays <= 256, exactly representable headroom in fp16, and the common path skips 32 accumulator
+    // multiplies per lane.  m_run starts at -inf, so the first tile always takes the rescale path.
+    float mx = sc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!__all((mx - m_run) * P.c <= 8.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * P.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = m_run * P.c;
+    float psum = 0.f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], P.c, -mc));
+        psum += p;
+        pf[kb][r >> 3][r & 7] = (f16)p;
+      }
+    l_run += psum;
 
     // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; k-slot (hi*8 + jj) of MFMA (kb, tt) is key
-    //      kb*32 + 16*tt + 4*hi + jj (jj < 4) and kb*32 + 16*tt + 8 + 4*hi + (jj - 4) (jj >= 4).
-    //      Every V^T fragment feeds both query blocks.
+    //      kb*32 + 16*tt + 4*hi + jj (jj < 4) and kb*32 + 16*tt + 8 + 4*hi + (jj - 4) (jj >= 4)
+    const char* Vs = Vsm + (tile & 1) * (64 * VT_PITCH);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -213,35 +195,41 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           f16x8 vf;
           vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
           vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb)
-            oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][tt], oacc[qb][db], 0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][tt], oacc[db], 0, 0, 0);
         }
-    if (more) write_v(cur ^ 1, nv0, nv1);
+    if (more1) write_v((tile + 1) & 1, nv0, nv1);
     __syncthreads();
+  };
+
+  {
+    uint4 v0, v1;
+    stage_k(0, 0);
+    if (ntiles > 1) stage_k(1, 1);
+    load_v(0, v0, v1);
+    write_v(0, v0, v1);
+  }
+  __syncthreads();
+  f32x16 sA[2], sB[2];
+  qk(sA, 0);
+  __syncthreads();   // nobody may overwrite K buffer 0 (tile 2) before every wave has finished its first QK^T
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    step(sA, sB, tile);
+    if (tile + 1 < ntiles) step(sB, sA, tile + 1);
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < P.Nq) {
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    float lt = l_run[qb];
-    {
-      const unsigned u = __builtin_bit_cast(unsigned, lt);
-      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      lt = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
-    }
-    const float inv = 1.0f / lt;
-    if (qrow[qb] < P.Nq) {
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int g = 0; g < 4; ++g) {
+        f16x4 ov;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f16x4 ov;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ov[i] = (f16)(oacc[qb][db][g * 4 + i] * inv);
-          *reinterpret_cast<f16x4*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * g + 4 * hi) = ov;
-        }
-    }
+        for (int i = 0; i < 4; ++i) ov[i] = (f16)(oacc[db][g * 4 + i] * inv);
+        *reinterpret_cast<f16x4*>(op + (size_t)qrow * P.ldo + db * 32 + 8 * g + 4 * hi) = ov;
+      }
   }
 }
 
