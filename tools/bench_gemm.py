@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leftrefill_amd import ops  # noqa: E402
 
 
-def run(M, N, K, taps, tm, tn, splits, reps, H=None):
+def run(M, N, K, taps, tm, tn, splits, reps, geglu=False):
     dev = torch.device("cuda:0")
     C = K // taps
     if taps == 9:
@@ -25,8 +25,9 @@ def run(M, N, K, taps, tm, tn, splits, reps, H=None):
     x = torch.randn(M, C, device=dev).half()
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     b = torch.randn(N, device=dev)
-    out = torch.empty(M, N, device=dev, dtype=torch.float16)
-    f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits)
+    out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=torch.float16)
+    f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits,
+                              geglu=geglu)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
@@ -44,6 +45,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("dims", type=int, nargs="+")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--geglu", action="store_true")
     a = ap.parse_args()
     M, N, K, taps = a.dims[:4]
     ops.AUTOTUNE = False
@@ -53,7 +55,9 @@ if __name__ == "__main__":
         cfgs = [(128, 64, 0), (128, 128, 0), (128, 160, 0), (256, 128, 0), (256, 160, 0), (256, 320, 0)]
     for tm, tn, sp in cfgs:
         try:
-            us, tf = run(M, N, K, taps, tm, tn, sp, a.reps)
+            if a.geglu and tn == 160:
+                continue
+            us, tf = run(M, N, K, taps, tm, tn, sp, a.reps, a.geglu)
             print(f"M={M} N={N} K={K} taps={taps} tile {tm}x{tn} splits={sp}: {us:8.1f} us  {tf:7.1f} TFLOP/s")
         except Exception as e:  # noqa: BLE001
             print(f"tile {tm}x{tn}: {e}")
