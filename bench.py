@@ -108,7 +108,7 @@ def kernel_roofline(model, batch, B, dump=None):
             if name == "gemm_conv":
                 desc = dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[0], K=a[1].shape[1], taps=k.get("taps", 1),
                             stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
-                            cat=k.get("x2") is not None)
+                            cat=k.get("x2") is not None, resid=k.get("resid") is not None)
             else:
                 desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
             rec[name].append((e0, e1, desc))
@@ -129,11 +129,18 @@ def kernel_roofline(model, batch, B, dump=None):
         unet.use_hip_graph = True
     fl = unet_flops(unet, x.shape[2], x.shape[3])
     n = 2 * B
+    # algorithmic HBM bytes of the GEMM family: every source element, weight and residual read once, output written once
+    gbytes = 0.0
+    for _, _, d in rec["gemm_conv"]:
+        src_rows = d["M"] * (4 if d["stride"] == 2 else 1) / (4 if d["up"] else 1)
+        n_out = d["N"] // 2 if d["geglu"] else d["N"]
+        gbytes += 2.0 * (src_rows * d["K"] / d["taps"] + d["N"] * d["K"] + d["M"] * n_out * (2 if d["resid"] else 1))
     out = {}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
         out[name] = {"launches": len(rec[name]), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(rec[name])),
                      "tflops": n * fl[key] / (ms * 1e-3) / 1e12}
+    out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
     if dump:
         rows = []
         for name in rec:
@@ -241,9 +248,15 @@ def main():
     if rank == 0 and not a.no_roofline:
         kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)
         g = kern["gemm_conv"]
+        traffic = None      # PMC-measured HBM bytes per GEMM launch (tools/pmc_step.py under rocprofv3 --pmc, committed)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> (implicit-GEMM conv3x3/1x1/linear)",
                            "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                           "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                           "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
                            "launches_per_unet_step": g["launches"], "avg_launch_us": g["avg_us"],
                            "algorithmic_gflop_per_unet_step": 2 * B * fl["gemm"] / 1e9}
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12

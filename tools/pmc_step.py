@@ -1,0 +1,74 @@
+"""HBM traffic of the GEMM family over ONE eager UNet step (configs[1], UNet batch 8), from rocprofv3 PMC counters.
+
+Two roles:
+
+  python tools/pmc_step.py run
+      the workload to put under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains):
+      builds the bench model, tunes tiles on a first eager step, then runs ONE more eager step (no hipGraph -- the
+      counter collection does not survive graph replay on this stack).
+
+  python tools/pmc_step.py reduce <fetch_dir> <write_dir> <out.json>
+      reads the two counter_collection CSVs, keeps the LAST step's gemm_conv* dispatches (one per ops.gemm_conv call,
+      their number is `launches_per_unet_step` of bench.py) and writes per-launch averages, applying the gfx950
+      correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests at 64 B -> x2; both counters are in KiB).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run():
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    model = bench.build_model(dev)
+    B = 4
+    c_concat, c_cross, uc_cross, x_T = bench.synthetic_batch(B, 64, 128, dev, 1234)
+    unet = model.model.diffusion_model
+    unet.use_hip_graph = False
+    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+    t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+    ctx = torch.cat([uc_cross, c_cross]).half()
+    with torch.no_grad():
+        for _ in range(2):
+            unet(x, t, ctx)
+            torch.cuda.synchronize()
+    print("pmc_step: done")
+
+
+def _rows(d):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, f"no counter_collection.csv under {d}"
+    out = []
+    for f in files:
+        out += list(csv.DictReader(open(f)))
+    out.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    return out
+
+
+def reduce_(fetch_dir, write_dir, out_path, launches=210):
+    res = {}
+    for key, d, counter, corr in (("fetch", fetch_dir, "FETCH_SIZE", 2.0), ("write", write_dir, "WRITE_SIZE", 1.0)):
+        rows = [r for r in _rows(d) if "gemm_conv" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        last = rows[-launches:]
+        kib = sum(float(r["Counter_Value"]) for r in last)
+        res[key + "_bytes_per_launch"] = corr * kib * 1024.0 / len(last)
+        res[key + "_launches"] = len(last)
+    res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+    res["note"] = ("GEMM family, last eager UNet step at batch 8 (configs[1]); FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE "
+                   "as reported (uncalibrated per the guide); separate --pmc passes")
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run()
+    else:
+        reduce_(sys.argv[2], sys.argv[3], sys.argv[4], *(int(v) for v in sys.argv[5:6]))
