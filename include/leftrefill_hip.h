@@ -87,6 +87,8 @@ typedef struct lr_gemm_args {
   int32_t B, H, W;          /* output grid; M = B*H*W */
   int32_t Hs, Ws;           /* source grid */
   int32_t taps, stride, up;
+  int32_t asym;             /* 0: 3x3 pad 1 on every side; 1: pad only bottom/right (F.pad (0,1,0,1) + padding 0, the VAE
+                               Downsample, ldm/modules/diffusionmodules/model.py:83-86) */
   const lr_half* wt; int32_t N;      /* weights [N][taps*(C1+C2)] */
   const float* bias;                 /* [N] or NULL */
   const lr_half* rowvec; int32_t ld_rowvec; /* [B][ld_rowvec] per-sample vector added to every row of sample b, or NULL */
@@ -111,6 +113,12 @@ int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
  * q [B][Nq][ldq], k/v [B][Nkv][ldk|ldv], o [B][Nq][ldo]; head h occupies columns [h*64, h*64+64). */
 int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                      int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+
+/* ---- row softmax of materialised logits (VAE AttnBlock: single head, d_head = C = 512) ---------------------------
+ * replaces: `w_ = w_ * (int(c)**(-0.5)); w_ = softmax(w_, dim=2)` (ldm/modules/diffusionmodules/model.py:186-187) between
+ *           the two bmm's (185, 192), which run through lr_gemm_conv_f16 (logits = q k^T with wt = k; out = p v with
+ *           wt = v^T).  p[m][:] = softmax(scale * s[m][:]), fp32 math, fp16 in/out, N % 8 == 0, N <= 16384; p may alias s. */
+int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, float scale, lr_stream_t st);
 
 /* ---- re-arranged multi-view token gather / scatter ----------------------------------------------------------------
  * replaces: multiview_attention.py:436-448 (gather to [target, ref_0..]) and 452-462 (scatter back; target -> every

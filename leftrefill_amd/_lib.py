@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -21,6 +21,7 @@ class GemmArgs(ctypes.Structure):
         ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("Hs", ctypes.c_int32), ("Ws", ctypes.c_int32),
         ("taps", ctypes.c_int32), ("stride", ctypes.c_int32), ("up", ctypes.c_int32),
+        ("asym", ctypes.c_int32),
         ("wt", c_void_p), ("N", ctypes.c_int32),
         ("bias", c_void_p),
         ("rowvec", c_void_p), ("ld_rowvec", ctypes.c_int32),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "lr_groupnorm_stats": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "lr_groupnorm_apply": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                            c_int, c_void_p, c_void_p],
+    "lr_softmax_rows_f16": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "lr_layernorm": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
     "lr_timestep_embedding": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "lr_linear_small_m": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

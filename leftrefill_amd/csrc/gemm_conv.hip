@@ -24,7 +24,7 @@
 
 struct GemmParams {
   const f16* p1; const f16* p2; const f16* wt; const float* bias; const f16* rowvec; const f16* resid; f16* out;
-  int C1, C2, H, W, Hs, Ws, taps, stride, up, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
+  int C1, C2, H, W, Hs, Ws, taps, stride, up, pad, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
   int ntiles_n, nblocks;
   int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
   int ntiles_m, m_fastest; // tile order inside an XCD's contiguous chunk (see tile_order())
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing the concat boundary
       seg_tap = tap; seg_src = srcsel;
       int dy = 0, dx = 0;
-      if (P.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
       const int cs = srcsel ? P.C2 : P.C1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform
       seg_tap = tap; seg_src = srcsel;
       int dy = 0, dx = 0;
-      if (P.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
       const int cs = srcsel ? P.C2 : P.C1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -716,9 +716,16 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Hs <= 0 || a->Ws <= 0 || a->N <= 0) return LR_E_ARG;
   P.H = a->H; P.W = a->W; P.Hs = a->Hs; P.Ws = a->Ws;
   P.taps = a->taps; P.stride = a->stride; P.up = a->up;
+  P.pad = a->asym ? 0 : 1;   // asym: F.pad(x, (0,1,0,1)) + conv padding 0 (VAE Downsample)
   P.wt = (const f16*)a->wt; P.N = a->N; P.bias = a->bias;
   P.M = a->B * a->H * a->W;
   P.K = a->taps * (P.C1 + P.C2);
+  // 32-bit byte offsets in the gather (bit 31 marks out-of-range): every operand must stay below 2 GiB
+  const int64_t lim = (int64_t)1 << 31;
+  const int64_t src_rows = (int64_t)a->B * a->Hs * a->Ws;
+  if (src_rows * P.C1 * 2 >= lim || src_rows * P.C2 * 2 >= lim || (int64_t)P.N * P.K * 2 >= lim ||
+      (int64_t)a->B * a->H * a->W >= lim / 2)
+    return LR_E_UNSUPPORTED;
   P.rowvec = (const f16*)a->rowvec; P.ld_rowvec = a->ld_rowvec;
   P.resid = (const f16*)a->resid; P.ld_resid = a->ld_resid;
   P.out = (f16*)a->out; P.ld_out = a->ld_out;

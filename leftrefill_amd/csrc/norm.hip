@@ -218,6 +218,59 @@ __global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restr
 // Number of pixel chunks actually used for a tensor of HW pixels per sample (both kernels derive it the same way).
 // Measured on MI355X inside a hipGraph (tools/bench_gn.py): ~256 stats blocks / ~512 apply blocks is the sweet spot --
 // more blocks lose to the per-block prologue, fewer starve the 256 CUs.  Env overrides are for experiments only.
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row softmax of materialised fp16 logits (single-head d = C attention of the VAE AttnBlock, where the logits go
+// through the GEMM kernel):  p[m][:] = softmax(scale * s[m][:]) in fp32, one 256-thread block per row, the row stays
+// in registers (NV 16-byte vectors per thread).  In place is allowed.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ void softmax_rows_kernel(const f16* __restrict__ s, f16* __restrict__ p, int N, float scale) {
+  __shared__ float red[8];
+  const size_t row = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const f16* src = s + row * (size_t)N;
+  f16* dst = p + row * (size_t)N;
+  float f[NV][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * 256 + t) * 8;
+    if (c < N) {
+      const uint4 u = *reinterpret_cast<const uint4*>(src + c);
+      lr_unpack8(u, f[v]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { f[v][i] *= scale; mx = fmaxf(mx, f[v][i]); }
+    }
+  }
+  mx = lr_wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * 256 + t) * 8;
+    if (c < N) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { f[v][i] = __expf(f[v][i] - mx); sum += f[v][i]; }
+    }
+  }
+  sum = lr_wave_sum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * 256 + t) * 8;
+    if (c < N) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[v][i] *= inv;
+      *reinterpret_cast<uint4*>(dst + c) = lr_pack8(f[v]);
+    }
+  }
+}
+
 static int gn_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -290,5 +343,19 @@ extern "C" int lr_layernorm(const lr_half* x, const float* gamma, const float* b
     case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
     default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
   }
+  return lr_launch_status();
+}
+
+extern "C" int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, float scale, lr_stream_t st) {
+  if (!s || !p || M <= 0 || N <= 0) return LR_E_ARG;
+  if (N % 8) return LR_E_ALIGN;
+  if (N > 8 * 2048) return LR_E_UNSUPPORTED;
+  const int nv = (N + 2047) / 2048;
+  dim3 grid(M), block(256);
+  hipStream_t hs = (hipStream_t)st;
+  if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else if (nv <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
   return lr_launch_status();
 }

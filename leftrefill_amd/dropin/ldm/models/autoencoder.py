@@ -1,6 +1,9 @@
 """`ldm.models.autoencoder.AutoencoderKL` (reference ldm/models/autoencoder.py:13-91), inference part only:
 encode -> DiagonalGaussianDistribution(quant_conv(encoder(x))), decode -> decoder(post_quant_conv(z)).
-Host-side PyTorch-ROCm module (VAE stays off the HIP hot path by the north star); state-dict keys as the reference."""
+State-dict keys as the reference.  CUDA inputs run on the HIP kernels (leftrefill_amd.vae_engine: the conv / GroupNorm /
+GEMM kernels of the UNet step; weights are packed on first use and re-packed when a parameter changes); the nn.Module
+graph itself is the PyTorch host-side definition (used for CPU tensors, e.g. the CPU golden pin) -- set `use_hip = False`
+to force it on a GPU."""
 import torch
 import torch.nn as nn
 
@@ -31,10 +34,35 @@ class AutoencoderKL(nn.Module):
             sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
             self.load_state_dict(sd, strict=False)
 
+    use_hip = True
+
+    def _sig(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def prepare(self, force=False):
+        """Pack the weights for the HIP kernels; redone automatically when a parameter was (re)loaded or moved."""
+        from leftrefill_amd import vae_engine
+        sig = self._sig()
+        packed = getattr(self, "_lr_packed", None)
+        if packed is None or force or packed[0] != sig:
+            with torch.no_grad():
+                packed = (sig, vae_engine.PackedEncoder(self.encoder, self.quant_conv),
+                          vae_engine.PackedDecoder(self.decoder, self.post_quant_conv))
+            self._lr_packed = packed
+        return packed
+
     def encode(self, x):
+        if x.is_cuda and self.use_hip:
+            from leftrefill_amd import vae_engine
+            with torch.no_grad():
+                return DiagonalGaussianDistribution(vae_engine.encode_moments(x.float(), self.prepare()[1]))
         return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
 
     def decode(self, z):
+        if z.is_cuda and self.use_hip:
+            from leftrefill_amd import vae_engine
+            with torch.no_grad():
+                return vae_engine.decode(z.float(), self.prepare()[2])
         return self.decoder(self.post_quant_conv(z))
 
     def forward(self, input, sample_posterior=True):

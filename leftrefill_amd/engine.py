@@ -140,8 +140,8 @@ def linear(x, pl: PackedLinear, resid=None, M=None):
     return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid)
 
 
-def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0):
-    """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample) or 1x1 conv over an Act."""
+def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False):
+    """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample; asym: pad bottom/right only) or 1x1 conv over an Act."""
     if pc.taps == 9:
         if up:
             H, W = act.H * 2, act.W * 2
@@ -152,7 +152,7 @@ def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0):
     else:
         H, W = act.H, act.W
     y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
-                      x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid)
+                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid)
     return Act(y, act.N, H, W)
 
 

@@ -111,7 +111,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
     return out
 
 
-def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=None, bias=None, rowvec=None,
+def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
               resid=None, geglu=False, out=None, tile_n=0, tile_m=0, splits=0):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
     lib = _lib.load()
@@ -134,7 +134,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=N
     a = GemmArgs()
     a.p1, a.C1, a.p2, a.C2 = _p(x1), C1, _p(x2), C2
     a.B, a.H, a.W, a.Hs, a.Ws = B, H, W, Hs, Ws
-    a.taps, a.stride, a.up = taps, stride, up
+    a.taps, a.stride, a.up, a.asym = taps, stride, up, int(bool(asym))
     a.wt, a.N = _p(wt), Nw
     a.bias = _p(bias)
     if bias is not None:
@@ -151,7 +151,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, x2=N
     a.workspace, a.workspace_bytes = 0, 0
     st = _stream()
     if tile_m == 0 and tile_n == 0 and AUTOTUNE:
-        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index)
+        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index, bool(asym))
         best = _tile_cache.get(key)
         if best is None and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu)
@@ -208,6 +208,17 @@ def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None):
         out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
     _lib.check(lib.lr_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                     B, heads, Nq, Nkv, float(scale), _stream()), "attention")
+    return out
+
+
+def softmax_rows(s, scale, out=None):
+    """p = softmax(scale * s, dim=-1) for materialised fp16 logits s [M, N] (VAE AttnBlock); in place when out is s."""
+    lib = _lib.load()
+    _chk16(s, "s")
+    M, N = s.shape
+    if out is None:
+        out = torch.empty_like(s)
+    _lib.check(lib.lr_softmax_rows_f16(_p(s), _p(out), M, N, float(scale), _stream()), "softmax_rows")
     return out
 
 

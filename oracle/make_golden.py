@@ -241,6 +241,35 @@ def gen_vae(ns):
                             sample=post.sample().numpy(), keys=np.array(list(sd.keys())))
 
 
+VAE_HIP_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
+                        num_res_blocks=2, attn_resolutions=[], dropout=0.0)   # widths 64/128/256/256: multiples of 64
+
+
+def gen_vae_hip(ns):
+    """KL-VAE at channel widths the HIP kernels take (multiples of 64) + the two VAE-only operators at full width:
+    AttnBlock(512) (model.py:153-204) and the asymmetric-pad Downsample(128) (model.py:69-88)."""
+    from ldm.models.autoencoder import AutoencoderKL
+    from ldm.modules.diffusionmodules import model as M
+    ref = AutoencoderKL(dict(VAE_HIP_DDCONFIG), {"target": "torch.nn.Identity"}, 4).eval()
+    sd = {k: torch.from_numpy(weights.fill_like("vaeh." + k, v.shape)) for k, v in ref.state_dict().items()}
+    ref.load_state_dict(sd)
+    x = G.T("vaeh.x", (2, 3, 64, 128))
+    out = {}
+    with torch.no_grad():
+        moments = ref.quant_conv(ref.encoder(x))
+        z = ref.encode(x).mode()
+        out.update(moments=moments.numpy(), z=z.numpy(), dec=ref.decode(z).numpy())
+        attn = M.AttnBlock(512).eval()
+        attn.load_state_dict({k: torch.from_numpy(weights.fill_like("vaeh.attn." + k, v.shape))
+                              for k, v in attn.state_dict().items()})
+        out["attn_y"] = attn(G.T("vaeh.attn.x", (2, 512, 8, 16))).numpy()
+        down = M.Downsample(128, True).eval()
+        down.load_state_dict({k: torch.from_numpy(weights.fill_like("vaeh.down." + k, v.shape))
+                              for k, v in down.state_dict().items()})
+        out["down_y"] = down(G.T("vaeh.down.x", (2, 128, 16, 32))).numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_hip.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -249,12 +278,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ns = ref_import.import_reference()
-    todo = [a.only] if a.only else ["ops", "sampler", "mv", "vae", "unet"]
+    todo = [a.only] if a.only else ["ops", "sampler", "mv", "vae", "vae_hip", "unet"]
     for what in todo:
         print(f"[{what}]")
         t0 = time.time()
         {"ops": gen_ops, "unet": lambda n: gen_unet(n, a.skip_full), "mv": gen_mv, "sampler": gen_sampler,
-         "vae": gen_vae}[what](ns)
+         "vae": gen_vae, "vae_hip": gen_vae_hip}[what](ns)
         print(f"[{what}] done in {time.time() - t0:.1f}s")
 
 

@@ -1,0 +1,137 @@
+"""GPU parity of the KL-VAE on the HIP kernels against goldens generated from the real
+reference (oracle/make_golden.py gen_vae_hip: AutoencoderKL at widths 64/128/256/256, AttnBlock(512), Downsample(128)).
+
+Tolerances: single operators at the north-star rtol 2e-3 / atol 1e-3 (+ the fp16 rounding of a sum of two O(1) terms
+for the residual AttnBlock); the 25-conv encoder / 30-conv decoder chains by relative L2 (fp16 activations, like the
+UNet criterion in test_gpu_unet.py) with an element-wise cap.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_spec as G, weights  # noqa: E402
+from oracle.make_golden import VAE_HIP_DDCONFIG  # noqa: E402  (config dict only; nothing from /root/reference is read)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _fill(mod, prefix):
+    mod.load_state_dict({k: torch.from_numpy(weights.fill_like(prefix + k, v.shape)) for k, v in mod.state_dict().items()})
+    return mod.eval()
+
+
+def _vae():
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.autoencoder import AutoencoderKL
+    return _fill(AutoencoderKL(dict(VAE_HIP_DDCONFIG), {"target": "torch.nn.Identity"}, 4), "vaeh.").to(dev())
+
+
+def _rel(out, ref):
+    out, ref = out.float().cpu(), torch.as_tensor(ref).float()
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs()
+    return (err.norm() / ref.norm()).item(), err.max().item()
+
+
+def test_vae_downsample_asym_pad(golden):
+    """F.pad(x, (0,1,0,1)) + 3x3 stride-2 conv, padding 0 (model.py:83-86) through lr_gemm_conv_f16 with asym = 1."""
+    from leftrefill_amd import engine, ops
+    g = golden("vae_hip")
+    conv = _fill(torch.nn.Conv2d(128, 128, 3, stride=2, padding=0), "vaeh.down.conv.").to(dev())
+    x = G.T("vaeh.down.x", (2, 128, 16, 32)).to(dev())
+    a = engine.act_from_nchw(x)
+    y = engine.conv(a, engine.PackedConv(conv), asym=True)
+    assert (y.H, y.W) == (8, 16)
+    out = engine.act_to_nchw(y, 128, torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), g["down_y"], rtol=2e-3, atol=2e-3)
+
+
+def test_vae_attnblock_d512(golden):
+    """Single-head d=512 AttnBlock: GEMM logits -> lr_softmax_rows_f16 -> GEMM with v^T, + proj_out + residual."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.model import AttnBlock
+    from leftrefill_amd import engine, vae_engine
+    g = golden("vae_hip")
+    blk = _fill(AttnBlock(512), "vaeh.attn.").to(dev())
+    x = G.T("vaeh.attn.x", (2, 512, 8, 16)).to(dev())
+    y = vae_engine.vae_attn(engine.act_from_nchw(x), vae_engine.PackedVaeAttn(blk))
+    out = engine.act_to_nchw(y, 512, torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), g["attn_y"], rtol=2e-3, atol=3e-3)
+
+
+def test_softmax_rows_kernel():
+    from leftrefill_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for M, N in ((5, 8), (33, 520), (16, 2048), (7, 8192), (3, 16384)):
+        s = (4.0 * torch.randn(M, N, generator=gen)).half().to(dev())
+        ref = torch.softmax(s.float() * 0.37, dim=-1)
+        p = ops.softmax_rows(s, 0.37)
+        assert (p.float() - ref).abs().max().item() <= 1e-3 * ref.max().item() + 1e-6
+        assert abs(p.float().sum(-1) - 1).max().item() < 2e-3
+        q = ops.softmax_rows(s.clone(), 0.37)
+        assert torch.equal(p, q)
+
+
+def test_vae_encode_decode_vs_reference_golden(golden):
+    g = golden("vae_hip")
+    m = _vae()
+    x = G.T("vaeh.x", (2, 3, 64, 128)).to(dev())
+    post = m.encode(x)
+    moments = torch.cat([post.mean, post.logvar], dim=1)
+    rel, mx = _rel(moments, g["moments"])
+    print(f"[vae encode] rel_l2 {rel:.3e} max_abs {mx:.3e}")
+    assert rel < 4e-3 and mx < 2e-2
+    z = torch.from_numpy(g["z"]).to(dev())           # decode from the reference's own latent
+    dec = m.decode(z)
+    assert dec.shape == (2, 3, 64, 128) and dec.dtype == torch.float32
+    rel, mx = _rel(dec, g["dec"])
+    print(f"[vae decode] rel_l2 {rel:.3e} max_abs {mx:.3e}")
+    assert rel < 4e-3 and mx < 2.5e-2
+    # the HIP path is the one that ran, and it is deterministic
+    assert torch.equal(dec, m.decode(z))
+    # PyTorch definition of the same module on the same device (pinned to the reference on CPU) as a second checker
+    m.use_hip = False
+    with torch.no_grad():
+        rel2, _ = _rel(dec, m.decode(z).cpu())
+    assert rel2 < 4e-3
+
+
+def test_vae_repacks_after_weight_change():
+    m = _vae()
+    z = G.T("vaeh.z_in", (1, 4, 8, 16)).to(dev())
+    a = m.decode(z)
+    with torch.no_grad():
+        m.decoder.conv_out.bias.add_(1.0)
+    b = m.decode(z)
+    assert (b - a - 1.0).abs().max().item() < 2e-2
+
+
+def test_vae_decode_full_canvas_size_runs():
+    """512x1024 decode at the shipped width (ch 128, 4 levels) -- size-independent properties only: finite, deterministic,
+    batch entries independent (image 0 of a batch of 2 == the same latent decoded alone, up to the summation order of
+    the GroupNorm partials / split-K, which are functions of the batch size)."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.autoencoder import AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    m = AutoencoderKL(dd, {"target": "torch.nn.Identity"}, 4).to(dev()).eval()
+    gen = torch.Generator(device=dev()).manual_seed(0)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, device=dev(), generator=gen) * (1.0 / p[0].numel()) ** 0.5)
+    z = torch.randn(2, 4, 64, 128, device=dev(), generator=gen)
+    y2 = m.decode(z)
+    y1 = m.decode(z[:1])
+    assert y2.shape == (2, 3, 512, 1024) and torch.isfinite(y2).all()
+    assert torch.equal(y2, m.decode(z))
+    assert ((y2[:1] - y1).norm() / y1.norm()).item() < 1e-3
+    post = m.encode(y2.clamp(-1, 1))
+    assert post.mean.shape == (2, 4, 64, 128) and torch.isfinite(post.mean).all()

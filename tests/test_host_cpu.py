@@ -250,6 +250,34 @@ def test_dropin_vae_matches_reference_golden(golden):
         np.testing.assert_allclose(post.sample().numpy(), g["sample"], atol=1e-5)   # RNG re-seeded to 42 inside
 
 
+def test_dropin_vae_matches_reference_golden_hip_widths(golden):
+    """Same pin at the channel widths the HIP path takes (64/128/256/256, incl. the mid AttnBlock): the PyTorch definition
+    that tests/test_gpu_vae.py uses as its second checker."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.models.autoencoder import AutoencoderKL
+    from ldm.modules.diffusionmodules.model import AttnBlock, Downsample
+    from oracle import golden_spec as G, weights
+    from oracle.make_golden import VAE_HIP_DDCONFIG
+    g = golden("vae_hip")
+
+    def fill(mod, prefix):
+        mod.load_state_dict({k: torch.from_numpy(weights.fill_like(prefix + k, v.shape))
+                             for k, v in mod.state_dict().items()})
+        return mod.eval()
+
+    m = fill(AutoencoderKL(dict(VAE_HIP_DDCONFIG), {"target": "torch.nn.Identity"}, 4), "vaeh.")
+    x = G.T("vaeh.x", (2, 3, 64, 128))
+    with torch.no_grad():
+        post = m.encode(x)
+        np.testing.assert_allclose(torch.cat([post.mean, post.logvar], 1).numpy(), g["moments"], atol=2e-5)
+        np.testing.assert_allclose(m.decode(torch.from_numpy(g["z"])).numpy(), g["dec"], atol=5e-5)
+        np.testing.assert_allclose(fill(AttnBlock(512), "vaeh.attn.")(G.T("vaeh.attn.x", (2, 512, 8, 16))).numpy(),
+                                   g["attn_y"], atol=2e-5)
+        np.testing.assert_allclose(fill(Downsample(128, True), "vaeh.down.")(G.T("vaeh.down.x", (2, 128, 16, 32))).numpy(),
+                                   g["down_y"], atol=2e-5)
+
+
 def test_full_vae_key_count():
     import leftrefill_amd.dropin as dropin
     dropin.install()
