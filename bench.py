@@ -157,6 +157,33 @@ def kernel_roofline(model, batch, B, dump=None):
     return out, fl
 
 
+def vae_timing(B, device):
+    """Next row, reported beside the metric, never inside `value`: KL-VAE decode of the B sampled latents
+    and encode of B 512x1024 images on the same HIP kernels (shipped width, random-init weights)."""
+    from ldm.models.autoencoder import AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)     # model_config.yaml:44-58
+    vae = AutoencoderKL(dd, {"target": "torch.nn.Identity"}, 4).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for p in vae.parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, device=device, generator=g) * (1.0 / p[0].numel()) ** 0.5)
+    z = torch.randn(B, 4, 64, 128, device=device, generator=g)
+    x = torch.randn(B, 3, 512, 1024, device=device, generator=g).clamp(-1, 1)
+    out = {}
+    for name, fn, tflop in (("decode", lambda: vae.decode(z), 5.10), ("encode", lambda: vae.encode(x), 2.30)):
+        fn()                                  # tile autotune + weight packing
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out[name] = {"ms": ms, "batch": B, "tflops": B * tflop / ms}
+    return out
+
+
 def cpu_baseline():
     """Oracle (fp32 torch CPU restatement) on a bounded sample: ONE CFG UNet step (N=2) at latent 64x128."""
     from oracle import unet_ref
@@ -263,6 +290,8 @@ def main():
         res["kernels"] = {"attention_kernel": kern["attention"],
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
+    if rank == 0 and not a.no_roofline:
+        res["vae_512x1024"] = vae_timing(B, device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -95,7 +95,7 @@ typedef struct lr_gemm_args {
   const lr_half* resid; int32_t ld_resid;   /* [M][ld_resid] or NULL */
   lr_half* out; int32_t ld_out;             /* [M][ld_out] */
   int32_t geglu;
-  int32_t tile_n;           /* 0 = auto; 64 | 128 | 160 (tile_m 128) or 128 | 160 | 320 (tile_m 256) */
+  int32_t tile_n;           /* 0 = auto; 64 | 128 | 160 (tile_m 128) or 128 | 160 | 256 | 320 (tile_m 256) */
   int32_t tile_m;           /* 0 = auto; 128 (4 waves, 2-stage) | 256 (8 waves, 3-stage counted-vmcnt pipeline) */
   /* split-K (small-M shapes that cannot fill 256 CUs): fp32 partial tiles go to `workspace`
    * [splits][M][N] and a second launch reduces them in a fixed order and applies the epilogue.

@@ -293,6 +293,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   <128, 4, 3>, <160, 4, 3>: wave tile 64 x BN/2, 3-stage ring (loads two K-steps ahead)
 //   <320, 2, 2>            : wave tile 128 x 80 (40 accumulator tiles): 28 % fewer LDS bytes per MFMA and 31 % less
 //                            L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
+//   <256, 2, 2>            : wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
 //   <320, 4, 2>            : wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
 template <int BN, int WMW, int NSTAGE>
 __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
@@ -759,6 +760,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   else if (tm == 128 && tn == 160 && !P.geglu) rc = launch_gemm<160>(P, st);
   else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3>(P, st);
   else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160, 4, 3>(P, st);
+  else if (tm == 256 && tn == 256) rc = launch_gemm256<256, 2, 2>(P, st);                 // wave tile 128 x 64
   else if (tm == 256 && tn == 320 && !P.geglu) rc = launch_gemm256<320, 2, 2>(P, st);
   else if (tm == 256 && tn == 320 && P.geglu) rc = launch_gemm256<320, 4, 2>(P, st);   // wave tile 64 x 160: even TN
   else return LR_E_UNSUPPORTED;

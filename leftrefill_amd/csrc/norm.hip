@@ -275,8 +275,12 @@ static int gn_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-static int gn_nchunks(int N, int HW) {
-  static const int target_blocks = gn_env("LR_GN_STAT_BLOCKS", 256);
+static int gn_nchunks(int N, int HW, int C) {
+  static const int base_blocks = gn_env("LR_GN_STAT_BLOCKS", 256);
+  // ~1 block per CU for the UNet's tensors (<= 126 MB); tensors of the VAE's size (0.5 GB) get one block per 512 KB so
+  // enough loads are in flight to stream at HBM rate
+  const long long want = ((long long)N * HW * C * 2) >> 19;
+  const int target_blocks = want > base_blocks ? (int)want : base_blocks;
   int c = (target_blocks + N - 1) / N;
   if (c > LR_GN_CHUNKS) c = LR_GN_CHUNKS;
   if (c > HW / 8) c = HW / 8;
@@ -295,7 +299,7 @@ extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, 
   if (R < 1) R = 1;
   const int threads = nOct * R;
   if (threads > 1024) return LR_E_UNSUPPORTED;
-  const int nchunks = gn_nchunks(N, HW);
+  const int nchunks = gn_nchunks(N, HW, C);
   dim3 grid(nchunks, N);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)R * C * 2 * sizeof(float), (hipStream_t)s,
                      (const f16*)x1, C1, (const f16*)x2, C2, HW, partials, nOct, R, nchunks);
@@ -318,7 +322,9 @@ extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, 
   int R = 256 / nOct;
   if (R < 1) R = 1;
   const int threads = nOct * R;
-  static const int apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 512);
+  static const int base_apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 512);
+  const long long want_blocks = ((long long)N * HW * C * 2) >> 18;     // one block per 256 KB for very large tensors
+  const long long apply_blocks = want_blocks > base_apply_blocks ? want_blocks : base_apply_blocks;
   ppb = (int)(((long long)N * HW + apply_blocks - 1) / apply_blocks);
   if (ppb < 16) ppb = 16;
   if (ppb > HW) ppb = HW;
@@ -326,7 +332,7 @@ extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, 
   dim3 grid((HW + ppb - 1) / ppb, N);
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, (hipStream_t)s, (const f16*)x1, C1, (const f16*)x2, C2,
-                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, gn_nchunks(N, HW));
+                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, gn_nchunks(N, HW, C));
   return lr_launch_status();
 }
 

@@ -17,7 +17,7 @@ GN_CHUNKS = 256
 # tile configuration is timed with HIP events and the fastest is cached.  All tile configurations accumulate K in the
 # same order, so the choice never changes results bit-wise (split-K stays a deterministic function of the shape).
 AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "1") != "0"
-TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 320))
+TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320))
 _tile_cache = {}
 
 

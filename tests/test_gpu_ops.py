@@ -123,7 +123,7 @@ def test_timestep_embedding_and_time_mlp(golden):
 
 
 def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True, rowvec=False, resid=False,
-               tile_n=0, wscale=1.0, tile_m=0, splits=0):
+               tile_n=0, wscale=1.0, tile_m=0, splits=0, asym=False):
     from leftrefill_amd import ops, packing
     d = dev()
     Ct = Cin + C2
@@ -139,7 +139,10 @@ def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True
     xin = x
     if up:
         xin = F.interpolate(x, scale_factor=2, mode="nearest")
-    ref = F.conv2d(xin, w, b, stride=stride, padding=1 if taps == 9 else 0)
+    if asym:     # VAE Downsample: F.pad (0,1,0,1) + padding 0 (model.py:83-86)
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, b, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xin, w, b, stride=stride, padding=1 if taps == 9 else 0)
     rv = rs = None
     if rowvec:
         rv = h16(G.T(name + ".rv", (N, Cout)))
@@ -151,7 +154,7 @@ def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True
     bp = packing.pack_bias(b).to(d) if bias else None
     x1 = to_tok(x[:, :Cin])
     x2 = to_tok(x[:, Cin:]) if C2 else None
-    y = ops.gemm_conv(x1, wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, x2=x2, bias=bp,
+    y = ops.gemm_conv(x1, wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym, x2=x2, bias=bp,
                       rowvec=rv.half().to(d) if rowvec else None, resid=to_tok(rs) if resid else None, tile_n=tile_n,
                       tile_m=tile_m, splits=splits)
     y = y[:, :Cout]
@@ -170,21 +173,24 @@ def test_conv3x3_variants():
     _conv_case("c3_s1_big", 2, 640, 1280, 8, 16, rowvec=True)
     _conv_case("c3_cat_res", 2, 320, 640, 8, 12, C2=640, rowvec=True, resid=True)
     _conv_case("c3_s2", 2, 320, 320, 6, 10, stride=2)
+    _conv_case("c3_s2_asym", 2, 128, 128, 6, 10, stride=2, asym=True)
+    _conv_case("c3_s2_asym64", 1, 64, 64, 5, 7, stride=2, asym=True, tile_n=64)
     _conv_case("c3_up", 1, 640, 640, 8, 12, up=1)
     _conv_case("c1_cat", 2, 640, 320, 8, 8, taps=1, C2=320)
     _conv_case("c3_in", 2, 64, 320, 16, 32)   # padded input conv (9 -> 64 channels handled by caller)
     _conv_case("c3_m_tail", 1, 128, 64, 5, 9)  # M = 45 < tile
 
 
-@pytest.mark.parametrize("tile_n", [128, 160, 320])
+@pytest.mark.parametrize("tile_n", [128, 160, 256, 320])
 def test_conv_tile256(tile_n):
     """The 256-row, 8-wave, 3-stage counted-vmcnt kernel: every gather mode, tails in M and N, split-K."""
     k = dict(tile_m=256, tile_n=tile_n)
-    co = 384 if tile_n == 128 else 320
+    co = 384 if tile_n in (128, 256) else 320
     _conv_case(f"t256_{tile_n}_c3", 2, 320, co, 16, 24, **k)                       # M = 768
     _conv_case(f"t256_{tile_n}_tail", 1, 128, co, 9, 13, rowvec=True, resid=True, **k)   # M = 117 (< one tile)
     _conv_case(f"t256_{tile_n}_cat", 2, 320, 640, 12, 20, C2=640, rowvec=True, resid=True, **k)
     _conv_case(f"t256_{tile_n}_s2", 2, 320, co, 10, 14, stride=2, **k)
+    _conv_case(f"t256_{tile_n}_s2a", 2, 128, co, 10, 14, stride=2, asym=True, **k)
     _conv_case(f"t256_{tile_n}_up", 1, 640, 640, 16, 24, up=1, **k)
     _conv_case(f"t256_{tile_n}_lin", 1, 320, 960, 1, 700, taps=1, **k)              # short K (5 steps), M tail
     _conv_case(f"t256_{tile_n}_lin1", 1, 64, 320, 1, 300, taps=1, **k)             # single K-step
@@ -211,7 +217,7 @@ def test_geglu_tile256():
     u, gate = F.linear(x, w, b).chunk(2, dim=-1)
     ref = u * F.gelu(gate)
     wp, bp = packing.pack_geglu(w, b)
-    for tn in (128, 320):
+    for tn in (128, 256, 320):
         y = ops.gemm_conv(x.half().to(d), wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=256,
                           tile_n=tn)
         report(f"geglu tile256x{tn}", y, ref)

@@ -40,6 +40,9 @@ with torch.no_grad():
     d_hip = timeit(lambda: m.decode(z))
     e_hip = timeit(lambda: m.encode(x))
     y_hip = m.decode(z)
+    if len(sys.argv) > 2 and sys.argv[2] == "hip":
+        print(f"B={B} decode {d_hip:.1f} ms  encode {e_hip:.1f} ms")
+        sys.exit(0)
     m.use_hip = False
     d_t32 = timeit(lambda: m.decode(z), 1)
     e_t32 = timeit(lambda: m.encode(x), 1)
@@ -52,3 +55,6 @@ rel = ((y_hip - y_ref).norm() / y_ref.norm()).item()
 print(f"B={B} decode: hip {d_hip:.1f} ms ({B * 5.10 / d_hip:.0f} TFLOP/s)  torch fp32 {d_t32:.1f} ms  torch autocast {d_t16:.1f} ms")
 print(f"B={B} encode: hip {e_hip:.1f} ms ({B * 2.30 / e_hip:.0f} TFLOP/s)  torch fp32 {e_t32:.1f} ms  torch autocast {e_t16:.1f} ms")
 print(f"decode rel-L2 hip vs torch fp32 at 512x1024: {rel:.3e}")
+from leftrefill_amd import ops  # noqa: E402
+for k, v in sorted(ops.tile_cache().items(), key=lambda kv: -kv[0][0]):
+    print(k[:6], v)
