@@ -157,6 +157,34 @@ def kernel_roofline(model, batch, B, dump=None):
     return out, fl
 
 
+def unet_step_events(model, batch, B, n=25, warm=5):
+    """SURVEY 8d reporting: HIP-event time of ONE graph-replayed UNet forward at batch 2B (median of n after warm),
+    and of the fused CFG + DDIM update, separately."""
+    from leftrefill_amd import ops
+    unet = model.model.diffusion_model
+    c_concat, c_cross, uc_cross, x_T = batch
+    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+    t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
+    ctx = torch.cat([uc_cross, c_cross]).half()
+    times, upd = [], []
+    with torch.no_grad():
+        for i in range(warm + n):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            eps = unet(x, t, ctx)
+            e1.record()
+            ops.ddim_cfg_step(x_T, eps, x_T, CFG, 0.5, 0.6, 0.1, 0.7)
+            e2.record()
+            e2.synchronize()
+            if i >= warm:
+                times.append(e0.elapsed_time(e1))
+                upd.append(1e3 * e1.elapsed_time(e2))
+    times.sort()
+    upd.sort()
+    return {"unet_forward_ms_median": times[len(times) // 2], "unet_forward_ms_min": times[0],
+            "ddim_update_us_median": upd[len(upd) // 2], "n": n, "warmup": warm, "unet_batch": 2 * B}
+
+
 def vae_timing(B, device):
     """Next row, reported beside the metric, never inside `value`: KL-VAE decode of the B sampled latents
     and encode of B 512x1024 images on the same HIP kernels (shipped width, random-init weights)."""
@@ -230,8 +258,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LR_BENCH_SHARE_GPU=1 is a test hook only: all ranks on cuda:0 over gloo, to exercise this code path on a 1-GPU box
+        share = os.environ.get("LR_BENCH_SHARE_GPU") == "1"
+        if share:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -291,6 +326,7 @@ def main():
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline:
+        res["unet_step_events"] = unet_step_events(model, batch, B)
         res["vae_512x1024"] = vae_timing(B, device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
