@@ -45,6 +45,12 @@ class AutoencoderKL(nn.Module):
         sig = self._sig()
         packed = getattr(self, "_lr_packed", None)
         if packed is None or force or packed[0] != sig:
+            bad = [n for n, m in self.named_modules() if isinstance(m, nn.Conv2d) and n not in
+                   ("encoder.conv_in", "decoder.conv_out", "encoder.conv_out", "decoder.conv_in", "quant_conv",
+                    "post_quant_conv") and (m.in_channels % 64 or m.out_channels % 64)]
+            if bad:
+                raise RuntimeError(f"VAE on the HIP kernels needs channel widths that are multiples of 64 ({bad[0]}); "
+                                   "set `use_hip = False` on this AutoencoderKL to run the PyTorch definition")
             with torch.no_grad():
                 packed = (sig, vae_engine.PackedEncoder(self.encoder, self.quant_conv),
                           vae_engine.PackedDecoder(self.decoder, self.post_quant_conv))

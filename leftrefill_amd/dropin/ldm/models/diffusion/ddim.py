@@ -53,12 +53,15 @@ class DDIMSampler(object):
                 c0 = c0[0]
             if c0.shape[0] != batch_size:
                 print(f"Warning: Got {c0.shape[0]} conditionings but batch-size is {batch_size}")
-        if isinstance(conditioning, list):
-            raise NotImplementedError("ddim_multi_sampling (list conditioning, NVS consistency sampler) is a 'next' row")
         if quantize_x0 or score_corrector is not None or dynamic_threshold is not None or noise_dropout > 0.:
             raise NotImplementedError("quantize_x0 / score_corrector / dynamic_threshold / noise_dropout are unused")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C, H, W = shape
+        if isinstance(conditioning, list):       # NVS consistency sampler (ddim.py:103-120)
+            return self.ddim_multi_sampling(conditioning, (batch_size, C, H, W), callback=callback, temperature=temperature,
+                                            x_T=x_T, unconditional_guidance_scale=unconditional_guidance_scale,
+                                            unconditional_conditioning=unconditional_conditioning,
+                                            ucg_schedule=ucg_schedule)
         return self.ddim_sampling(conditioning, (batch_size, C, H, W), callback=callback, img_callback=img_callback,
                                   mask=mask, x0=x0, temperature=temperature, x_T=x_T, log_every_t=log_every_t,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
@@ -99,6 +102,50 @@ class DDIMSampler(object):
                 intermediates['pred_x0'].append(pred_x0)
         self._cfg_cache = None
         return img, intermediates
+
+    @torch.no_grad()
+    def ddim_multi_sampling(self, cond, shape, x_T=None, callback=None, timesteps=None, temperature=1.,
+                            unconditional_guidance_scale=1., unconditional_conditioning=None, ucg_schedule=None,
+                            **kwargs):
+        """K conditionings denoised side by side; after every step the right half of ONE of them -- chosen with python's
+        `random.shuffle`, consuming the RNG exactly like the reference -- replaces the right half of all K states
+        (reference ddim.py:147-222).  Returns (img[0], {})."""
+        import random
+        device = self.model.betas.device
+        b = shape[0]
+        K = len(cond)
+        if x_T is None:
+            first = torch.randn(shape, device=device)       # the reference aliases ONE randn tensor K times (ddim.py:160)
+            img = [first] * K
+        else:
+            img = [x.to(device=device, dtype=torch.float32) for x in x_T]
+        ucs = unconditional_conditioning if unconditional_conditioning is not None else [None] * K
+        steps = self.ddim_timesteps
+        if timesteps is not None:
+            end = int(min(timesteps / steps.shape[0], 1) * steps.shape[0]) - 1
+            steps = steps[:end]
+        total_steps = steps.shape[0]
+        for i, step in enumerate(np.flip(steps)):
+            index = total_steps - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            if ucg_schedule is not None:
+                unconditional_guidance_scale = ucg_schedule[i]
+            new_img = []
+            for img_, cond_, uc_ in zip(img, cond, ucs):
+                x_prev, _ = self.p_sample_ddim(img_, cond_, ts, index=index, temperature=temperature,
+                                               unconditional_guidance_scale=unconditional_guidance_scale,
+                                               unconditional_conditioning=uc_)
+                new_img.append(x_prev)
+            order = list(range(K))
+            random.shuffle(order)                 # same RNG consumption and same pick as shuffling the K tensors
+            half = new_img[0].shape[-1] // 2
+            right = new_img[order[0]][..., half:].clone()
+            for x_ in new_img:
+                x_[..., half:] = right
+            img = new_img
+            if callback:
+                callback(i)
+        return img[0], {}
 
     # the conditioning is constant over the loop: build the [uncond; cond] batch once instead of 50 torch.cat calls
     def _prepare_cfg_inputs(self, c, uc, scale):

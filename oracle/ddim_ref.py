@@ -102,3 +102,47 @@ def ddim_sample(apply_unet, S, x_T, c_concat, c_cross, uc_cross, scale, eta=0.0,
             inter["x_inter"].append(img)
             inter["pred_x0"].append(pred_x0)
     return img, inter
+
+
+def multi_pick(n, rng=None):
+    """Which condition's right half is shared after a step (ddim.py:208-212): `random.shuffle(list); list[0]`.
+    Shuffling a list of indices consumes the python RNG exactly like shuffling the n tensors and yields the same choice."""
+    import random
+    order = list(range(n))
+    (rng or random).shuffle(order)
+    return order[0]
+
+
+@torch.no_grad()
+def ddim_multi_sample(apply_unet, S, x_Ts, c_concats, c_crosses, uc_crosses, scale, eta=0.0, noises=None, rng=None):
+    """DDIMSampler.ddim_multi_sampling (ddim.py:147-222): K conditionings advance side by side; after every step the
+    right half (last dim) of ONE randomly chosen condition overwrites the right half of all K states.  Returns img[0].
+
+    noises: optional list of S*K tensors in call order (step-major, condition-minor), cf. ddim.py:378.
+    """
+    K = len(c_concats)
+    tabs = ddim_tables(S, eta)
+    ts = tabs["timesteps"]
+    imgs = [x.clone().float() for x in x_Ts]
+    B = imgs[0].shape[0]
+    total = ts.shape[0]
+    n = 0
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((B,), int(step), dtype=torch.long)
+        new = []
+        for k in range(K):
+            xc = torch.cat([torch.cat([imgs[k]] * 2), torch.cat([c_concats[k]] * 2)], dim=1)
+            e_u, e_c = apply_unet(xc, torch.cat([t] * 2), torch.cat([uc_crosses[k], c_crosses[k]])).chunk(2)
+            noise = noises[n] if noises is not None else None
+            n += 1
+            x_prev, _ = cfg_ddim_update(imgs[k], e_u, e_c, scale, tabs["alphas"][index], tabs["alphas_prev"][index],
+                                        tabs["sigmas"][index], tabs["sqrt_one_minus_alphas"][index], noise)
+            new.append(x_prev)
+        pick = multi_pick(K, rng)
+        half = new[0].shape[-1] // 2
+        right = new[pick][..., half:].clone()
+        for k in range(K):
+            new[k][..., half:] = right
+        imgs = new
+    return imgs[0]

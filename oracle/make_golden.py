@@ -223,6 +223,36 @@ def gen_sampler(ns):
     np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
 
 
+def gen_sampler_multi(ns):
+    """`ddim_multi_sampling` (ddim.py:147-222): K conditionings sampled side by side, after every step the right half of
+    ONE randomly picked condition (python `random.shuffle`) overwrites the right half of all of them."""
+    import random
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    ucfg = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": cfg.kwargs()}
+    wrapper = ns.ddpm.DiffusionWrapper(ucfg, "hybrid")
+    _load(wrapper.diffusion_model, G.unet_state(G.TRAJ_CONFIG))
+    out = {}
+    for case, S, eta, B, h, w, K, seed in G.MULTI_CASES:
+        x_T = [G.T(f"{case}.x_T{k}", (B, 4, h, w)) for k in range(K)]
+        conds = [{"c_concat": [G.T(f"{case}.c_concat{k}", (B, 5, h, w))],
+                  "c_crossattn": [G.T(f"{case}.c_cross{k}", (B, 77, cfg.context_dim))]} for k in range(K)]
+        ucs = [{"c_concat": conds[k]["c_concat"], "c_crossattn": [G.T(f"{case}.uc_cross{k}", (B, 77, cfg.context_dim))]}
+               for k in range(K)]
+        noises = [G.T(f"{case}.noise{i}", (B, 4, h, w)) for i in range(S * K)]
+        it = iter(noises)
+        ns.ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        ldm = _FakeLDM(ns, wrapper=wrapper)
+        s = ns.ddim.DDIMSampler(ldm)
+        random.seed(seed)
+        samples, _ = s.sample(S, B, (4, h, w), conds, verbose=False, eta=eta, x_T=[t.clone() for t in x_T],
+                              unconditional_guidance_scale=G.CFG_SCALE, unconditional_conditioning=ucs)
+        out[case + ".samples"] = samples.numpy()
+        out[case + ".t_seq"] = torch.stack([c[0] for c in ldm.calls]).numpy()
+        assert len(ldm.calls) == S * K
+        print(f"  multi {case}: samples mean {samples.mean():+.4f} std {samples.std():.4f} calls {len(ldm.calls)}")
+    np.savez_compressed(os.path.join(OUT, "sampler_multi.npz"), **out)
+
+
 VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
                     num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 
@@ -278,12 +308,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ns = ref_import.import_reference()
-    todo = [a.only] if a.only else ["ops", "sampler", "mv", "vae", "vae_hip", "unet"]
+    todo = [a.only] if a.only else ["ops", "sampler", "sampler_multi", "mv", "vae", "vae_hip", "unet"]
     for what in todo:
         print(f"[{what}]")
         t0 = time.time()
         {"ops": gen_ops, "unet": lambda n: gen_unet(n, a.skip_full), "mv": gen_mv, "sampler": gen_sampler,
-         "vae": gen_vae, "vae_hip": gen_vae_hip}[what](ns)
+         "sampler_multi": gen_sampler_multi, "vae": gen_vae, "vae_hip": gen_vae_hip}[what](ns)
         print(f"[{what}] done in {time.time() - t0:.1f}s")
 
 

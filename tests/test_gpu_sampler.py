@@ -103,14 +103,15 @@ def test_sample_is_deterministic_and_graph_reused():
 def test_log_images_end_to_end_glue():
     """RefInpaintLDM.log_images (ref_inpainting_ldm.py:37-72): VAE encode of image / masked image, nearest mask
     down-sampling, channel order [z | mask | masked latent], unconditional prompt, 50->5 step CFG sampling, VAE decode.
-    The VAE (host PyTorch) is shared with the expected-value computation, so this pins the GLUE, not the VAE."""
+    log_images runs the VAE on the HIP kernels; the expected value uses the PyTorch definition of the same module
+    (pinned to the reference on CPU) and the CPU oracle for the sampler / UNet."""
     import leftrefill_amd.dropin as dropin
     dropin.install()
     from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
     from oracle import weights
     dev = torch.device("cuda:0")
     cfg = G.CONFIGS[G.TRAJ_CONFIG]
-    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
               num_res_blocks=1, attn_resolutions=[], dropout=0.0)
     m = RefInpaintLDM(first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
                                           "params": {"ddconfig": dd, "embed_dim": 4,
@@ -157,6 +158,7 @@ def test_log_images_end_to_end_glue():
     assert torch.equal(out["origin_image"], batch["image"].permute(0, 3, 1, 2))
     # expected value: same VAE (host torch) + CPU oracle for the sampler/UNet
     vae = m.first_stage_model
+    vae.use_hip = False
     with torch.no_grad():
         lat = vae.encode(batch["masked_image"].permute(0, 3, 1, 2).float()).sample() * 0.18215
         mk = torch.nn.functional.interpolate(batch["mask"].permute(0, 3, 1, 2).float(), size=lat.shape[-2:])
@@ -168,3 +170,52 @@ def test_log_images_end_to_end_glue():
     err = (out["pred"].float().cpu() - ref).abs().max().item()
     print(f"[log_images] max|pred - expected| = {err:.3e} (ref absmax {ref.abs().max().item():.2f})")
     assert err <= 5e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case,S,eta,B,h,w,K,seed", G.MULTI_CASES, ids=[c[0] for c in G.MULTI_CASES])
+def test_multi_condition_sampler(golden, case, S, eta, B, h, w, K, seed):
+    """DDIMSampler.sample with a LIST of conditionings -> ddim_multi_sampling (reference ddim.py:147-222), golden from
+    the real reference incl. python-`random` pick sequence; timestep sequence bit-identical."""
+    import random
+    dev = torch.device("cuda:0")
+    m, cfg = model(dev)
+    g = golden("sampler_multi")
+    x_T = [G.T(f"{case}.x_T{k}", (B, 4, h, w)).to(dev) for k in range(K)]
+    conds = [{"c_concat": [G.T(f"{case}.c_concat{k}", (B, 5, h, w)).to(dev)],
+              "c_crossattn": [G.T(f"{case}.c_cross{k}", (B, 77, cfg.context_dim)).to(dev)]} for k in range(K)]
+    ucs = [{"c_concat": conds[k]["c_concat"], "c_crossattn": [G.T(f"{case}.uc_cross{k}", (B, 77, cfg.context_dim)).to(dev)]}
+           for k in range(K)]
+    noises = [G.T(f"{case}.noise{i}", (B, 4, h, w)) for i in range(S * K)]
+    import ldm.models.diffusion.ddim as ddim_mod
+    from ldm.models.diffusion.ddim import DDIMSampler
+    it = iter(noises)
+    orig_noise = ddim_mod.noise_like
+    ddim_mod.noise_like = lambda shape, device, repeat=False: next(it).to(device)
+    t_seq = []
+    orig_apply = m.apply_model
+
+    def spy(x, t, c, **kw):
+        t_seq.append(int(t[0].item()))
+        return orig_apply(x, t, c, **kw)
+
+    m.apply_model = spy
+    try:
+        random.seed(seed)
+        samples, _ = DDIMSampler(m).sample(S, B, (4, h, w), conds, verbose=False, eta=eta, x_T=x_T,
+                                           unconditional_guidance_scale=G.CFG_SCALE, unconditional_conditioning=ucs)
+    finally:
+        ddim_mod.noise_like = orig_noise
+        m.apply_model = orig_apply
+    assert t_seq == list(g[case + ".t_seq"])
+    ref = torch.from_numpy(g[case + ".samples"])
+    sd = G.unet_state(G.TRAJ_CONFIG)
+    random.seed(seed)
+    emul = ddim_ref.ddim_multi_sample(lambda xc, t, ctx: unet_ref.unet_forward(sd, cfg, xc, t, ctx, mode="autocast16"),
+                                      S, [x.cpu() for x in x_T], [c["c_concat"][0].cpu() for c in conds],
+                                      [c["c_crossattn"][0].cpu() for c in conds], [u["c_crossattn"][0].cpu() for u in ucs],
+                                      G.CFG_SCALE, eta=eta, noises=noises)
+    rel = ((samples.float().cpu() - ref).norm() / ref.norm()).item()
+    rel_e = ((emul - ref).norm() / ref.norm()).item()
+    print(f"[multi {case}] rel_l2 {rel:.3e} | autocast16 emulation {rel_e:.3e} | scale {ref.abs().max().item():.2f}")
+    assert torch.isfinite(samples).all()
+    assert rel <= max(2.0 * rel_e, 5e-3), (rel, rel_e)

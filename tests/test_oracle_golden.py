@@ -91,6 +91,31 @@ def test_ddim_trajectory(golden, case, S, eta, B, h, w):
     np.testing.assert_allclose(torch.stack(inter["pred_x0"]).numpy(), g[case + ".pred_x0"], rtol=0, atol=2e-4 * scale)
 
 
+@pytest.mark.parametrize("case,S,eta,B,h,w,K,seed", G.MULTI_CASES, ids=[c[0] for c in G.MULTI_CASES])
+def test_ddim_multi_condition_trajectory(golden, case, S, eta, B, h, w, K, seed):
+    """ddim_multi_sampling (reference ddim.py:147-222) incl. the python-`random` choice of the shared right half."""
+    import random
+    g = golden("sampler_multi")
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    sd = G.unet_state(G.TRAJ_CONFIG)
+    x_T = [G.T(f"{case}.x_T{k}", (B, 4, h, w)) for k in range(K)]
+    cc = [G.T(f"{case}.c_concat{k}", (B, 5, h, w)) for k in range(K)]
+    c = [G.T(f"{case}.c_cross{k}", (B, 77, cfg.context_dim)) for k in range(K)]
+    uc = [G.T(f"{case}.uc_cross{k}", (B, 77, cfg.context_dim)) for k in range(K)]
+    noises = [G.T(f"{case}.noise{i}", (B, 4, h, w)) for i in range(S * K)]
+    t_seq = []
+
+    def apply(xc, t, ctx):
+        t_seq.append(int(t[0]))
+        return unet_ref.unet_forward(sd, cfg, xc, t, ctx)
+
+    random.seed(seed)
+    out = ddim_ref.ddim_multi_sample(apply, S, x_T, cc, c, uc, G.CFG_SCALE, eta=eta, noises=noises)
+    assert t_seq == list(g[case + ".t_seq"])
+    ref = g[case + ".samples"]
+    assert np.abs(out.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("case,V,concat,b,H,W", G.MV_CASES, ids=[c[0] for c in G.MV_CASES])
 def test_multiview_unet(golden, case, V, concat, b, H, W):
     cfg = G.mv_config(V, concat)
