@@ -219,3 +219,86 @@ def test_multi_condition_sampler(golden, case, S, eta, B, h, w, K, seed):
     print(f"[multi {case}] rel_l2 {rel:.3e} | autocast16 emulation {rel_e:.3e} | scale {ref.abs().max().item():.2f}")
     assert torch.isfinite(samples).all()
     assert rel <= max(2.0 * rel_e, 5e-3), (rel, rel_e)
+
+
+@pytest.mark.parametrize("V,concat", [(3, True), (2, False)], ids=["v3_concat_target", "v2_plain"])
+def test_multiview_log_images_end_to_end(V, concat):
+    """`inpainting_ldm.multiview_ref_inpainting_ldm.RefInpaintLDM.log_images` (reference 113-180) over MultiViewUnetModel:
+    5-D batch -> (b v) canvases -> joint sampling -> target view / reference slicing.  Expected value: PyTorch definition
+    of the VAE + CPU oracle of the multi-view UNet and sampler."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.multiview_ref_inpainting_ldm import RefInpaintLDM
+    from oracle import weights
+    dev = torch.device("cuda:0")
+    cfg = G.mv_config(V, concat)
+    v = V - 1 if concat else V
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    m = RefInpaintLDM(first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                          "params": {"ddconfig": dd, "embed_dim": 4,
+                                                     "lossconfig": {"target": "torch.nn.Identity"}}},
+                      cond_stage_config={"target": "torch.nn.Identity"},
+                      unet_config={"target": "ldm.modules.diffusionmodules.multiview_unet.MultiViewUnetModel",
+                                   "params": cfg.kwargs()},
+                      conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
+                      timesteps=1000, channels=4, first_stage_key="image", cond_stage_key="txt",
+                      cond_stage_trainable=True, data_config={"img_size": 64}, view_mode=True, view_num=V,
+                      concat_target=concat)
+    assert (m.view_num, m.concat_target, m.view_mode) == (V, concat, True)
+    sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV.")
+    m.model.diffusion_model.load_state_dict(sd, strict=True)
+    m.first_stage_model.load_state_dict({k: torch.from_numpy(weights.fill_like("vae2." + k, t.shape))
+                                         for k, t in m.first_stage_model.state_dict().items()})
+    b, S = 1, 64
+    Wc = 2 * S if concat else S              # concat_target: [ref | target] canvases; otherwise square views
+    n = b * v
+    ctx_c = G.T("mve2e.c", (n, 77, cfg.context_dim))
+    ctx_u = G.T("mve2e.u", (n, 77, cfg.context_dim))
+
+    class Prompt(torch.nn.Module):
+        def encode(self, txt):
+            assert isinstance(txt, list) and len(txt) == n
+            return (ctx_u if txt[0] == "" else ctx_c).to(dev)
+
+    m.cond_stage_model = Prompt()
+    m = m.to(dev).eval()
+    img = G.T("mve2e.img", (b, v, S, Wc, 3), "unit")
+    mask = torch.zeros(b, v, S, Wc, 1)
+    mask[:, 0, 16:48, Wc - S + 8:Wc - S + 40] = 1.0
+    batch = {"image": img.to(dev), "mask": mask.to(dev), "masked_image": (img * (mask < 0.5)).to(dev), "txt": ["p"] * n}
+    x_T = G.T("mve2e.x_T", (n, 4, S // 8, Wc // 8))
+    import ldm.models.diffusion.ddim as ddim_mod
+    orig_sampling = ddim_mod.DDIMSampler.ddim_sampling
+
+    def with_xT(self, cond, shape, **kw):
+        kw["x_T"] = x_T.to(dev)
+        return orig_sampling(self, cond, shape, **kw)
+
+    ddim_mod.DDIMSampler.ddim_sampling = with_xT
+    try:
+        out = m.log_images(batch, ddim_steps=5, ddim_eta=0.0, unconditional_guidance_scale=2.5)
+    finally:
+        ddim_mod.DDIMSampler.ddim_sampling = orig_sampling
+    assert set(out) == {"masked_image", "origin_image", "pred", "reference"}
+    assert batch["image"].dim() == 4                       # flattened in place like the reference
+    assert out["pred"].shape == (b, 3, S, S) and torch.isfinite(out["pred"]).all()
+    flat_masked = batch["masked_image"].permute(0, 3, 1, 2).reshape(b, v, 3, S, Wc)
+    if concat:
+        assert torch.equal(out["reference"], flat_masked[..., :S]) and out["reference"].shape == (b, v, 3, S, S)
+        assert torch.equal(out["origin_image"], batch["image"].permute(0, 3, 1, 2).reshape(b, v, 3, S, Wc)[:, 0, ..., S:])
+    else:
+        assert torch.equal(out["reference"], flat_masked[:, 1:])
+    vae = m.first_stage_model
+    vae.use_hip = False
+    with torch.no_grad():
+        lat = vae.encode(batch["masked_image"].permute(0, 3, 1, 2).float()).sample() * 0.18215
+        mk = torch.nn.functional.interpolate(batch["mask"].permute(0, 3, 1, 2).float(), size=lat.shape[-2:])
+        c_concat = torch.cat([mk, lat], 1).cpu()
+        z, _ = ddim_ref.ddim_sample(lambda xc, t, c: unet_ref.unet_forward(sd, cfg, xc, t, c), 5, x_T, c_concat, ctx_c,
+                                    ctx_u, 2.5, eta=0.0)
+        full = vae.decode((z / 0.18215).to(dev)).cpu().reshape(b, v, 3, S, Wc)
+    ref = full[:, 0, ..., S:] if concat else full[:, 0]
+    err = (out["pred"].float().cpu() - ref).abs().max().item()
+    print(f"[mv log_images V={V} concat={concat}] max|pred - expected| = {err:.3e} (ref absmax {ref.abs().max().item():.2f})")
+    assert err <= 5e-2 * max(1.0, ref.abs().max().item())
