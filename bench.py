@@ -39,14 +39,23 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 S_DDIM, CFG, ETA = 50, 2.5, 1.0
 
 
-def build_model(device):
+# config 4: view_num / concat_target and the canvas size of one view, all canvases of a sample on ONE GPU
+MV_WORKLOADS = {"mv5": dict(view_num=5, concat_target=True, h=64, w=128),     # 4 canvases [ref_i | target], seq 5*4096
+                "mv4": dict(view_num=4, concat_target=False, h=64, w=64)}     # 4 square views, seq 4*4096
+
+
+def build_model(device, workload="single"):
     import leftrefill_amd.dropin as dropin
     dropin.install()
     from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
+    target, params = "ldm.modules.diffusionmodules.openaimodel.UNetModel", dict(UNET_PARAMS)
+    if workload != "single":
+        mv = MV_WORKLOADS[workload]
+        target = "ldm.modules.diffusionmodules.multiview_unet.MultiViewUnetModel"
+        params.update(view_num=mv["view_num"], concat_target=mv["concat_target"])
     model = RefInpaintLDM(first_stage_config={"target": "torch.nn.Identity"},
                           cond_stage_config={"target": "torch.nn.Identity"},
-                          unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
-                                       "params": dict(UNET_PARAMS)},
+                          unet_config={"target": target, "params": params},
                           conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
                           timesteps=1000, channels=4, image_size=64, first_stage_key="image", cond_stage_key="txt",
                           data_config={"img_size": 512})
@@ -246,6 +255,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="user batch B per GPU (UNet batch 2B under CFG)")
+    ap.add_argument("--workload", default="single", choices=["single", "mv5", "mv4"],
+                    help="single = configs[1] (the metric); mv5 / mv4 = multi-view config 4 on one GPU (not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
@@ -271,8 +282,14 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
     B, h, w = a.batch, 64, 128
+    samples_per_step = B
+    if a.workload != "single":      # B counts canvases from here on; one sample = (view_num - 1 | view_num) canvases
+        mv = MV_WORKLOADS[a.workload]
+        views = mv["view_num"] - 1 if mv["concat_target"] else mv["view_num"]
+        samples_per_step = max(1, a.batch // 4)
+        B, h, w = samples_per_step * views, mv["h"], mv["w"]
 
-    model = build_model(device)
+    model = build_model(device, a.workload)
     batch = synthetic_batch(B, h, w, device, 1234 + rank)
 
     def barrier():
@@ -295,7 +312,7 @@ def main():
         dt = tt.item()
     assert torch.isfinite(out).all()
     ms_per_step = 1e3 * dt / a.steps
-    images_per_s = world * B * a.steps / dt
+    images_per_s = world * samples_per_step * a.steps / dt
     unet_step_ms = ms_per_step / S_DDIM     # per DDIM iteration (UNet step at batch 2B + fused update), incl. host loop
 
     res = {"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": images_per_s,
@@ -306,6 +323,10 @@ def main():
                       "global_batch": world * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
                       "parallelism": f"dp{world} (sample-sharded, no data-path collective)"},
            "per_unet_step_ms": unet_step_ms}
+    if a.workload != "single":
+        res["config"]["workload"] = (f"config 4 ({a.workload}): {MV_WORKLOADS[a.workload]}, {samples_per_step} sample(s) = {B} "
+                                     f"canvases per GPU (UNet batch {2 * B}), 50 DDIM steps, cfg=2.5, eta=1.0, fp16")
+        res["config"]["global_batch"], res["config"]["per_gpu_batch"] = world * samples_per_step, samples_per_step
 
     if rank == 0 and not a.no_roofline:
         kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)
@@ -325,7 +346,7 @@ def main():
         res["kernels"] = {"attention_kernel": kern["attention"],
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and a.workload == "single":
         res["unet_step_events"] = unet_step_events(model, batch, B)
         res["vae_512x1024"] = vae_timing(B, device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
