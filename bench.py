@@ -217,7 +217,7 @@ def vae_timing(B, device):
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
-        out[name] = {"ms": ms, "batch": B, "tflops": B * tflop / ms}
+        out[name] = {"ms": ms, "batch": B, "tflops": B * tflop / (ms * 1e-3)}
     return out
 
 

@@ -114,6 +114,13 @@ int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
 int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                      int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 
+/* Same attention with V supplied pre-transposed: vt [B][heads*64][ld_vt] from lr_transpose_v_f16 (ld_vt = Nkv rounded up
+ * to 64, tail keys zero, keys permuted inside every group of 16 to the MFMA k-slot order).  The V tile then streams into
+ * LDS by DMA like K; worth it for long key sequences (self-attention), the transpose costs one read + write of V. */
+int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt, lr_half* o,
+                        int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s);
+
 /* ---- row softmax of materialised logits (VAE AttnBlock: single head, d_head = C = 512) ---------------------------
  * replaces: `w_ = w_ * (int(c)**(-0.5)); w_ = softmax(w_, dim=2)` (ldm/modules/diffusionmodules/model.py:186-187) between
  *           the two bmm's (185, 192), which run through lr_gemm_conv_f16 (logits = q k^T with wt = k; out = p v with

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -52,6 +52,9 @@ SIGNATURES = {
     "lr_gemm_conv_f16": [ctypes.POINTER(GemmArgs), c_void_p],
     "lr_attention_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_float, c_void_p],
+    "lr_attention_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                         c_int, c_float, c_void_p],
+    "lr_transpose_v_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_ddim_cfg_step": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,

@@ -32,6 +32,10 @@ struct AttnParams {
   float c;  // scale * log2(e)
 };
 
+// VT = true: P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below):
+// the V tile then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment
+// is ONE ds_read_b128.
+template <bool VT>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams P) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KB * 128 + 2 * 64 * VT_PITCH];
   char* Ksm = smem;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 
   const f16* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
   const f16* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
-  const f16* vp = P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
+  const f16* vp = VT ? P.v + ((size_t)b * P.heads + h) * 64 * P.ldv : P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
   f16* op = P.o + (size_t)b * P.Nq * P.ldo + h * 64;
   const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
 
@@ -80,6 +84,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const f16* g = key < P.Nkv ? kp + (size_t)key * P.ldk + chunk * 8 : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ks + rbase * 128), 16, 0, 0);
+    }
+  };
+  // V^T staging (VT): rows = d, 128 bytes = the tile's 64 (permuted) keys; ldv is padded to whole tiles and zero filled
+  auto stage_vt = [&](int buf, int tile) {
+    char* Vs = Vsm + buf * (64 * VT_PITCH);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (i * 4 + w) * 8;
+      const int row = rbase + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const f16* g = vp + (size_t)row * P.ldv + tile * ATT_KB + chunk * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Vs + rbase * 128), 16, 0, 0);
     }
   };
   // V staging through registers: thread owns key pair kpair = w*8 + lane/8 and d-chunk j = lane%8
@@ -114,9 +130,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  {
+  stage_k(0, 0);
+  if constexpr (VT) {
+    stage_vt(0, 0);
+  } else {
     uint4 v0, v1;
-    stage_k(0, 0);
     load_v(0, v0, v1);
     write_v(0, v0, v1);
   }
@@ -128,7 +146,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
     if (more) {
       stage_k(cur ^ 1, tile + 1);
-      load_v(tile + 1, nv0, nv1);
+      if constexpr (VT) stage_vt(cur ^ 1, tile + 1);
+      else load_v(tile + 1, nv0, nv1);
     }
     const char* Ks = Ksm + cur * (ATT_KB * 128);
     const char* Vs = Vsm + cur * (64 * VT_PITCH);
@@ -207,17 +226,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int drow = db * 32 + ql;
-          const int key0 = kb * 32 + 16 * tt + 4 * hi;
-          const f16x4 va = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + key0 * 2);
-          const f16x4 vb = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + (key0 + 8) * 2);
           f16x8 vf;
-          vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
-          vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+          if constexpr (VT) {
+            const int vc = kb * 4 + tt * 2 + hi;     // 16-byte chunk = this lane's 8 k-slots, contiguous after the permute
+            vf = *reinterpret_cast<const f16x8*>(Vs + drow * 128 + ((vc ^ ((drow >> 1) & 7)) << 4));
+          } else {
+            const int key0 = kb * 32 + 16 * tt + 4 * hi;
+            const f16x4 va = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + key0 * 2);
+            const f16x4 vb = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + (key0 + 8) * 2);
+            vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+            vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+          }
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb)
             oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][tt], oacc[qb][db], 0, 0, 0);
         }
-    if (more) write_v(cur ^ 1, nv0, nv1);
+    if constexpr (!VT) {
+      if (more) write_v(cur ^ 1, nv0, nv1);
+    }
     __syncthreads();
   }
 
@@ -245,11 +271,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   }
 }
 
-extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
-                                lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
+static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
+                            int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nkv <= 0) return LR_E_ARG;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
+  if (vt && (ldv % ATT_KB || ldv < Nkv)) return LR_E_ALIGN;
   AttnParams P;
   P.q = (const f16*)q; P.k = (const f16*)k; P.v = (const f16*)v; P.o = (f16*)o;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
@@ -257,6 +284,59 @@ extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int
   P.nqt = (Nq + ATT_QB - 1) / ATT_QB;
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
-  hipLaunchKernelGGL(attention_kernel, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  if (vt) hipLaunchKernelGGL(attention_kernel<true>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  else hipLaunchKernelGGL(attention_kernel<false>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  return lr_launch_status();
+}
+
+extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+                                lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
+  return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false);
+}
+
+extern "C" int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt,
+                                   lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
+  return launch_attention(q, ldq, k, ldk, vt, ld_vt, o, ldo, B, heads, Nq, Nkv, scale, s, true);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// V [B][Nkv][ldv] (head h = columns h*64 .. +64)  ->  V^T [B][heads*64][ld_vt], ld_vt = Nkv rounded up to 64, tail keys
+// zero.  Within every group of 16 keys the order is [0-3, 8-11, 4-7, 12-15]: the 8 k-slots an MFMA lane needs for
+// P^T (the S^T accumulator's key order, see attention_kernel) become one contiguous 16-byte piece.
+// grid = (key tiles, heads, B), block = 256.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict__ v, int ldv, f16* __restrict__ vt, int ld_vt,
+                                                          int heads, int Nkv) {
+  __shared__ f16 tile[64][72];     // [key][d], 144-byte pitch
+  const int t = threadIdx.x;
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const f16* src = v + (size_t)b * Nkv * ldv + h * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int key = i * 32 + (t >> 3), j = t & 7;
+    const int gk = kt * 64 + key;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (gk < Nkv) u = *reinterpret_cast<const uint4*>(src + (size_t)gk * ldv + j * 8);
+    *reinterpret_cast<uint4*>(&tile[key][j * 8]) = u;
+  }
+  __syncthreads();
+  const int d = t >> 2, g = t & 3;      // output row d, 16-key group g
+  f16 r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ko = (i & 3) + ((i >> 2) == 0 ? 0 : (i >> 2) == 1 ? 8 : (i >> 2) == 2 ? 4 : 12);
+    r[i] = tile[g * 16 + ko][d];
+  }
+  f16* dst = vt + (((size_t)b * heads + h) * 64 + d) * ld_vt + kt * 64 + g * 16;
+  *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&r[0]);
+  *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&r[8]);
+}
+
+extern "C" int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv,
+                                  lr_stream_t s) {
+  if (!v || !vt || B <= 0 || heads <= 0 || Nkv <= 0) return LR_E_ARG;
+  if (ldv % 8 || ld_vt % ATT_KB || ld_vt < Nkv || (((uintptr_t)v | (uintptr_t)vt) & 15)) return LR_E_ALIGN;
+  dim3 grid(ld_vt / ATT_KB, heads, B);
+  hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)s, (const f16*)v, ldv, (f16*)vt, ld_vt, heads, Nkv);
   return lr_launch_status();
 }

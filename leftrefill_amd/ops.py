@@ -197,15 +197,35 @@ def _tune_tiles(lib, a, device, geglu, reps=3):
     return best
 
 
-def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None):
+VT_MIN_KEYS = int(os.environ.get("LEFTREFILL_VT_MIN_KEYS", "1024"))   # pre-transpose V for key sequences at least this long
+
+
+def transpose_v(v, B, heads, Nkv):
+    """v [B*Nkv, >=heads*64] (row stride ldv) -> V^T [B, heads*64, pad64(Nkv)] in the attention kernel's key order."""
+    lib = _lib.load()
+    assert v.is_cuda and v.dtype == torch.float16 and v.stride(1) == 1
+    ld = ((Nkv + 63) // 64) * 64
+    vt = torch.empty(B, heads * 64, ld, device=v.device, dtype=torch.float16)
+    _lib.check(lib.lr_transpose_v_f16(_p(v), v.stride(0), _p(vt), ld, B, heads, Nkv, _stream()), "transpose_v")
+    return vt
+
+
+def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     """q [B*Nq, >=heads*64] (row stride = ldq), k/v [B*Nkv, ...]; returns [B*Nq, heads*64] fp16.
 
-    q/k/v may be column slices of a fused projection (strided rows, unit column stride)."""
+    q/k/v may be column slices of a fused projection (strided rows, unit column stride).  Long key sequences go through
+    the pre-transposed-V kernel (vt: optional cached result of transpose_v, e.g. for a fixed context)."""
     lib = _lib.load()
     for t_ in (q, k, v):
         assert t_.is_cuda and t_.dtype == torch.float16 and t_.stride(1) == 1
     if out is None:
         out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+    if vt is None and Nkv >= VT_MIN_KEYS:
+        vt = transpose_v(v, B, heads, Nkv)
+    if vt is not None:
+        _lib.check(lib.lr_attention_vt_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),
+                                           out.stride(0), B, heads, Nq, Nkv, float(scale), _stream()), "attention_vt")
+        return out
     _lib.check(lib.lr_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                     B, heads, Nq, Nkv, float(scale), _stream()), "attention")
     return out

@@ -297,6 +297,39 @@ def test_attention(B, heads, Nq, Nkv):
     report(f"attention B{B} h{heads} {Nq}x{Nkv}", o.reshape(B, Nq, C), ref, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 2, 256, 256), (1, 3, 300, 200), (2, 1, 64, 77), (1, 2, 1024, 1024),
+                                            (1, 1, 130, 1100)])
+def test_attention_pretransposed_v(B, heads, Nq, Nkv):
+    """lr_transpose_v_f16 + lr_attention_vt_f16 (V^T streamed by LDS-DMA): same result as the register-transposing
+    kernel -- bit-identical, since the MFMA operands are the same values in the same k order -- incl. key tails."""
+    from leftrefill_amd import ops
+    d = dev()
+    C = heads * 64
+    q = h16(G.T(f"attvt.{Nq}.{Nkv}.q", (B, Nq, C))).reshape(B * Nq, C).half().to(d)
+    kv = torch.cat([h16(G.T(f"attvt.{Nq}.{Nkv}.k", (B, Nkv, C))), h16(G.T(f"attvt.{Nq}.{Nkv}.v", (B, Nkv, C)))], -1)
+    kv = kv.reshape(B * Nkv, 2 * C).half().to(d)
+    k, v = kv[:, :C], kv[:, C:]                       # strided column slices like the fused projections
+    vt = ops.transpose_v(v, B, heads, Nkv)
+    ld = vt.shape[2]
+    assert ld % 64 == 0 and ld >= Nkv
+    # layout check: within each 16-key group the order is [0-3, 8-11, 4-7, 12-15]; tail keys are zero
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    vpad = torch.zeros(B, ld, C, dtype=torch.float16, device=d)
+    vpad[:, :Nkv] = v.reshape(B, Nkv, C)
+    idx = (torch.arange(ld).reshape(-1, 16)[:, perm]).reshape(-1).to(d)
+    assert torch.equal(vt, vpad[:, idx].permute(0, 2, 1).contiguous())
+    old_min = ops.VT_MIN_KEYS
+    try:
+        ops.VT_MIN_KEYS = 1 << 30
+        o_ref = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
+        ops.VT_MIN_KEYS = 1
+        o_vt = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
+    finally:
+        ops.VT_MIN_KEYS = old_min
+    assert torch.equal(o_ref, o_vt)
+    assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt), o_ref)
+
+
 def test_attention_online_softmax_rescale():
     """Force the running max to jump late in the sequence (guide rule 26): one key matches one query strongly."""
     from leftrefill_amd import ops

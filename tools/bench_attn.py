@@ -14,6 +14,8 @@ dev = torch.device("cuda:0")
 qkv = torch.randn(B * Nq, 3 * C, device=dev).half()
 kv = qkv if Nq == Nkv else torch.randn(B * Nkv, 3 * C, device=dev).half()
 f = lambda: ops.attention(qkv[:, :C], kv[:, C:2 * C], kv[:, 2 * C:], B, heads, Nq, Nkv, 0.125)
+if len(sys.argv) > 6:
+    ops.VT_MIN_KEYS = int(sys.argv[6])      # 1: always pre-transpose V; huge: never
 for _ in range(3):
     f()
 torch.cuda.synchronize()
