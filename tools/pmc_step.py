@@ -34,11 +34,26 @@ def run():
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
+    from leftrefill_amd import ops
+    descs = []
+    orig = ops.gemm_conv
+
+    def spy(*a, **k):
+        descs.append(dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[0], K=a[1].shape[1], taps=k.get("taps", 1),
+                          stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
+                          resid=k.get("resid") is not None))
+        return orig(*a, **k)
+
     with torch.no_grad():
-        for _ in range(2):
+        for i in range(2):
+            if i == 1:
+                ops.gemm_conv = spy
             unet(x, t, ctx)
             torch.cuda.synchronize()
-    print("pmc_step: done")
+    ops.gemm_conv = orig
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(descs, open("gpurun_out/pmc_descs.json", "w"))
+    print("pmc_step: done", len(descs))
 
 
 def _rows(d):
@@ -53,12 +68,32 @@ def _rows(d):
 
 def reduce_(fetch_dir, write_dir, out_path, launches=210):
     res = {}
+    per = {}
     for key, d, counter, corr in (("fetch", fetch_dir, "FETCH_SIZE", 2.0), ("write", write_dir, "WRITE_SIZE", 1.0)):
         rows = [r for r in _rows(d) if "gemm_conv" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         last = rows[-launches:]
         kib = sum(float(r["Counter_Value"]) for r in last)
         res[key + "_bytes_per_launch"] = corr * kib * 1024.0 / len(last)
         res[key + "_launches"] = len(last)
+        per[key] = [corr * float(r["Counter_Value"]) * 1024.0 for r in last]
+    if os.path.exists("gpurun_out/pmc_descs.json"):
+        descs = json.load(open("gpurun_out/pmc_descs.json"))
+        if len(descs) == len(per["fetch"]):
+            agg = {}
+            for d, f, w in zip(descs, per["fetch"], per["write"]):
+                src_rows = d["M"] * (4 if d["stride"] == 2 else 1) / (4 if d["up"] else 1)
+                n_out = d["N"] // 2 if d["geglu"] else d["N"]
+                alg_r = 2.0 * (src_rows * d["K"] / d["taps"] + d["N"] * d["K"] + (d["M"] * n_out if d["resid"] else 0))
+                alg_w = 2.0 * d["M"] * n_out
+                k = f'{d["M"]}x{d["N"]}x{d["K"]} t{d["taps"]} s{d["stride"]} u{d["up"]}' + (" geglu" if d["geglu"] else "")
+                a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0])
+                a[0] += 1; a[1] += f; a[2] += alg_r; a[3] += w; a[4] += alg_w
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            res["per_shape"] = [dict(shape=k, n=a[0], fetch_mb=a[1] / a[0] / 1e6, alg_read_mb=a[2] / a[0] / 1e6,
+                                     write_mb=a[3] / a[0] / 1e6, alg_write_mb=a[4] / a[0] / 1e6) for k, a in rows]
+            for r in res["per_shape"][:30]:
+                print(f'{r["shape"]:38s} n={r["n"]:2d} fetch {r["fetch_mb"]:8.1f} MB (alg {r["alg_read_mb"]:7.1f})  '
+                      f'write {r["write_mb"]:7.1f} (alg {r["alg_write_mb"]:7.1f})')
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
     res["note"] = ("GEMM family, last eager UNet step at batch 8 (configs[1]); FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE "
                    "as reported (uncalibrated per the guide); separate --pmc passes")
