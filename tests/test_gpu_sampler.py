@@ -302,3 +302,54 @@ def test_multiview_log_images_end_to_end(V, concat):
     err = (out["pred"].float().cpu() - ref).abs().max().item()
     print(f"[mv log_images V={V} concat={concat}] max|pred - expected| = {err:.3e} (ref absmax {ref.abs().max().item():.2f})")
     assert err <= 5e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_config1_full_width_256x512_10_steps():
+    """BASELINE.json configs[0]: 1-ref inpainting at 256x512 (latent 32x64), bs=1, 10 DDIM steps, cfg=2.5 -- the full
+    866 M-parameter SD2-inpainting UNet on the HIP path against the CPU oracle (fp32 restatement pinned to the reference
+    at this width by goldens G4) on identical latents / timesteps.  Also prints the oracle's CPU time for this config."""
+    import time
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
+    dev = torch.device("cuda:0")
+    cfg = G.CONFIGS["FULL"]
+    sd = G.unet_state("FULL")
+    m = RefInpaintLDM(first_stage_config={"target": "torch.nn.Identity"},
+                      cond_stage_config={"target": "torch.nn.Identity"},
+                      unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                   "params": cfg.kwargs()},
+                      conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
+                      timesteps=1000, channels=4, data_config={"img_size": 256})
+    m.model.diffusion_model.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    B, h, w, S = 1, 32, 64, 10
+    x_T = G.T("cfg1.x_T", (B, 4, h, w))
+    c_concat = G.T("cfg1.c_concat", (B, 5, h, w))
+    c_cross = G.T("cfg1.c_cross", (B, 77, cfg.context_dim))
+    uc_cross = G.T("cfg1.uc_cross", (B, 77, cfg.context_dim))
+    t_seq = []
+    orig_apply = m.apply_model
+
+    def spy(x, t, c, **kw):
+        t_seq.append(int(t[0].item()))
+        return orig_apply(x, t, c, **kw)
+
+    m.apply_model = spy
+    cond = {"c_concat": [c_concat.to(dev)], "c_crossattn": [c_cross.to(dev)]}
+    uc = {"c_concat": [c_concat.to(dev)], "c_crossattn": [uc_cross.to(dev)]}
+    samples, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=S, eta=0.0, x_T=x_T.to(dev),
+                              unconditional_guidance_scale=G.CFG_SCALE, unconditional_conditioning=uc)
+    m.apply_model = orig_apply
+    trace = []
+    t0 = time.time()
+    ref, _ = ddim_ref.ddim_sample(lambda xc, t, ctx: unet_ref.unet_forward(sd, cfg, xc, t, ctx), S, x_T, c_concat,
+                                  c_cross, uc_cross, G.CFG_SCALE, eta=0.0, trace=trace)
+    cpu_s = time.time() - t0
+    assert t_seq == [tr[1] for tr in trace] == list(range(901, 0, -100))       # [901, 801, ..., 1]
+    err = (samples.float().cpu() - ref).abs()
+    rel = (err.norm() / ref.norm()).item()
+    print(f"[config 1] 256x512 bs=1 S=10: rel_l2 {rel:.3e} max_abs {err.max().item():.3e} (|ref| max "
+          f"{ref.abs().max().item():.2f}); CPU oracle {cpu_s:.1f} s on {torch.get_num_threads()} threads")
+    assert torch.isfinite(samples).all()
+    assert rel <= 6e-3
