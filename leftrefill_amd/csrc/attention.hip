@@ -18,11 +18,14 @@
 //   more than 2^8 (exp2 domain).
 #include "common.h"
 
+#include <type_traits>
+
 #define ATT_THREADS 256
 #define ATT_QB 256
 #define ATT_KB 64
 #define VT_PITCH 136  // bytes per V^T row (64 keys * 2 B + 8 pad)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -140,7 +143,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   }
   __syncthreads();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
+  // One K/V tile.  TAIL is a compile-time tag: only a partial last tile carries the key-index compares of the -inf mask
+  // (left in the common path they cost ~70 VALU instructions per tile -- the compiler hoists them above the branch).
+  auto process_tile = [&](int tile, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int cur = tile & 1;
     const bool more = tile + 1 < ntiles;
     uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
-      if (tile * ATT_KB + ATT_KB > P.Nkv) {
+      if constexpr (TAIL) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -203,17 +209,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
       }
-      const float mc = m_run[qb] * P.c;
-      float psum = 0.f;
+      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two values per VALU issue) for the exp2 argument and the row sum
+      const f32x2 c2 = {P.c, P.c};
+      const f32x2 mc2 = {m_run[qb] * P.c, m_run[qb] * P.c};
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], P.c, -mc));
-          psum += p;
-          pf[qb][kb][r >> 3][r & 7] = (f16)p;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+          const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
+          const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          ps2 += pv;
+          pf[qb][kb][r >> 3][r & 7] = (f16)pv[0];
+          pf[qb][kb][r >> 3][(r & 7) + 1] = (f16)pv[1];
         }
-      l_run[qb] += psum;
+      l_run[qb] += ps2[0] + ps2[1];
     }
 
     // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; k-slot (hi*8 + jj) of MFMA (kb, tt) is key
@@ -245,7 +256,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       if (more) write_v(cur ^ 1, nv0, nv1);
     }
     __syncthreads();
-  }
+  };
+  const int nfull = P.Nkv / ATT_KB;
+  for (int tile = 0; tile < nfull; ++tile) process_tile(tile, std::false_type{});
+  if (nfull < ntiles) process_tile(nfull, std::true_type{});
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
