@@ -174,7 +174,8 @@ def _workspace(lib, a, device):
     return ws
 
 
-def _tune_tiles(lib, a, device, geglu, reps=3):
+def _tune_tiles(lib, a, device, geglu, reps=4, rounds=2):
+    """Time every tile configuration (best of `rounds` x `reps` launches) and return the fastest."""
     st = _stream()
     best, best_t = None, float("inf")
     for tm, tn in TILE_CANDIDATES:
@@ -184,13 +185,15 @@ def _tune_tiles(lib, a, device, geglu, reps=3):
         ws = _workspace(lib, a, device)
         if lib.lr_gemm_conv_f16(a, st) != 0:
             continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            lib.lr_gemm_conv_f16(a, st)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1)
+        t = float("inf")
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                lib.lr_gemm_conv_f16(a, st)
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1))
         del ws
         if t < best_t:
             best, best_t = (tm, tn), t
