@@ -175,19 +175,19 @@ def unet_step_events(model, batch, B, n=25, warm=5):
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
-    times, upd = [], []
+    evs = []
     with torch.no_grad():
-        for i in range(warm + n):
+        for i in range(warm + n):        # no host sync inside the loop: launches stay queued ahead of the GPU like in sample()
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
             eps = unet(x, t, ctx)
             e1.record()
             ops.ddim_cfg_step(x_T, eps, x_T, CFG, 0.5, 0.6, 0.1, 0.7)
             e2.record()
-            e2.synchronize()
-            if i >= warm:
-                times.append(e0.elapsed_time(e1))
-                upd.append(1e3 * e1.elapsed_time(e2))
+            evs.append((e0, e1, e2))
+    torch.cuda.synchronize()
+    times = [a.elapsed_time(b) for a, b, _ in evs[warm:]]
+    upd = [1e3 * b.elapsed_time(c) for _, b, c in evs[warm:]]
     times.sort()
     upd.sort()
     return {"unet_forward_ms_median": times[len(times) // 2], "unet_forward_ms_min": times[0],
