@@ -86,7 +86,8 @@ typedef struct lr_gemm_args {
   const lr_half* p2; int32_t C2;
   int32_t B, H, W;          /* output grid; M = B*H*W */
   int32_t Hs, Ws;           /* source grid */
-  int32_t taps, stride, up;
+  int32_t taps, stride, up; /* up: 0 none | 1 nearest 2x | 2 zero-insertion 2x (odd source rows / columns read as 0: with
+                               flipped, transposed weights this is the input gradient of a stride-2 conv) */
   int32_t asym;             /* 0: 3x3 pad 1 on every side; 1: pad only bottom/right (F.pad (0,1,0,1) + padding 0, the VAE
                                Downsample, ldm/modules/diffusionmodules/model.py:83-86) */
   const lr_half* wt; int32_t N;      /* weights [N][taps*(C1+C2)] */
@@ -142,6 +143,26 @@ int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr
 int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev,
                      float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t,
                      float sqrt_one_minus_at, lr_stream_t s);
+
+/* ==== backward of the same operators (training with frozen weights: input gradients only) =========================
+ * replaces: what torch.autograd derives for the reference's modules under `loss.backward()` (train_inpainting.py:141 ->
+ *           LatentDiffusion.p_losses, ldm/models/diffusion/ddpm.py:900-935), recomputed per block by
+ *           CheckpointFunction.backward (ldm/modules/diffusionmodules/util.py:133-151).
+ * Input gradients of conv / linear are lr_gemm_conv_f16 itself on flipped / transposed weights (stride-2: `up = 2`). */
+
+/* LayerNorm: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  x, dy, dx [M][C] fp16. */
+int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M, int C,
+                     lr_stream_t s);
+/* GroupNorm(32)[+SiLU] over the virtual concat [x1 | x2]: fwd_partials = lr_groupnorm_stats of the same input;
+ * bwd_partials: N*LR_GN_CHUNKS*64 floats of scratch; dy [N*HW][C1+C2]; dx1 [N*HW][C1], dx2 [N*HW][C2] (NULL if C2 = 0). */
+int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
+                     const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu,
+                     float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s);
+/* GEGLU: pre = projection + bias in the packed [u16 | g16] column layout (lr_gemm_conv_f16 with geglu = 0 on the packed
+ * weights), dy [M][H] -> dpre [M][2H] (same layout): du = dy * gelu(g), dg = dy * u * gelu'(g). */
+int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s);
+/* nearest-2x upsample: y[n][h][w][:] = sum of the four fine pixels of x [N][2H][2W][C]. */
+int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
 
 #ifdef __cplusplus
 }

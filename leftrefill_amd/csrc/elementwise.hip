@@ -186,7 +186,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 5; }
+extern "C" int lr_abi_version(void) { return 6; }
 
 extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
                                        int H, int W, lr_stream_t s) {
@@ -275,5 +275,83 @@ extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32,
     hipLaunchKernelGGL(ddim_cfg_step_kernel<f16>, grid, block, 0, (hipStream_t)s, x, (const f16*)eps, noise, x_prev,
                        pred_x0, (long long)numel, cfg_scale, sqrt_at, sqrt_one_minus_at, sqrt_aprev, dir_coef,
                        sigma_t);
+  return lr_launch_status();
+}
+
+
+// =====================================================================================================================
+// Backward helpers (training with frozen weights)
+// =====================================================================================================================
+// GEGLU backward.  pre [M][2H]: the projection (+bias) in the packed layout of lr_gemm_conv_f16 (16-column groups
+// [u16 | g16 | u16 | g16 ...]); dy [M][H];  dpre (same layout as pre): du = dy * gelu(g), dg = dy * u * gelu'(g),
+// gelu'(g) = Phi(g) + g * phi(g)  (erf form, attention.py:56-58).  One thread per 8 output columns.
+__global__ void geglu_bwd_kernel(const f16* __restrict__ pre, const f16* __restrict__ dy, f16* __restrict__ dpre, long long total,
+                                 int H) {
+  const int cpr = H >> 3;      // 8-column chunks per row of dy
+  for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const long long m = id / cpr;
+    const int c = (int)(id - m * cpr) * 8;            // first output column of this chunk
+    const int pc = (c >> 4) * 32 + (c & 15);          // packed column of u; g sits 16 columns later
+    float u[8], g[8], d[8], du[8], dg[8];
+    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
+    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
+    lr_unpack8(*reinterpret_cast<const uint4*>(dy + m * H + c), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float cdf = 0.5f * (1.0f + lr_erf(g[i] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[i] * g[i]);
+      du[i] = d[i] * g[i] * cdf;
+      dg[i] = d[i] * u[i] * fmaf(g[i], pdf, cdf);
+    }
+    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc) = lr_pack8(du);
+    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc + 16) = lr_pack8(dg);
+  }
+}
+
+extern "C" int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) {
+  if (!pre || !dy || !dpre || M <= 0 || H <= 0) return LR_E_ARG;
+  if (H % 16) return LR_E_ALIGN;
+  const long long total = (long long)M * (H / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)pre, (const f16*)dy,
+                     (f16*)dpre, total, H);
+  return lr_launch_status();
+}
+
+// Backward of the nearest-2x upsample in front of a conv (Upsample.forward, openaimodel.py:115): the four fine pixels
+// of a coarse pixel add up.  x [N][2H][2W][C] -> y [N][H][W][C].
+__global__ void sumpool2x2_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long total, int H, int W, int C) {
+  const int cpr = C >> 3;
+  for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % cpr) * 8;
+    long long pix = id / cpr;
+    const int xw = (int)(pix % W);
+    pix /= W;
+    const int yh = (int)(pix % H);
+    const long long n = pix / H;
+    const f16* src = x + ((n * 2 * H + 2 * yh) * 2 * W + 2 * xw) * (long long)C + c;
+    float a[8], acc[8];
+    lr_unpack8(*reinterpret_cast<const uint4*>(src), acc);
+    lr_unpack8(*reinterpret_cast<const uint4*>(src + C), a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += a[i];
+    lr_unpack8(*reinterpret_cast<const uint4*>(src + 2LL * W * C), a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += a[i];
+    lr_unpack8(*reinterpret_cast<const uint4*>(src + 2LL * W * C + C), a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += a[i];
+    *reinterpret_cast<uint4*>(y + ((n * H + yh) * W + xw) * (long long)C + c) = lr_pack8(acc);
+  }
+}
+
+extern "C" int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0) return LR_E_ARG;
+  if (C % 8) return LR_E_ALIGN;
+  const long long total = (long long)N * H * W * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)x, (f16*)y, total, H, W, C);
   return lr_launch_status();
 }

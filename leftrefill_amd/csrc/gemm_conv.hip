@@ -24,7 +24,7 @@
 
 struct GemmParams {
   const f16* p1; const f16* p2; const f16* wt; const float* bias; const f16* rowvec; const f16* resid; f16* out;
-  int C1, C2, H, W, Hs, Ws, taps, stride, up, pad, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
+  int C1, C2, H, W, Hs, Ws, taps, stride, up, pad, zins, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
   int ntiles_n, nblocks;
   int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
   int ntiles_m, m_fastest; // tile order inside an XCD's contiguous chunk (see tile_order())
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
       for (int i = 0; i < 4; ++i) {
         const int row = (i * 4 + w) * 8 + (lane >> 3);
         const int iy = ry[i] + dy, ix = rx[i] + dx;
-        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && !(((iy | ix) & 1) & P.zins);
         const int sy = iy >> P.up, sx = ix >> P.up;
         const int chunk = slot ^ ((row >> 1) & 7);
         avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
       for (int i = 0; i < 4; ++i) {
         const int row = (i * 8 + w) * 8 + (lane >> 3);
         const int iy = ry[i] + dy, ix = rx[i] + dx;
-        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && !(((iy | ix) & 1) & P.zins);
         const int sy = iy >> P.up, sx = ix >> P.up;
         const int chunk = slot ^ ((row >> 1) & 7);
         avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
@@ -713,10 +713,12 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (P.C1 <= 0 || P.C1 % 64 || P.C2 % 64) return LR_E_ALIGN;
   if (a->taps != 1 && a->taps != 9) return LR_E_UNSUPPORTED;
   if (a->stride != 1 && a->stride != 2) return LR_E_UNSUPPORTED;
-  if (a->up != 0 && a->up != 1) return LR_E_UNSUPPORTED;
+  if (a->up < 0 || a->up > 2) return LR_E_UNSUPPORTED;
   if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Hs <= 0 || a->Ws <= 0 || a->N <= 0) return LR_E_ARG;
   P.H = a->H; P.W = a->W; P.Hs = a->Hs; P.Ws = a->Ws;
   P.taps = a->taps; P.stride = a->stride; P.up = a->up;
+  P.zins = (a->up == 2) ? 1 : 0;      // up == 2: zero-insertion upsample (dgrad of a stride-2 conv)
+  if (P.zins) P.up = 1;
   P.pad = a->asym ? 0 : 1;   // asym: F.pad(x, (0,1,0,1)) + conv padding 0 (VAE Downsample)
   P.wt = (const f16*)a->wt; P.N = a->N; P.bias = a->bias;
   P.M = a->B * a->H * a->W;

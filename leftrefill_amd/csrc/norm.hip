@@ -365,3 +365,259 @@ extern "C" int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, f
   else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
   return lr_launch_status();
 }
+
+// =====================================================================================================================
+// Backward (training, frozen weights: only the input gradient is produced).  fp16 activations / gradients, fp32 math.
+// =====================================================================================================================
+
+// ---- LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  One wave per row.
+template <int NV>
+__global__ void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, const float* __restrict__ gamma,
+                                     float eps, f16* __restrict__ dx, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nOct = C >> 3;
+  float v[NV][8], g[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+      lr_unpack8(*reinterpret_cast<const uint4*>(x + (size_t)row * C + o * 8), v[j]);
+      lr_unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)row * C + o * 8), g[j]);
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + o * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + o * 8 + 4);
+      const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sum += v[j][i]; g[j][i] *= gm[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { v[j][i] = 0.f; g[j][i] = 0.f; }
+    }
+  }
+  const float mean = lr_wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; sq = fmaf(d, d, sq); }
+    }
+  }
+  const float rstd = rsqrtf(lr_wave_sum(sq) / (float)C + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[j][i] = (v[j][i] - mean) * rstd;     // xhat
+        s1 += g[j][i];
+        s2 = fmaf(g[j][i], v[j][i], s2);
+      }
+    }
+  }
+  s1 = lr_wave_sum(s1) / (float)C;
+  s2 = lr_wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + j * 64;
+    if (o < nOct) {
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = rstd * (g[j][i] - s1 - v[j][i] * s2);
+      *reinterpret_cast<uint4*>(dx + (size_t)row * C + o * 8) = lr_pack8(f);
+    }
+  }
+}
+
+extern "C" int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M,
+                                int C, lr_stream_t s) {
+  if (!x || !dy || !gamma || !dx || M <= 0) return LR_E_ARG;
+  if (C % 8 || C > 2048) return LR_E_ALIGN;
+  const int nv = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)s;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
+    case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
+    case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
+    default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
+  }
+  return lr_launch_status();
+}
+
+// ---- GroupNorm(32)[+SiLU] backward.  z = xhat * gamma + beta, y = act(z); dz = dy * act'(z), g = dz * gamma;
+//      per (sample, group): S1 = sum g, S2 = sum g * xhat;  dx = rstd * (g - (S1 + xhat * S2) / m),  m = HW * C/32.
+//      Two launches like the forward: bwd_stats -> partials [N][chunks][32][2] (S1, S2), bwd_apply -> dx1 | dx2.
+//      Both re-derive mean / rstd from the FORWARD partials (lr_groupnorm_stats of the same input).
+__device__ __forceinline__ void gn_finalize_stats(const float* __restrict__ partials, int n, int nchunks, int HW, int Cg,
+                                                  float eps, float* s_mean, float* s_rstd) {
+  const int t = threadIdx.x;
+  if (t < 128) {
+    const int g = t >> 2, sub = t & 3;
+    double s = 0.0, q = 0.0;
+    const float* ps = partials + ((size_t)n * nchunks * 32 + g) * 2;
+    for (int c = sub; c < nchunks; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+#pragma unroll
+    for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+    if (sub == 0) {
+      const double cnt = (double)HW * (double)Cg;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+}
+
+__device__ __forceinline__ float gn_act_grad(float z, int silu) {
+  if (!silu) return 1.0f;
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  return sg * fmaf(z, 1.0f - sg, 1.0f);
+}
+
+__global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+                                    const f16* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float eps, int silu, float* __restrict__ out, int nOct,
+                                    int R, int nchunks) {
+  extern __shared__ float s_part[];  // [R][C][2]
+  __shared__ float s_mean[32], s_rstd[32];
+  const int C = C1 + C2, Cg = C / 32;
+  const int n = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  const int o = t % nOct, r = t / nOct;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const int c0 = o * 8;
+  gn_finalize_stats(fwd, n, nchunks, HW, Cg, eps, s_mean, s_rstd);
+  __syncthreads();
+  const f16* src;
+  int cs;
+  if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; cs = C1; } else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
+  const f16* gsrc = dy + ((size_t)n * HW) * C + c0;
+  float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int g = (c0 + i) / Cg;
+    mu[i] = s_mean[g]; rs[i] = s_rstd[g]; ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
+    s1[i] = 0.f; s2[i] = 0.f;
+  }
+  for (int p = p0 + r; p < p1; p += R) {
+    float xv[8], gv[8];
+    lr_unpack8(*reinterpret_cast<const uint4*>(src + (size_t)p * cs), xv);
+    lr_unpack8(*reinterpret_cast<const uint4*>(gsrc + (size_t)p * C), gv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (xv[i] - mu[i]) * rs[i];
+      const float z = fmaf(xh, ga[i], be[i]);
+      const float g = gv[i] * gn_act_grad(z, silu) * ga[i];
+      s1[i] += g;
+      s2[i] = fmaf(g, xh, s2[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s_part[((size_t)r * C + c0 + i) * 2 + 0] = s1[i];
+    s_part[((size_t)r * C + c0 + i) * 2 + 1] = s2[i];
+  }
+  __syncthreads();
+  if (t < 32) {
+    float a = 0.f, b = 0.f;
+    for (int c = t * Cg; c < (t + 1) * Cg; ++c)
+      for (int rr = 0; rr < R; ++rr) { a += s_part[((size_t)rr * C + c) * 2]; b += s_part[((size_t)rr * C + c) * 2 + 1]; }
+    float* dst = out + (((size_t)n * nchunks + chunk) * 32 + t) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+__global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+                                    const f16* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ bwd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int silu,
+                                    f16* __restrict__ dx1, f16* __restrict__ dx2, int pix_per_block, int nOct, int R,
+                                    int nchunks) {
+  __shared__ float s_mean[32], s_rstd[32], s_c1[32], s_c2[32];
+  const int C = C1 + C2, Cg = C / 32;
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int o = t % nOct, r = t / nOct;
+  const int c0 = o * 8;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+  gn_finalize_stats(fwd, n, nchunks, HW, Cg, eps, s_mean, s_rstd);
+  __syncthreads();
+  if (t < 128) {
+    const int g = t >> 2, sub = t & 3;
+    double a = 0.0, b = 0.0;
+    const float* ps = bwd + ((size_t)n * nchunks * 32 + g) * 2;
+    for (int c = sub; c < nchunks; c += 4) { a += (double)ps[c * 64]; b += (double)ps[c * 64 + 1]; }
+#pragma unroll
+    for (int sh = 2; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh, 64); b += __shfl_xor(b, sh, 64); }
+    if (sub == 0) {
+      const double m = (double)HW * (double)Cg;
+      s_c1[g] = (float)(a / m);
+      s_c2[g] = (float)(b / m);
+    }
+  }
+  __syncthreads();
+  if (r >= R) return;
+  const f16* src;
+  f16* dst;
+  int cs;
+  if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; dst = dx1 + ((size_t)n * HW) * C1 + c0; cs = C1; }
+  else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); dst = dx2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
+  const f16* gsrc = dy + ((size_t)n * HW) * C + c0;
+  float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int g = (c0 + i) / Cg;
+    mu[i] = s_mean[g]; rs[i] = s_rstd[g]; ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
+    k1[i] = s_c1[g]; k2[i] = s_c2[g];
+  }
+  for (int p = p0 + r; p < p1; p += R) {
+    float xv[8], gv[8], f[8];
+    lr_unpack8(*reinterpret_cast<const uint4*>(src + (size_t)p * cs), xv);
+    lr_unpack8(*reinterpret_cast<const uint4*>(gsrc + (size_t)p * C), gv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (xv[i] - mu[i]) * rs[i];
+      const float z = fmaf(xh, ga[i], be[i]);
+      const float g = gv[i] * gn_act_grad(z, silu) * ga[i];
+      f[i] = rs[i] * (g - k1[i] - xh * k2[i]);
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)p * cs) = lr_pack8(f);
+  }
+}
+
+extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
+                                const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu,
+                                float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) {
+  if (!x1 || !dy || !fwd_partials || !bwd_partials || !gamma || !beta || !dx1 || N <= 0 || HW <= 0) return LR_E_ARG;
+  if (!x2) C2 = 0;
+  if (C2 && !dx2) return LR_E_ARG;
+  const int C = C1 + C2;
+  if (C % 32 || C1 % 8 || C2 % 8) return LR_E_ALIGN;
+  const int nOct = C / 8;
+  int R = 256 / nOct;
+  if (R < 1) R = 1;
+  const int threads = nOct * R;
+  if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
+  const int nchunks = gn_nchunks(N, HW, C);
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunks, N), dim3(threads), (size_t)R * C * 2 * sizeof(float), st,
+                     (const f16*)x1, C1, (const f16*)x2, C2, HW, (const f16*)dy, fwd_partials, gamma, beta, eps, silu,
+                     bwd_partials, nOct, R, nchunks);
+  int rc = lr_launch_status();
+  if (rc) return rc;
+  long long blocks = ((long long)N * HW * C * 2) >> 18;
+  if (blocks < 512) blocks = 512;
+  int ppb = (int)(((long long)N * HW + blocks - 1) / blocks);
+  if (ppb < 16) ppb = 16;
+  if (ppb > HW) ppb = HW;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, st, (const f16*)x1, C1,
+                     (const f16*)x2, C2, HW, (const f16*)dy, fwd_partials, bwd_partials, gamma, beta, eps, silu, (f16*)dx1,
+                     (f16*)dx2, ppb, nOct, R, nchunks);
+  return lr_launch_status();
+}

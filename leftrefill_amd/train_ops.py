@@ -1,0 +1,196 @@
+"""Differentiable front end of the HIP operators (training with frozen weights: input gradients only).
+
+Same call signatures as `leftrefill_amd.ops`; every function falls straight through to `ops` unless autograd is recording
+and an input requires grad, in which case it runs as a `torch.autograd.Function` whose backward is made of HIP kernels:
+
+  conv / linear    dX = lr_gemm_conv_f16 on flipped, transposed weights (stride 2: zero-insertion gather, `up = 2`;
+                   nearest-up conv: dgrad at the fine resolution + lr_sumpool2x2); GEGLU epilogue: the projection is
+                   recomputed without the epilogue, lr_geglu_bwd, then the same dgrad GEMM
+  GroupNorm(+SiLU) lr_groupnorm_stats (recomputed) + lr_groupnorm_bwd
+  LayerNorm        lr_layernorm_bwd
+  attention        lr_attention_bwd_f16 (flash-style recomputation from the saved log-sum-exp)
+
+torch.autograd only orchestrates (graph, fan-in sums of residual branches, `torch.utils.checkpoint` recomputation like
+the reference's CheckpointFunction, ldm/modules/diffusionmodules/util.py:102-151); weights never receive gradients --
+the optimizer of the reference owns only the prompt tokens (ref_inpainting_ldm.py:86-87), which sit upstream of `context`.
+"""
+import torch
+
+from . import _lib, ops
+from .ops import *  # noqa: F401,F403  (re-export the non-differentiable entry points unchanged)
+from .ops import _p, _stream
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def dgrad_weight(wt, taps, lo, hi):
+    """Packed forward weight [N][taps*Ct] -> input-gradient weight [hi-lo][taps*N]: transposed, taps flipped.
+    Cached ON the weight tensor (its lifetime, invalidated by in-place updates through `_version`)."""
+    cache = wt.__dict__.setdefault("_lr_dgrad", {})
+    key = (wt._version, taps, lo, hi)
+    w = cache.get(key)
+    if w is None:
+        N = wt.shape[0]
+        Ct = wt.shape[1] // taps
+        w3 = wt.detach().reshape(N, taps, Ct)[:, :, lo:hi]
+        w = w3.permute(2, 1, 0).flip(1).reshape(hi - lo, taps * N).contiguous()
+        for k in [k for k in cache if k[0] != wt._version]:
+            del cache[k]
+        cache[key] = w
+    return w
+
+
+class _GemmConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, resid, wt, bias, rowvec, kw):
+        out = ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
+        ctx.kw, ctx.wt, ctx.bias = kw, wt, bias
+        ctx.C1 = x1.shape[-1]
+        ctx.C2 = 0 if x2 is None else x2.shape[-1]
+        ctx.has_resid = resid is not None
+        ctx.save_for_backward(*((x1, x2) if kw.get("geglu") else ()))      # plain conv / linear: dX needs only dY and W
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        kw, wt = ctx.kw, ctx.wt
+        dy = dy.contiguous()
+        B, H, W = kw["B"], kw["H"], kw["W"]
+        Hs, Ws = kw.get("Hs") or H, kw.get("Ws") or W
+        taps, stride, up = kw.get("taps", 1), kw.get("stride", 1), kw.get("up", 0)
+        if kw.get("asym"):
+            raise NotImplementedError("asymmetric-pad stride-2 conv (VAE encoder) has no backward: the VAE is frozen and not differentiated")
+        g = dy
+        if kw.get("geglu"):
+            x1, x2 = ctx.saved_tensors
+            pre = ops.gemm_conv(x1, wt, x2=x2, bias=ctx.bias, B=B, H=H, W=W, taps=taps)          # u | g, packed layout
+            g = geglu_bwd(pre, dy)
+        dxs = []
+        for lo, hi in ((0, ctx.C1), (ctx.C1, ctx.C1 + ctx.C2)):
+            if hi == lo or not ctx.needs_input_grad[0 if lo == 0 else 1]:
+                dxs.append(None)
+                continue
+            wd = dgrad_weight(wt, taps, lo, hi)
+            if taps == 1:
+                dx = ops.gemm_conv(g, wd, B=1, H=1, W=B * H * W, taps=1)
+            elif stride == 2:
+                dx = ops.gemm_conv(g, wd, B=B, H=Hs, W=Ws, Hs=H, Ws=W, taps=9, up=2)
+            elif up:
+                fine = ops.gemm_conv(g, wd, B=B, H=H, W=W, taps=9)
+                dx = sumpool2x2(fine, B, Hs, Ws)
+            else:
+                dx = ops.gemm_conv(g, wd, B=B, H=H, W=W, taps=9)
+            dxs.append(dx)
+        dresid = dy if ctx.has_resid and ctx.needs_input_grad[2] else None
+        return dxs[0], dxs[1], dresid, None, None, None, None
+
+
+def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
+    if not _needs_grad(x1, x2, resid):
+        return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
+    if rowvec is not None and rowvec.requires_grad:
+        raise NotImplementedError("gradient w.r.t. the time embedding is not produced (nothing trainable sits upstream of it)")
+    if kw.get("out") is not None:
+        raise ValueError("out= is not supported while autograd is recording")
+    return _GemmConv.apply(x1, x2, resid, wt, bias, rowvec, kw)
+
+
+def geglu_bwd(pre, dy):
+    lib = _lib.load()
+    M, H = dy.shape
+    assert pre.shape == (M, 2 * H) and pre.is_contiguous() and dy.is_contiguous()
+    dpre = torch.empty_like(pre)
+    _lib.check(lib.lr_geglu_bwd(_p(pre), _p(dy), _p(dpre), M, H, _stream()), "geglu_bwd")
+    return dpre
+
+
+def sumpool2x2(x, N, H, W):
+    """x [N*2H*2W, C] -> [N*H*W, C]: backward of the nearest-2x upsample."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    assert x.shape[0] == N * 4 * H * W and x.is_contiguous()
+    y = torch.empty(N * H * W, C, device=x.device, dtype=torch.float16)
+    _lib.check(lib.lr_sumpool2x2(_p(x), _p(y), N, H, W, C, _stream()), "sumpool2x2")
+    return y
+
+
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, N, HW, eps, silu):
+        lib = _lib.load()
+        C1 = x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        partials = torch.empty(N * ops.GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
+        y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+        st = _stream()
+        _lib.check(lib.lr_groupnorm_stats(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
+        _lib.check(lib.lr_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
+                                          int(bool(silu)), _p(y), st), "groupnorm_apply")
+        ctx.save_for_backward(x1, x2, gamma, beta, partials)
+        ctx.meta = (N, HW, float(eps), int(bool(silu)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x1, x2, gamma, beta, partials = ctx.saved_tensors
+        N, HW, eps, silu = ctx.meta
+        dy = dy.contiguous()
+        C1 = x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        scratch = torch.empty_like(partials)
+        dx1 = torch.empty_like(x1)
+        dx2 = None if x2 is None else torch.empty_like(x2)
+        _lib.check(lib.lr_groupnorm_bwd(_p(x1), C1, _p(x2), C2, _p(dy), N, HW, _p(partials), _p(gamma), _p(beta), eps, silu,
+                                        _p(scratch), _p(dx1), _p(dx2), _stream()), "groupnorm_bwd")
+        return dx1, dx2, None, None, None, None, None, None
+
+
+def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None):
+    if not _needs_grad(x1, x2):
+        return ops.group_norm(x1, N, HW, gamma, beta, eps, silu, x2)
+    return _GroupNorm.apply(x1.contiguous(), None if x2 is None else x2.contiguous(), gamma, beta, N, HW, eps, silu)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y = ops.layer_norm(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        M, C = x.shape
+        _lib.check(lib.lr_layernorm_bwd(_p(x), _p(dy), _p(gamma), ctx.eps, _p(dx), M, C, _stream()), "layernorm_bwd")
+        return dx, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    if not _needs_grad(x):
+        return ops.layer_norm(x, gamma, beta, eps)
+    return _LayerNorm.apply(x.contiguous(), gamma, beta, eps)
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, N, H, W, C, out_dtype):
+        ctx.meta = (y.shape[-1],)
+        return ops.nhwc_to_nchw(y, N, H, W, C, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.nchw_to_nhwc(dout.float().contiguous(), cpad=ctx.meta[0]), None, None, None, None, None
+
+
+def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
+    if not _needs_grad(y):
+        return ops.nhwc_to_nchw(y, N, H, W, C, out_dtype)
+    return _ToNCHW.apply(y, N, H, W, C, out_dtype)

@@ -1,0 +1,140 @@
+"""GPU parity of the backward (input-gradient) kernels against torch.autograd on the fp32 reference formulation of each
+operator (training with frozen weights).  Inputs / weights / upstream gradients are rounded
+to fp16 first so both sides differentiate the same function; the HIP side keeps fp16 activations and gradients with
+fp32 accumulation, so the bound is the north-star rtol 2e-3 / atol 1e-3 scaled by the gradient's magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_spec as G, weights  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def h16(t):
+    return t.half().float()
+
+
+def to_tok(x):       # NCHW fp32 -> token-major fp16 on the device
+    n, c, hh, ww = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * hh * ww, c).half().contiguous().to(dev())
+
+
+def from_tok(t, n, hh, ww):
+    return t.float().cpu().reshape(n, hh, ww, -1).permute(0, 3, 1, 2)
+
+
+def check(name, got, ref, rtol=2e-3, atol_scale=2e-3):
+    got, ref = got.float().cpu(), ref.float()
+    assert torch.isfinite(got).all(), name
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    rel = (err.norm() / ref.norm()).item()
+    print(f"[bwd {name}] rel_l2 {rel:.3e} max_abs {err.max().item():.3e} (|ref| max {scale:.3e})")
+    assert rel < 3e-3, (name, rel)
+    assert (err <= atol_scale * scale + rtol * ref.abs()).all(), name
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (77, 640), (130, 1280)])
+def test_layernorm_backward(M, C):
+    from leftrefill_amd import train_ops as T
+    x = h16(G.T(f"lnb.x{C}", (M, C)))
+    dy = h16(G.T(f"lnb.dy{C}", (M, C)))
+    g = torch.from_numpy(weights.fill_like(f"lnb.{C}.weight", (C,)))
+    b = torch.from_numpy(weights.fill_like(f"lnb.{C}.bias", (C,)))
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), g, b, 1e-5).backward(dy)
+    xd = x.half().to(dev()).requires_grad_(True)
+    y = T.layer_norm(xd, g.to(dev()), b.to(dev()), 1e-5)
+    y.backward(dy.half().to(dev()))
+    check(f"layernorm {M}x{C}", xd.grad, xr.grad)
+
+
+@pytest.mark.parametrize("N,C1,C2,H,W,silu,eps", [(2, 320, 0, 8, 16, True, 1e-5), (1, 640, 320, 16, 8, True, 1e-5),
+                                                   (2, 320, 0, 16, 16, False, 1e-6), (1, 1280, 1280, 8, 8, True, 1e-5)])
+def test_groupnorm_backward(N, C1, C2, H, W, silu, eps):
+    from leftrefill_amd import train_ops as T
+    C = C1 + C2
+    tag = f"gnb.{C1}.{C2}.{H}"
+    x = h16(G.T(tag + ".x", (N, C, H, W)))
+    dy = h16(G.T(tag + ".dy", (N, C, H, W)))
+    g = torch.from_numpy(weights.fill_like(tag + ".weight", (C,)))
+    b = torch.from_numpy(weights.fill_like(tag + ".bias", (C,)))
+    xr = x.clone().requires_grad_(True)
+    y = F.group_norm(xr, 32, g, b, eps)
+    (F.silu(y) if silu else y).backward(dy)
+    x1 = to_tok(x[:, :C1]).requires_grad_(True)
+    x2 = to_tok(x[:, C1:]).requires_grad_(True) if C2 else None
+    out = T.group_norm(x1, N, H * W, g.to(dev()), b.to(dev()), eps, silu, x2)
+    out.backward(to_tok(dy))
+    check(f"groupnorm {tag} dx1", from_tok(x1.grad, N, H, W), xr.grad[:, :C1])
+    if C2:
+        check(f"groupnorm {tag} dx2", from_tok(x2.grad, N, H, W), xr.grad[:, C1:])
+
+
+def _conv_bwd_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, resid=False):
+    from leftrefill_amd import packing, train_ops as T
+    Ct = Cin + C2
+    Hs, Ws = H, W
+    if stride == 2:
+        Hs, Ws = 2 * H, 2 * W
+    if up:
+        Hs, Ws = H // 2, W // 2
+    k = 3 if taps == 9 else 1
+    x = h16(G.T(name + ".x", (N, Ct, Hs, Ws)))
+    w = h16(torch.from_numpy(weights.fill_like(name + ".w", (Cout, Ct, k, k))))
+    b = torch.from_numpy(weights.fill_like(name + ".b", (Cout,)))
+    dy = h16(G.T(name + ".dy", (N, Cout, H, W)))
+    xr = x.clone().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    y = F.conv2d(xin, w, b, stride=stride, padding=1 if taps == 9 else 0)
+    rs = None
+    if resid:
+        rs = h16(G.T(name + ".rs", (N, Cout, H, W))).requires_grad_(True)
+        y = y + rs
+    y.backward(dy)
+    wp = packing.pack_conv(w, cin_pad=Ct).to(dev())
+    bp = packing.pack_bias(b).to(dev())
+    x1 = to_tok(x[:, :Cin]).requires_grad_(True)
+    x2 = to_tok(x[:, Cin:]).requires_grad_(True) if C2 else None
+    rd = to_tok(rs.detach()).requires_grad_(True) if resid else None
+    out = T.gemm_conv(x1, wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, x2=x2, bias=bp, resid=rd)
+    out.backward(to_tok(dy))
+    check(name + " dx1", from_tok(x1.grad, N, Hs, Ws), xr.grad[:, :Cin])
+    if C2:
+        check(name + " dx2", from_tok(x2.grad, N, Hs, Ws), xr.grad[:, Cin:])
+    if resid:
+        assert torch.equal(rd.grad, to_tok(dy))
+
+
+def test_conv_linear_input_gradients():
+    _conv_bwd_case("cb_lin", 1, 320, 640, 10, 30, taps=1)
+    _conv_bwd_case("cb_lin_res", 2, 640, 640, 8, 8, taps=1, resid=True)
+    _conv_bwd_case("cb_c3", 2, 320, 320, 12, 20)
+    _conv_bwd_case("cb_c3_cat", 1, 640, 320, 8, 16, C2=320, resid=True)
+    _conv_bwd_case("cb_c1_cat", 2, 640, 320, 8, 8, taps=1, C2=320)
+    _conv_bwd_case("cb_s2", 2, 320, 320, 6, 10, stride=2)
+    _conv_bwd_case("cb_up", 1, 640, 640, 8, 12, up=1)
+    _conv_bwd_case("cb_out", 2, 320, 64, 8, 16)          # padded output conv (4 -> 64 channels)
+
+
+def test_geglu_backward():
+    from leftrefill_amd import packing, train_ops as T
+    C, M = 320, 200
+    x = h16(G.T("ggb.x", (M, C)))
+    w = h16(torch.from_numpy(weights.fill_like("ggb.w", (8 * C, C))))
+    b = torch.from_numpy(weights.fill_like("ggb.b", (8 * C,)))
+    dy = h16(G.T("ggb.dy", (M, 4 * C)))
+    xr = x.clone().requires_grad_(True)
+    u, gate = F.linear(xr, w, b).chunk(2, dim=-1)
+    (u * F.gelu(gate)).backward(dy)
+    wp, bp = packing.pack_geglu(w, b)
+    xd = x.half().to(dev()).requires_grad_(True)
+    y = T.gemm_conv(xd, wp.to(dev()), B=1, H=1, W=M, taps=1, bias=bp.to(dev()), geglu=True)
+    y.backward(dy.half().to(dev()))
+    check("geglu dx", xd.grad, xr.grad)
