@@ -161,6 +161,23 @@ int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const
 /* GEGLU: pre = projection + bias in the packed [u16 | g16] column layout (lr_gemm_conv_f16 with geglu = 0 on the packed
  * weights), dy [M][H] -> dpre [M][2H] (same layout): du = dy * gelu(g), dg = dy * u * gelu'(g). */
 int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s);
+/* Attention: forward that also saves the log2-domain log-sum-exp (lse [B][heads][Nq] fp32), and the backward that
+ * recomputes P from it (two deterministic kernels: dQ over key tiles; dK, dV over query tiles; plus D = rowsum(dO o O)).
+ * qt / kt / dot are lr_transpose_v_f16 copies of q / k / dout ([B][heads*64][ld], ld = rows rounded up to 64);
+ * dsum: scratch [B][heads][Nq] fp32.  dq [B][Nq][lddq], dk / dv [B][Nkv][lddk | lddv], head h in columns h*64.. like q/k/v. */
+int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
+                         int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+typedef struct lr_attn_bwd_args {
+  const lr_half* q; const lr_half* k; const lr_half* v; const lr_half* o; const lr_half* dout;
+  const lr_half* qt; const lr_half* kt; const lr_half* dot;
+  const float* lse; float* dsum;
+  lr_half* dq; lr_half* dk; lr_half* dv;
+  int32_t ldq, ldk, ldv, ldo, lddo, ld_qt, ld_kt, lddq, lddk, lddv;
+  int32_t B, heads, Nq, Nkv;
+  float scale;
+} lr_attn_bwd_args;
+int lr_attention_bwd_f16(const lr_attn_bwd_args* args, lr_stream_t s);
+
 /* nearest-2x upsample: y[n][h][w][:] = sum of the four fine pixels of x [N][2H][2W][C]. */
 int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
 

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -35,6 +35,13 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class AttnBwdArgs(ctypes.Structure):
+    """struct lr_attn_bwd_args (include/leftrefill_hip.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "o", "dout", "qt", "kt", "dot", "lse", "dsum", "dq", "dk", "dv")] +
+                [(n, ctypes.c_int32) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "ld_qt", "ld_kt", "lddq", "lddk", "lddv",
+                                               "B", "heads", "Nq", "Nkv")] + [("scale", ctypes.c_float)])
+
+
 # symbol -> argtypes; every function returns int
 SIGNATURES = {
     "lr_abi_version": [],
@@ -59,6 +66,9 @@ SIGNATURES = {
                          c_int, c_float, c_void_p],
     "lr_attention_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_float, c_void_p],
+    "lr_attention_lse_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                             c_int, c_float, c_void_p],
+    "lr_attention_bwd_f16": [ctypes.POINTER(AttnBwdArgs), c_void_p],
     "lr_transpose_v_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

@@ -33,6 +33,7 @@ struct AttnParams {
   const f16* q; const f16* k; const f16* v; f16* o;
   int ldq, ldk, ldv, ldo, heads, Nq, Nkv, nqt, nblocks;
   float c;  // scale * log2(e)
+  float* lse;  // optional [B][heads][Nq]: log2-domain log-sum-exp m*c + log2(l) (saved for the backward), or NULL
 };
 
 // VT = true: P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below):
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       lt = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
     }
     const float inv = 1.0f / lt;
+    if (P.lse && hi == 0 && qrow[qb] < P.Nq)
+      P.lse[((size_t)b * P.heads + h) * P.Nq + qrow[qb]] = fmaf(m_run[qb], P.c, __builtin_amdgcn_logf(lt));
     if (qrow[qb] < P.Nq) {
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -286,7 +289,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 }
 
 static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
-                            int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt) {
+                            int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt,
+                            float* lse = nullptr) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nkv <= 0) return LR_E_ARG;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
@@ -298,6 +302,7 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   P.nqt = (Nq + ATT_QB - 1) / ATT_QB;
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
+  P.lse = lse;
   if (vt) hipLaunchKernelGGL(attention_kernel<true>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   else hipLaunchKernelGGL(attention_kernel<false>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
@@ -306,6 +311,13 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
 extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                 lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
   return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false);
+}
+
+extern "C" int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+                                    lr_half* o, int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale,
+                                    lr_stream_t s) {
+  if (!lse) return LR_E_ARG;
+  return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false, lse);
 }
 
 extern "C" int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt,

@@ -19,6 +19,7 @@ import torch
 from . import _lib, ops
 from .ops import *  # noqa: F401,F403  (re-export the non-differentiable entry points unchanged)
 from .ops import _p, _stream
+from ._lib import AttnBwdArgs
 
 
 def _needs_grad(*ts):
@@ -194,3 +195,48 @@ def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
     if not _needs_grad(y):
         return ops.nhwc_to_nchw(y, N, H, W, C, out_dtype)
     return _ToNCHW.apply(y, N, H, W, C, out_dtype)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, B, heads, Nq, Nkv, scale):
+        lib = _lib.load()
+        out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+        lse = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
+        _lib.check(lib.lr_attention_lse_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+                                            out.stride(0), _p(lse), B, heads, Nq, Nkv, float(scale), _stream()),
+                   "attention_lse")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (B, heads, Nq, Nkv, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, out, lse = ctx.saved_tensors
+        B, heads, Nq, Nkv, scale = ctx.meta
+        dout = dout.contiguous()
+        C = heads * 64
+        qt = ops.transpose_v(q, B, heads, Nq)
+        kt = ops.transpose_v(k, B, heads, Nkv)
+        dot = ops.transpose_v(dout, B, heads, Nq)
+        dq = torch.empty(B * Nq, C, device=q.device, dtype=torch.float16)
+        dk = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
+        dv = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
+        dsum = torch.empty_like(lse)
+        a = AttnBwdArgs()
+        a.q, a.k, a.v, a.o, a.dout = _p(q), _p(k), _p(v), _p(out), _p(dout)
+        a.qt, a.kt, a.dot, a.lse, a.dsum = _p(qt), _p(kt), _p(dot), _p(lse), _p(dsum)
+        a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
+        a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
+        a.ld_qt, a.ld_kt = qt.shape[2], kt.shape[2]
+        a.lddq, a.lddk, a.lddv = C, C, C
+        a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
+        _lib.check(lib.lr_attention_bwd_f16(a, _stream()), "attention_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
+    if not _needs_grad(q, k, v):
+        return ops.attention(q, k, v, B, heads, Nq, Nkv, scale, out=out, vt=vt)
+    return _Attention.apply(q, k, v, B, heads, Nq, Nkv, scale)

@@ -138,3 +138,35 @@ def test_geglu_backward():
     y = T.gemm_conv(xd, wp.to(dev()), B=1, H=1, W=M, taps=1, bias=bp.to(dev()), geglu=True)
     y.backward(dy.half().to(dev()))
     check("geglu dx", xd.grad, xr.grad)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 64, 64), (2, 2, 128, 128), (1, 3, 300, 200), (2, 5, 256, 77), (1, 2, 512, 1024)])
+def test_attention_backward(B, heads, Nq, Nkv):
+    """dQ, dK, dV of softmax(q k^T / 8) v per head vs torch.autograd on the fp32 formulation; q / k / v are strided column
+    slices of one fused buffer like in the UNet; the forward output of the lse-saving kernel must equal the plain one."""
+    from leftrefill_amd import ops, train_ops as T
+    d = dev()
+    C = heads * 64
+    tag = f"attb.{Nq}.{Nkv}.{heads}"
+    q = h16(G.T(tag + ".q", (B, Nq, C)))
+    k = h16(G.T(tag + ".k", (B, Nkv, C)))
+    v = h16(G.T(tag + ".v", (B, Nkv, C)))
+    do = h16(G.T(tag + ".do", (B, Nq, C)))
+    qr, kr, vr = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+
+    def split(t_, n):
+        return t_.reshape(B, n, heads, 64).permute(0, 2, 1, 3)
+
+    o_ref = F.scaled_dot_product_attention(split(qr, Nq), split(kr, Nkv), split(vr, Nkv), scale=0.125)
+    o_ref = o_ref.permute(0, 2, 1, 3).reshape(B, Nq, C)
+    o_ref.backward(do)
+    qd = q.reshape(B * Nq, C).half().to(d).requires_grad_(True)
+    kv = torch.cat([k, v], -1).reshape(B * Nkv, 2 * C).half().to(d).requires_grad_(True)
+    o = T.attention(qd, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, 0.125)
+    with torch.no_grad():
+        o_plain = ops.attention(qd.detach(), kv.detach()[:, :C], kv.detach()[:, C:], B, heads, Nq, Nkv, 0.125)
+    assert torch.equal(o.detach(), o_plain)
+    o.backward(do.reshape(B * Nq, C).half().to(d))
+    check(tag + " dq", qd.grad.reshape(B, Nq, C), qr.grad)
+    check(tag + " dk", kv.grad[:, :C].reshape(B, Nkv, C), kr.grad)
+    check(tag + " dv", kv.grad[:, C:].reshape(B, Nkv, C), vr.grad)
