@@ -19,7 +19,8 @@ import torch
 import torch as th
 import torch.nn as nn
 
-from leftrefill_amd import engine, ops
+from leftrefill_amd import engine
+from leftrefill_amd import train_ops as ops     # == leftrefill_amd.ops unless autograd records an input that requires grad
 from ldm.modules.attention import SpatialTransformer
 from ldm.modules.diffusionmodules.util import (checkpoint, conv_nd, linear, normalization, timestep_embedding,
                                                zero_module)
@@ -378,8 +379,12 @@ class UNetModel(nn.Module):
         x = x.float().contiguous()
         timesteps = timesteps.to(torch.int64).contiguous()
         ctx_src = context
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the noisy latent is not produced (p_losses feeds x_noisy without grad)")
         context = context.to(torch.float16).contiguous()
-        if not self.use_hip_graph:
+        if not self.use_hip_graph or (torch.is_grad_enabled() and context.requires_grad):
+            # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
+            # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
         key = (tuple(x.shape), tuple(context.shape), x.device.index)
         g = self._graphs.get(key)

@@ -19,7 +19,8 @@ from typing import Optional
 
 import torch
 
-from . import ops, packing
+from . import packing
+from . import train_ops as ops     # == leftrefill_amd.ops unless autograd is recording and an input requires grad
 
 
 @dataclass
@@ -176,7 +177,7 @@ def resblock(act: Act, pr: PackedRes, emb_out):
 def self_attention(x, pa: PackedAttn, B, L, resid):
     C = x.shape[1]
     qkv = linear(x, pa.qkv)
-    a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, pa.heads, L, L, pa.dim_head ** -0.5)
+    a = ops.attention_qkv(qkv, B, pa.heads, L, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=resid)
 
 
@@ -186,7 +187,7 @@ def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid, kv=None):
     q = linear(x, pa.q)
     if kv is None:
         kv = linear(ctx, pa.kv)
-    a = ops.attention(q, kv[:, :C], kv[:, C:], B, pa.heads, L, Lc, pa.dim_head ** -0.5)
+    a = ops.attention_q_kv(q, kv, B, pa.heads, L, Lc, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=resid)
 
 

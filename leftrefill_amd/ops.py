@@ -234,6 +234,18 @@ def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     return out
 
 
+def attention_qkv(qkv, B, heads, L, scale):
+    """Self-attention on the fused projection qkv [B*L, 3C] (q | k | v column blocks)."""
+    C = heads * 64
+    return attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, heads, L, L, scale)
+
+
+def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale):
+    """Cross-attention: q [B*Nq, C], fused context projection kv [B*Nkv, 2C] (k | v column blocks)."""
+    C = heads * 64
+    return attention(q, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, scale)
+
+
 def softmax_rows(s, scale, out=None):
     """p = softmax(scale * s, dim=-1) for materialised fp16 logits s [M, N] (VAE AttnBlock); in place when out is s."""
     lib = _lib.load()

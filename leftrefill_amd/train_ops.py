@@ -197,46 +197,122 @@ def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
     return _ToNCHW.apply(y, N, H, W, C, out_dtype)
 
 
+def _attention_backward(q, k, v, out, lse, dout, meta, dq, dk, dv):
+    """dq / dk / dv: pre-allocated (possibly strided column-slice) outputs."""
+    lib = _lib.load()
+    B, heads, Nq, Nkv, scale = meta
+    dout = dout.contiguous()
+    qt = ops.transpose_v(q, B, heads, Nq)
+    kt = ops.transpose_v(k, B, heads, Nkv)
+    dot = ops.transpose_v(dout, B, heads, Nq)
+    dsum = torch.empty_like(lse)
+    a = AttnBwdArgs()
+    a.q, a.k, a.v, a.o, a.dout = _p(q), _p(k), _p(v), _p(out), _p(dout)
+    a.qt, a.kt, a.dot, a.lse, a.dsum = _p(qt), _p(kt), _p(dot), _p(lse), _p(dsum)
+    a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
+    a.ld_qt, a.ld_kt = qt.shape[2], kt.shape[2]
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
+    _lib.check(lib.lr_attention_bwd_f16(a, _stream()), "attention_bwd")
+
+
+def _attention_forward(q, k, v, B, heads, Nq, Nkv, scale):
+    lib = _lib.load()
+    out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+    lse = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
+    _lib.check(lib.lr_attention_lse_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                        _p(lse), B, heads, Nq, Nkv, float(scale), _stream()), "attention_lse")
+    return out, lse
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, B, heads, Nq, Nkv, scale):
-        lib = _lib.load()
-        out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
-        lse = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
-        _lib.check(lib.lr_attention_lse_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
-                                            out.stride(0), _p(lse), B, heads, Nq, Nkv, float(scale), _stream()),
-                   "attention_lse")
+        out, lse = _attention_forward(q, k, v, B, heads, Nq, Nkv, scale)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.meta = (B, heads, Nq, Nkv, float(scale))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        lib = _lib.load()
         q, k, v, out, lse = ctx.saved_tensors
-        B, heads, Nq, Nkv, scale = ctx.meta
-        dout = dout.contiguous()
+        B, heads, Nq, Nkv, _ = ctx.meta
         C = heads * 64
-        qt = ops.transpose_v(q, B, heads, Nq)
-        kt = ops.transpose_v(k, B, heads, Nkv)
-        dot = ops.transpose_v(dout, B, heads, Nq)
         dq = torch.empty(B * Nq, C, device=q.device, dtype=torch.float16)
         dk = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
         dv = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
-        dsum = torch.empty_like(lse)
-        a = AttnBwdArgs()
-        a.q, a.k, a.v, a.o, a.dout = _p(q), _p(k), _p(v), _p(out), _p(dout)
-        a.qt, a.kt, a.dot, a.lse, a.dsum = _p(qt), _p(kt), _p(dot), _p(lse), _p(dsum)
-        a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
-        a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
-        a.ld_qt, a.ld_kt = qt.shape[2], kt.shape[2]
-        a.lddq, a.lddk, a.lddv = C, C, C
-        a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
-        _lib.check(lib.lr_attention_bwd_f16(a, _stream()), "attention_bwd")
+        _attention_backward(q, k, v, out, lse, dout, ctx.meta, dq, dk, dv)
         return dq, dk, dv, None, None, None, None, None
+
+
+class _AttentionQKV(torch.autograd.Function):
+    """Self-attention on the fused [q | k | v] projection: the three gradients land in ONE [M, 3C] buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, heads, L, scale):
+        C = heads * 64
+        out, lse = _attention_forward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, heads, L, L, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (B, heads, L, L, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        C = ctx.meta[1] * 64
+        d = torch.empty_like(qkv)
+        _attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, lse, dout, ctx.meta, d[:, :C], d[:, C:2 * C],
+                            d[:, 2 * C:])
+        return d, None, None, None, None
+
+
+class _AttentionQ_KV(torch.autograd.Function):
+    """Cross-attention: q plus the fused [k | v] context projection."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, heads, Nq, Nkv, scale):
+        C = heads * 64
+        out, lse = _attention_forward(q, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, scale)
+        ctx.save_for_backward(q, kv, out, lse)
+        ctx.meta = (B, heads, Nq, Nkv, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        C = ctx.meta[1] * 64
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _attention_backward(q, kv[:, :C], kv[:, C:], out, lse, dout, ctx.meta, dq, dkv[:, :C], dkv[:, C:])
+        return dq, dkv, None, None, None, None, None
 
 
 def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     if not _needs_grad(q, k, v):
         return ops.attention(q, k, v, B, heads, Nq, Nkv, scale, out=out, vt=vt)
     return _Attention.apply(q, k, v, B, heads, Nq, Nkv, scale)
+
+
+def attention_qkv(qkv, B, heads, L, scale):
+    if not _needs_grad(qkv):
+        return ops.attention_qkv(qkv, B, heads, L, scale)
+    return _AttentionQKV.apply(qkv.contiguous(), B, heads, L, scale)
+
+
+def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale):
+    if not _needs_grad(q, kv):
+        return ops.attention_q_kv(q, kv, B, heads, Nq, Nkv, scale)
+    return _AttentionQ_KV.apply(q.contiguous(), kv.contiguous(), B, heads, Nq, Nkv, scale)
+
+
+def mv_gather(x, b, v, s):
+    if _needs_grad(x):
+        raise NotImplementedError("the multi-view token re-arrangement has no backward yet")
+    return ops.mv_gather(x, b, v, s)
+
+
+def mv_scatter(seq, b, v, s):
+    if _needs_grad(seq):
+        raise NotImplementedError("the multi-view token re-arrangement has no backward yet")
+    return ops.mv_scatter(seq, b, v, s)
