@@ -2,7 +2,7 @@
 
 Keeps the reference's class names, constructor kwargs and attributes that the sampler / callers read
 (reference ldm/models/diffusion/ddpm.py: DDPM 46-535, LatentDiffusion 538-1324, DiffusionWrapper 1327-1371,
-LatentFinetuneDiffusion 1512-1651, LatentInpaintDiffusion 1654-1701), minus the PyTorch-Lightning training loop,
+LatentFinetuneDiffusion 1512-1651, LatentInpaintDiffusion 1654-1701), minus the PyTorch-Lightning trainer hooks,
 EMA, logging and the unused upscale/depth variants (out of scope).
 
 On the hot path only `apply_model` -> `DiffusionWrapper.forward` ('hybrid': channel-concat of the noisy latent with
@@ -75,8 +75,17 @@ class DDPM(nn.Module):
         self.model = DiffusionWrapper(unet_config, conditioning_key)
         self.use_ema = False  # every LeftRefill config sets use_ema: False
         self.v_posterior = v_posterior
+        self.original_elbo_weight = original_elbo_weight
+        self.l_simple_weight = l_simple_weight
+        self.loss_type = loss_type
+        self.learn_logvar = learn_logvar
         self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
                                linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        logvar = torch.full(fill_value=float(logvar_init), size=(self.num_timesteps,))     # reference 129-134
+        if learn_logvar:
+            self.logvar = nn.Parameter(logvar, requires_grad=True)
+        else:
+            self.register_buffer('logvar', logvar)
 
     @property
     def device(self):
@@ -98,6 +107,28 @@ class DDPM(nn.Module):
                           ("sqrt_recip_alphas_cumprod", np.sqrt(1. / ac)),
                           ("sqrt_recipm1_alphas_cumprod", np.sqrt(1. / ac - 1))):
             self.register_buffer(name, f32(val))
+        # variational-bound weights of the training loss (reference 176-203), eps-parameterisation
+        alphas = 1. - betas
+        post_var = (1 - self.v_posterior) * betas * (1. - ac_prev) / (1. - ac) + self.v_posterior * betas
+        self.register_buffer("posterior_variance", f32(post_var))
+        if self.parameterization == "eps":
+            lvlb = self.betas ** 2 / (2 * self.posterior_variance * f32(alphas) * (1 - self.alphas_cumprod))
+        elif self.parameterization == "x0":
+            lvlb = 0.5 * torch.sqrt(f32(ac)) / (2. * 1 - f32(ac))
+        else:
+            lvlb = torch.ones_like(self.betas)
+        lvlb[0] = lvlb[1]
+        self.register_buffer("lvlb_weights", lvlb, persistent=False)
+
+    def get_loss(self, pred, target, mean=True):
+        """reference 378-391 (under the reference's autocast the fp16 prediction is promoted to fp32 here)"""
+        pred = pred.to(target.dtype)
+        if self.loss_type == 'l1':
+            loss = (target - pred).abs()
+            return loss.mean() if mean else loss
+        if self.loss_type == 'l2':
+            return torch.nn.functional.mse_loss(target, pred, reduction='mean' if mean else 'none')
+        raise NotImplementedError(f"unknown loss type '{self.loss_type}'")
 
     def q_sample(self, x_start, t, noise=None):
         noise = default(noise, lambda: torch.randn_like(x_start))
@@ -218,6 +249,40 @@ class LatentDiffusion(DDPM):
         if isinstance(out, tuple) and not return_ids:
             return out[0]
         return out
+
+
+    # ---- training objective (reference 854-863, 900-935); the UNet backward runs on the HIP kernels (train_ops) ----------
+    def forward(self, x, c, *args, **kwargs):
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
+        assert self.model.conditioning_key is None or c is not None
+        return self.p_losses(x, c, t, *args, **kwargs)
+
+    def p_losses(self, x_start, cond, t, noise=None):
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        model_output = self.apply_model(x_noisy, t, cond)
+        prefix = 'train' if self.training else 'val'
+        if self.parameterization == "x0":
+            target = x_start
+        elif self.parameterization == "eps":
+            target = noise
+        else:
+            raise NotImplementedError("v-parameterisation is not used by LeftRefill")
+        loss_dict = {}
+        loss_simple = self.get_loss(model_output, target, mean=False).mean([1, 2, 3])
+        loss_dict[f'{prefix}/loss_simple'] = loss_simple.mean()
+        logvar_t = self.logvar[t].to(self.device)
+        loss = loss_simple / torch.exp(logvar_t) + logvar_t
+        if self.learn_logvar:
+            loss_dict[f'{prefix}/loss_gamma'] = loss.mean()
+            loss_dict['logvar'] = self.logvar.data.mean()
+        loss = self.l_simple_weight * loss.mean()
+        loss_vlb = self.get_loss(model_output, target, mean=False).mean(dim=(1, 2, 3))
+        loss_vlb = (self.lvlb_weights[t] * loss_vlb).mean()
+        loss_dict[f'{prefix}/loss_vlb'] = loss_vlb
+        loss = loss + self.original_elbo_weight * loss_vlb
+        loss_dict[f'{prefix}/loss'] = loss
+        return loss, loss_dict
 
 
 class LatentFinetuneDiffusion(LatentDiffusion):

@@ -146,3 +146,17 @@ def ddim_multi_sample(apply_unet, S, x_Ts, c_concats, c_crosses, uc_crosses, sca
             new[k][..., half:] = right
         imgs = new
     return imgs[0]
+
+
+def p_losses(apply_unet, x_start, c_concat, c_cross, t, noise, ac=None):
+    """LatentDiffusion.p_losses (ddpm.py:900-935) for the eps-parameterised hybrid inpainting model with the shipped
+    settings (l2 loss, logvar = 0 buffer, l_simple_weight 1, original_elbo_weight 0): q_sample -> UNet -> MSE.
+
+    apply_unet(xc [B,9,h,w], t, ctx) -> eps (any float dtype).  Returns (loss, loss_simple, x_noisy); differentiable
+    w.r.t. c_cross when apply_unet is (test infrastructure: the checker for the HIP backward)."""
+    ac = torch.from_numpy(alphas_cumprod() if ac is None else ac).float()
+    shape = (-1, 1, 1, 1)
+    x_noisy = ac.sqrt()[t].reshape(shape) * x_start + (1.0 - ac).sqrt()[t].reshape(shape) * noise      # ddpm.py:370-373
+    eps = apply_unet(torch.cat([x_noisy, c_concat], dim=1), t, c_cross).float()
+    loss_simple = torch.nn.functional.mse_loss(noise, eps, reduction="none").mean([1, 2, 3])
+    return loss_simple.mean(), loss_simple, x_noisy

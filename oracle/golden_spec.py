@@ -178,5 +178,6 @@ def mv_config(view_num, concat_target):
 STEP_CASES = [("step_eta0", 50, 0.0, 17), ("step_eta1", 50, 1.0, 49), ("step_eta1_last", 10, 1.0, 0)]  # (case,S,eta,index)
 TRAJ_CASES = [("traj_s10", 10, 0.0, 1, 8, 16), ("traj_s50", 50, 0.0, 1, 8, 16), ("traj_s10_eta1_b2", 10, 1.0, 2, 8, 16)]
 MULTI_CASES = [("multi_k3_s10", 10, 1.0, 1, 8, 16, 3, 1234)]   # (case, S, eta, B, h, w, K conditionings, random.seed)
+TRAIN_CASES = [("train_b2", 2, 16, 32, [501, 21])]   # (case, B, h, w, timesteps): p_losses + backward to the context
 CFG_SCALE = 2.5
 TRAJ_CONFIG = "MID"

@@ -253,6 +253,44 @@ def gen_sampler_multi(ns):
     np.savez_compressed(os.path.join(OUT, "sampler_multi.npz"), **out)
 
 
+def gen_train(ns):
+    """Training objective + backward of the REAL reference on CPU (ddpm.py:900-935 p_losses through apply_model, the hybrid
+    DiffusionWrapper and the reference UNet with its CheckpointFunction): loss, loss_dict and d loss / d context."""
+    import types
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    ucfg = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": cfg.kwargs()}
+    wrapper = ns.ddpm.DiffusionWrapper(ucfg, "hybrid")
+    _load(wrapper.diffusion_model, G.unet_state(G.TRAJ_CONFIG))
+    # NB the reference leaves the UNet parameters requiring grad (only the optimizer ignores them); its
+    # CheckpointFunction.backward differentiates w.r.t. them and fails if they are frozen (util.py:133-151)
+    out = {}
+    for case, B, h, w, ts in G.TRAIN_CASES:
+        fake = _FakeLDM(ns, wrapper=wrapper)
+        fake.register_buffer = lambda name, val, persistent=True, _f=fake: setattr(_f, name, val)
+        fake.v_posterior = 0.
+        ns.ddpm.DDPM.register_schedule(fake, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.0120)
+        fake.loss_type, fake.learn_logvar, fake.logvar = "l2", False, torch.zeros(1000)
+        fake.l_simple_weight, fake.original_elbo_weight, fake.training = 1., 0., True
+        fake.q_sample = types.MethodType(ns.ddpm.DDPM.q_sample, fake)
+        fake.get_loss = types.MethodType(ns.ddpm.DDPM.get_loss, fake)
+        x_start = G.T(case + ".x_start", (B, 4, h, w))
+        noise = G.T(case + ".noise", (B, 4, h, w))
+        c_concat = G.T(case + ".c_concat", (B, 5, h, w))
+        c_cross = G.T(case + ".c_cross", (B, 77, cfg.context_dim)).requires_grad_(True)
+        t = torch.tensor(ts, dtype=torch.long)
+        with torch.enable_grad():
+            loss, ld = ns.ddpm.LatentDiffusion.p_losses(fake, x_start, {"c_concat": [c_concat], "c_crossattn": [c_cross]}, t,
+                                                        noise=noise)
+            loss.backward()
+        out[case + ".loss"] = loss.detach().numpy()
+        out[case + ".loss_simple"] = ld["train/loss_simple"].detach().numpy()
+        out[case + ".loss_vlb"] = ld["train/loss_vlb"].detach().numpy()
+        out[case + ".x_noisy"] = ns.ddpm.DDPM.q_sample(fake, x_start, t, noise).numpy()
+        out[case + ".dctx"] = c_cross.grad.numpy()
+        print(f"  train {case}: loss {float(loss):.6f} |dctx| max {c_cross.grad.abs().max():.3e}")
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+
+
 VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
                     num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 
@@ -308,12 +346,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ns = ref_import.import_reference()
-    todo = [a.only] if a.only else ["ops", "sampler", "sampler_multi", "mv", "vae", "vae_hip", "unet"]
+    todo = [a.only] if a.only else ["ops", "sampler", "sampler_multi", "train", "mv", "vae", "vae_hip", "unet"]
     for what in todo:
         print(f"[{what}]")
         t0 = time.time()
         {"ops": gen_ops, "unet": lambda n: gen_unet(n, a.skip_full), "mv": gen_mv, "sampler": gen_sampler,
-         "sampler_multi": gen_sampler_multi, "vae": gen_vae, "vae_hip": gen_vae_hip}[what](ns)
+         "sampler_multi": gen_sampler_multi, "train": gen_train, "vae": gen_vae, "vae_hip": gen_vae_hip}[what](ns)
         print(f"[{what}] done in {time.time() - t0:.1f}s")
 
 

@@ -213,3 +213,40 @@ def test_unet_context_gradient_matches_oracle_autograd():
     cd2 = ctx.to(dev()).requires_grad_(True)
     m(x.to(dev()), t.to(dev()), context=cd2).float().backward(deps.to(dev()))
     assert torch.equal(cd2.grad, cd.grad)
+
+
+@pytest.mark.parametrize("case,B,h,w,ts", G.TRAIN_CASES, ids=[c[0] for c in G.TRAIN_CASES])
+def test_training_step_vs_reference_golden(golden, case, B, h, w, ts):
+    """RefInpaintLDM.p_losses on the HIP path (q_sample -> apply_model -> UNet -> MSE) and its backward to the context,
+    against the loss / gradient the REAL reference produced on CPU (tests/golden/train.npz).  fp16 gradients need the
+    loss scaling the reference's `--fp16` trainer applies (Lightning native AMP): the loss is scaled by 2^14 here."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
+    g = golden("train")
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    m = RefInpaintLDM(first_stage_config={"target": "torch.nn.Identity"}, cond_stage_config={"target": "torch.nn.Identity"},
+                      unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": cfg.kwargs()},
+                      conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
+                      timesteps=1000, channels=4, data_config={"img_size": 256})
+    m.model.diffusion_model.load_state_dict(G.unet_state(G.TRAJ_CONFIG), strict=True)
+    m = m.to(dev()).train()
+    for p in m.parameters():
+        p.requires_grad_(False)          # frozen backbone: result-identical to the reference, whose optimizer never steps them
+    x_start = G.T(case + ".x_start", (B, 4, h, w)).to(dev())
+    noise = G.T(case + ".noise", (B, 4, h, w)).to(dev())
+    c_concat = G.T(case + ".c_concat", (B, 5, h, w)).to(dev())
+    c_cross = G.T(case + ".c_cross", (B, 77, cfg.context_dim)).to(dev()).requires_grad_(True)
+    t = torch.tensor(ts, dtype=torch.long, device=dev())
+    loss, ld = m.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [c_cross]}, t, noise=noise)
+    scale = 2.0 ** 14
+    (loss * scale).backward()
+    grad = c_cross.grad.float().cpu() / scale
+    ref = torch.from_numpy(g[case + ".dctx"])
+    rel = ((grad - ref).norm() / ref.norm()).item()
+    print(f"[bwd train {case}] loss {loss.item():.6f} (reference {float(g[case + '.loss']):.6f}); d/dcontext rel_l2 {rel:.3e}, "
+          f"|grad| max {ref.abs().max().item():.3e}")
+    assert set(ld) == {"train/loss_simple", "train/loss_vlb", "train/loss"}
+    assert abs(loss.item() - float(g[case + ".loss"])) <= 2e-3 * float(g[case + ".loss"])
+    assert abs(ld["train/loss_vlb"].item() - float(g[case + ".loss_vlb"])) <= 3e-3 * abs(float(g[case + ".loss_vlb"]))
+    assert torch.isfinite(grad).all() and rel <= 1e-2

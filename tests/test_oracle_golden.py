@@ -116,6 +116,29 @@ def test_ddim_multi_condition_trajectory(golden, case, S, eta, B, h, w, K, seed)
     assert np.abs(out.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("case,B,h,w,ts", G.TRAIN_CASES, ids=[c[0] for c in G.TRAIN_CASES])
+def test_training_loss_and_context_gradient(golden, case, B, h, w, ts):
+    """p_losses + backward of the real reference (through its CheckpointFunction) vs autograd on the restatement: pins the
+    checker that tests/test_gpu_backward.py holds the HIP backward kernels against."""
+    g = golden("train")
+    cfg = G.CONFIGS[G.TRAJ_CONFIG]
+    sd = G.unet_state(G.TRAJ_CONFIG)
+    x_start = G.T(case + ".x_start", (B, 4, h, w))
+    noise = G.T(case + ".noise", (B, 4, h, w))
+    c_concat = G.T(case + ".c_concat", (B, 5, h, w))
+    c_cross = G.T(case + ".c_cross", (B, 77, cfg.context_dim)).requires_grad_(True)
+    t = torch.tensor(ts, dtype=torch.long)
+    with torch.enable_grad():
+        loss, loss_simple, x_noisy = ddim_ref.p_losses(
+            lambda xc, tt, ctx: unet_ref.unet_forward.__wrapped__(sd, cfg, xc, tt, ctx), x_start, c_concat, c_cross, t, noise)
+        loss.backward()
+    np.testing.assert_allclose(x_noisy.numpy(), g[case + ".x_noisy"], atol=1e-6)
+    np.testing.assert_allclose(loss.item(), g[case + ".loss"], rtol=1e-5)
+    np.testing.assert_allclose(loss_simple.mean().item(), g[case + ".loss_simple"], rtol=1e-5)
+    ref = g[case + ".dctx"]
+    assert np.abs(c_cross.grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("case,V,concat,b,H,W", G.MV_CASES, ids=[c[0] for c in G.MV_CASES])
 def test_multiview_unet(golden, case, V, concat, b, H, W):
     cfg = G.mv_config(V, concat)
