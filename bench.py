@@ -221,6 +221,78 @@ def vae_timing(B, device):
     return out
 
 
+def train_bench(a, rank, world, device):
+    """`--workload train` (not the metric; SURVEY 8f-2 / BASELINE configs[4]): one optimisation step of the prompt tokens
+    through the frozen UNet at canvas 256x512 (latent 32x64), per-GPU batch 16: p_losses forward + HIP backward to the
+    context + AdamW on the tokens (stand-in for `special_embeddings`, 73 x 1024), loss scale 2^14, data-parallel
+    all-reduce of the token gradient over RCCL when world > 1."""
+    import torch.distributed as dist
+    Bt, h, w = 16, 32, 64
+    model = build_model(device, "single").train()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device=device).manual_seed(99 + rank)
+    tokens = torch.nn.Parameter(0.02 * torch.randn(73, 1024, device=device, generator=g))
+    opt = torch.optim.AdamW([tokens], lr=1e-4)
+    base_ctx = torch.randn(Bt, 77, 1024, device=device, generator=g)
+    c_concat = torch.randn(Bt, 5, h, w, device=device, generator=g)
+    x_start = torch.randn(Bt, 4, h, w, device=device, generator=g)
+    scale = 2.0 ** 14
+
+    def step():
+        ctx = torch.cat([base_ctx[:, :1], base_ctx[:, 1:74] + tokens, base_ctx[:, 74:]], dim=1)
+        t = torch.randint(0, 1000, (Bt,), device=device, generator=g)
+        noise = torch.randn(Bt, 4, h, w, device=device, generator=g)
+        loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t, noise=noise)
+        (loss * scale).backward()
+        if world > 1:
+            dist.all_reduce(tokens.grad)
+            tokens.grad /= world
+        tokens.grad /= scale
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, a.warmup)):
+        loss = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(loss)
+    with torch.no_grad():      # forward alone, same shapes (eager, like the training forward)
+        unet = model.model.diffusion_model
+        unet.use_hip_graph = False
+        xin = torch.cat([x_start, c_concat], 1)
+        tt_ = torch.full((Bt,), 501, device=device, dtype=torch.long)
+        unet(xin, tt_, base_ctx.half())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            unet(xin, tt_, base_ctx.half())
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / 3 * 1e3
+    return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * a.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[4]-like: canvas 256x512 (latent 32x64), per-GPU batch 16, fp16 + loss scale 2^14, "
+                                   "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
+                       "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
+            "forward_only_ms": fwd_ms, "final_loss": float(loss)}
+
+
 def cpu_baseline():
     """Oracle (fp32 torch CPU restatement) on a bounded sample: ONE CFG UNet step (N=2) at latent 64x128."""
     from oracle import unet_ref
@@ -255,8 +327,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="user batch B per GPU (UNet batch 2B under CFG)")
-    ap.add_argument("--workload", default="single", choices=["single", "mv5", "mv4"],
-                    help="single = configs[1] (the metric); mv5 / mv4 = multi-view config 4 on one GPU (not the metric)")
+    ap.add_argument("--workload", default="single", choices=["single", "mv5", "mv4", "train"],
+                    help="single = configs[1] (the metric); mv5 / mv4 = multi-view config 4 on one GPU; train = training step "
+                         "(configs[4]-like) -- neither is the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
@@ -281,6 +354,14 @@ def main():
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
+    if a.workload == "train":
+        res = train_bench(a, rank, world, device)
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     B, h, w = a.batch, 64, 128
     samples_per_step = B
     if a.workload != "single":      # B counts canvases from here on; one sample = (view_num - 1 | view_num) canvases
