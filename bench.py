@@ -227,6 +227,7 @@ def train_bench(a, rank, world, device):
     context + AdamW on the tokens (stand-in for `special_embeddings`, 73 x 1024), loss scale 2^14, data-parallel
     all-reduce of the token gradient over RCCL when world > 1."""
     import torch.distributed as dist
+    from leftrefill_amd import dist as lrd
     Bt, h, w = 16, 32, 64
     model = build_model(device, "single").train()
     for p in model.parameters():
@@ -245,9 +246,7 @@ def train_bench(a, rank, world, device):
         noise = torch.randn(Bt, 4, h, w, device=device, generator=g)
         loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t, noise=noise)
         (loss * scale).backward()
-        if world > 1:
-            dist.all_reduce(tokens.grad)
-            tokens.grad /= world
+        lrd.allreduce_mean_grads([tokens])
         tokens.grad /= scale
         opt.step()
         opt.zero_grad(set_to_none=True)

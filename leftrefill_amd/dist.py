@@ -100,3 +100,20 @@ def mv_canvas_from_own(y, s):
     b, _, C = y.shape
     t, r = y[:, :s * s].reshape(b, s, s, C), y[:, s * s:].reshape(b, s, s, C)
     return torch.cat([r, t], dim=2).reshape(b, 2 * s * s, C)
+
+
+def allreduce_mean_grads(params):
+    """Data-parallel training with a frozen backbone: only the prompt-token parameters carry gradients (the reference's DDP
+    reduces every UNet / CLIP gradient although its optimizer owns just `special_embeddings`).  One flat
+    all-reduce (RCCL over xGMI on GPUs) of the few trainable gradients, averaged like DDP."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].reshape(g.shape).to(g.dtype))
+        off += n

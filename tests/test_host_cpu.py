@@ -51,6 +51,26 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lr_gemm_args), offsetof(l
     assert [int(v) for v in out] == got
 
 
+def test_attn_bwd_args_struct_layout_matches_header():
+    import subprocess, tempfile
+    from leftrefill_amd._lib import AttnBwdArgs
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "leftrefill_hip.h"
+int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lr_attn_bwd_args), offsetof(lr_attn_bwd_args, qt),
+  offsetof(lr_attn_bwd_args, dq), offsetof(lr_attn_bwd_args, ldq), offsetof(lr_attn_bwd_args, B), offsetof(lr_attn_bwd_args, scale)); }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")],
+                       check=True)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
+    got = [ctypes.sizeof(AttnBwdArgs), AttnBwdArgs.qt.offset, AttnBwdArgs.dq.offset, AttnBwdArgs.ldq.offset,
+           AttnBwdArgs.B.offset, AttnBwdArgs.scale.offset]
+    assert [int(v) for v in out] == got
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from leftrefill_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
@@ -219,6 +239,40 @@ def test_sample_sharding_gloo_world2():
     for p in procs:
         p.join(60)
     assert res[0] == (0, True, (0, 3)) and res[1] == (1, True, (3, 5))
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from leftrefill_amd import dist as lrd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = torch.nn.Parameter(torch.zeros(73, 8))
+    b = torch.nn.Parameter(torch.zeros(5))
+    c = torch.nn.Parameter(torch.zeros(3))          # no gradient: skipped
+    a.grad = torch.full((73, 8), float(rank + 1))
+    b.grad = torch.arange(5.) * (rank + 1)
+    lrd.allreduce_mean_grads([a, b, c])
+    q.put((rank, bool(torch.all(a.grad == 1.5)), bool(torch.equal(b.grad, torch.arange(5.) * 1.5)), c.grad is None))
+    dist.destroy_process_group()
+
+
+def test_training_gradient_allreduce_gloo_world2():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, True, True), (1, True, True, True)]
 
 
 def test_shard_range_partitions():
