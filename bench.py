@@ -221,7 +221,7 @@ def vae_timing(B, device):
     return out
 
 
-def train_bench(a, rank, world, device):
+def train_bench(a, rank, world, device, model=None, steps=None):
     """`--workload train` (not the metric; SURVEY 8f-2 / BASELINE configs[4]): one optimisation step of the prompt tokens
     through the frozen UNet at canvas 256x512 (latent 32x64), per-GPU batch 16: p_losses forward + HIP backward to the
     context + AdamW on the tokens (stand-in for `special_embeddings`, 73 x 1024), loss scale 2^14, data-parallel
@@ -229,7 +229,8 @@ def train_bench(a, rank, world, device):
     import torch.distributed as dist
     from leftrefill_amd import dist as lrd
     Bt, h, w = 16, 32, 64
-    model = build_model(device, "single").train()
+    steps = steps or a.steps
+    model = (model or build_model(device, "single")).train()
     for p in model.parameters():
         p.requires_grad_(False)
     g = torch.Generator(device=device).manual_seed(99 + rank)
@@ -262,7 +263,7 @@ def train_bench(a, rank, world, device):
         loss = step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
@@ -271,6 +272,7 @@ def train_bench(a, rank, world, device):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(loss)
+    model.eval()
     with torch.no_grad():      # forward alone, same shapes (eager, like the training forward)
         unet = model.model.diffusion_model
         unet.use_hip_graph = False
@@ -283,8 +285,8 @@ def train_bench(a, rank, world, device):
             unet(xin, tt_, base_ctx.half())
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / 3 * 1e3
-    return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * a.steps / dt,
-            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+    return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "configs[4]-like: canvas 256x512 (latent 32x64), per-GPU batch 16, fp16 + loss scale 2^14, "
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
@@ -432,6 +434,9 @@ def main():
     if rank == 0 and not a.no_roofline and a.workload == "single":
         res["unet_step_events"] = unet_step_events(model, batch, B)
         res["vae_512x1024"] = vae_timing(B, device)
+        if world == 1:      # next row 8f-2, reported beside the metric: one training step of the prompt tokens (see train_bench)
+            tr = train_bench(a, rank, world, device, model=model, steps=3)
+            res["training_256x512_b16"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -250,3 +250,28 @@ def test_training_step_vs_reference_golden(golden, case, B, h, w, ts):
     assert abs(loss.item() - float(g[case + ".loss"])) <= 2e-3 * float(g[case + ".loss"])
     assert abs(ld["train/loss_vlb"].item() - float(g[case + ".loss_vlb"])) <= 3e-3 * abs(float(g[case + ".loss_vlb"]))
     assert torch.isfinite(grad).all() and rel <= 1e-2
+
+
+def test_unet_full_width_context_gradient():
+    """The shipped 866 M-parameter width (latent 16x32, N=2): d loss / d context on the HIP path vs torch.autograd on the CPU
+    oracle (pinned to the reference at this width by goldens G4)."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from oracle import unet_ref
+    cfg = G.CONFIGS["FULL"]
+    sd = G.unet_state("FULL")
+    m = UNetModel(**cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev()).eval()
+    N, H, W = 2, 16, 32
+    x, t, ctx = G.unet_inputs("bwd_full", cfg, N, H, W, [981, 1])
+    deps = h16(G.T("bwd_full.deps", (N, 4, H, W)))
+    c = ctx.clone().requires_grad_(True)
+    unet_ref.unet_forward.__wrapped__(sd, cfg, x, t, c).backward(deps)
+    cd = ctx.to(dev()).requires_grad_(True)
+    m(x.to(dev()), t.to(dev()), context=cd).float().backward(deps.to(dev()))
+    g, g_ref = cd.grad.float().cpu(), c.grad
+    rel = ((g - g_ref).norm() / g_ref.norm()).item()
+    print(f"[bwd unet FULL] d/dcontext rel_l2 {rel:.3e}, |grad| max {g_ref.abs().max().item():.3e}")
+    assert torch.isfinite(g).all() and rel <= 1e-2
