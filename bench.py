@@ -272,6 +272,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(loss)
+    peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
     model.eval()
     with torch.no_grad():      # forward alone, same shapes (eager, like the training forward)
         unet = model.model.diffusion_model
@@ -291,7 +292,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
             "config": {"workload": "configs[4]-like: canvas 256x512 (latent 32x64), per-GPU batch 16, fp16 + loss scale 2^14, "
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
-            "forward_only_ms": fwd_ms, "final_loss": float(loss)}
+            "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb}
 
 
 def cpu_baseline():
@@ -436,7 +437,7 @@ def main():
         res["vae_512x1024"] = vae_timing(B, device)
         if world == 1:      # next row 8f-2, reported beside the metric: one training step of the prompt tokens (see train_bench)
             tr = train_bench(a, rank, world, device, model=model, steps=3)
-            res["training_256x512_b16"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss")}
+            res["training_256x512_b16"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -178,6 +178,10 @@ typedef struct lr_attn_bwd_args {
 } lr_attn_bwd_args;
 int lr_attention_bwd_f16(const lr_attn_bwd_args* args, lr_stream_t s);
 
+/* multi-view re-arrangement: gradient of lr_mv_gather (dseq -> dx: canvases other than 0 get zero in their right half) and
+ * of lr_mv_scatter (dx -> dseq: the target slot sums the right halves of all canvases). */
+int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st);
+int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
 /* nearest-2x upsample: y[n][h][w][:] = sum of the four fine pixels of x [N][2H][2W][C]. */
 int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
 

@@ -117,6 +117,8 @@ __global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const 
 // Multi-view token re-arrangement, concat_target=True (multiview_attention.py:440-446 / 456-460).
 // canvases x [b*v][s rows][2s cols][C]; sequence seq [b][(v+1)][s][s][C] = [target(from canvas 0), ref_0..ref_{v-1}].
 // ---------------------------------------------------------------------------------------------------------------
+// SUM = true is the backward of mv_scatter: the target slot collects the right halves of ALL canvases (fp32 sum).
+template <bool SUM>
 __global__ void mv_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ seq, int b, int v, int s, int C8,
                                  long long total) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -129,10 +131,23 @@ __global__ void mv_gather_kernel(const uint4* __restrict__ x, uint4* __restrict_
     const long long bi = q / (v + 1);
     const int canvas = j == 0 ? 0 : j - 1;
     const int scol = j == 0 ? s + col : col;
-    seq[idx] = x[((((size_t)bi * v + canvas) * s + row) * (2 * s) + scol) * C8 + c];
+    if (SUM && j == 0) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int cv = 0; cv < v; ++cv) {
+        float f[8];
+        lr_unpack8(x[((((size_t)bi * v + cv) * s + row) * (2 * s) + scol) * C8 + c], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += f[i];
+      }
+      seq[idx] = lr_pack8(acc);
+    } else {
+      seq[idx] = x[((((size_t)bi * v + canvas) * s + row) * (2 * s) + scol) * C8 + c];
+    }
   }
 }
 
+// ZERO = true is the backward of mv_gather: only canvas 0 contributed its right half, the others receive zero there.
+template <bool ZERO>
 __global__ void mv_scatter_kernel(const uint4* __restrict__ seq, uint4* __restrict__ x, int b, int v, int s, int C8,
                                   long long total) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -145,7 +160,8 @@ __global__ void mv_scatter_kernel(const uint4* __restrict__ seq, uint4* __restri
     const long long bi = q / v;
     const int j = col >= s ? 0 : canvas + 1;
     const int scol = col >= s ? col - s : col;
-    x[idx] = seq[((((size_t)bi * (v + 1) + j) * s + row) * s + scol) * C8 + c];
+    if (ZERO && col >= s && canvas != 0) x[idx] = make_uint4(0, 0, 0, 0);
+    else x[idx] = seq[((((size_t)bi * (v + 1) + j) * s + row) * s + scol) * C8 + c];
   }
 }
 
@@ -186,7 +202,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 7; }
+extern "C" int lr_abi_version(void) { return 8; }
 
 extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
                                        int H, int W, lr_stream_t s) {
@@ -244,7 +260,7 @@ extern "C" int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s,
   if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * (v + 1) * s * s * (C / 8);
-  hipLaunchKernelGGL(mv_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)x,
+  hipLaunchKernelGGL(mv_gather_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)x,
                      (uint4*)seq, b, v, s, C / 8, total);
   return lr_launch_status();
 }
@@ -253,7 +269,7 @@ extern "C" int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s
   if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * v * s * 2 * s * (C / 8);
-  hipLaunchKernelGGL(mv_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)seq,
+  hipLaunchKernelGGL(mv_scatter_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)seq,
                      (uint4*)x, b, v, s, C / 8, total);
   return lr_launch_status();
 }
@@ -353,5 +369,24 @@ extern "C" int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, 
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)x, (f16*)y, total, H, W, C);
+  return lr_launch_status();
+}
+
+// Backward of the multi-view re-arrangement (same shapes as lr_mv_gather / lr_mv_scatter, roles of x and seq swapped)
+extern "C" int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) {
+  if (!dx || !dseq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
+  if (C % 8) return LR_E_ALIGN;
+  const long long total = (long long)b * v * s * 2 * s * (C / 8);
+  hipLaunchKernelGGL(mv_scatter_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)dseq,
+                     (uint4*)dx, b, v, s, C / 8, total);
+  return lr_launch_status();
+}
+
+extern "C" int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) {
+  if (!dx || !dseq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
+  if (C % 8) return LR_E_ALIGN;
+  const long long total = (long long)b * (v + 1) * s * s * (C / 8);
+  hipLaunchKernelGGL(mv_gather_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)dx,
+                     (uint4*)dseq, b, v, s, C / 8, total);
   return lr_launch_status();
 }

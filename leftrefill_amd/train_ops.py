@@ -306,13 +306,43 @@ def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale):
     return _AttentionQ_KV.apply(q.contiguous(), kv.contiguous(), B, heads, Nq, Nkv, scale)
 
 
+class _MvGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, v, s):
+        ctx.meta = (b, v, s)
+        return ops.mv_gather(x, b, v, s)
+
+    @staticmethod
+    def backward(ctx, dseq):
+        lib = _lib.load()
+        b, v, s = ctx.meta
+        dseq = dseq.contiguous()
+        C = dseq.shape[-1]
+        dx = torch.empty(b * v * s * 2 * s, C, device=dseq.device, dtype=torch.float16)
+        _lib.check(lib.lr_mv_gather_bwd(_p(dseq), _p(dx), b, v, s, C, _stream()), "mv_gather_bwd")
+        return dx, None, None, None
+
+
+class _MvScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seq, b, v, s):
+        ctx.meta = (b, v, s)
+        return ops.mv_scatter(seq, b, v, s)
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        b, v, s = ctx.meta
+        dx = dx.contiguous()
+        C = dx.shape[-1]
+        dseq = torch.empty(b * (v + 1) * s * s, C, device=dx.device, dtype=torch.float16)
+        _lib.check(lib.lr_mv_scatter_bwd(_p(dx), _p(dseq), b, v, s, C, _stream()), "mv_scatter_bwd")
+        return dseq, None, None, None
+
+
 def mv_gather(x, b, v, s):
-    if _needs_grad(x):
-        raise NotImplementedError("the multi-view token re-arrangement has no backward yet")
-    return ops.mv_gather(x, b, v, s)
+    return _MvGather.apply(x, b, v, s) if _needs_grad(x) else ops.mv_gather(x, b, v, s)
 
 
 def mv_scatter(seq, b, v, s):
-    if _needs_grad(seq):
-        raise NotImplementedError("the multi-view token re-arrangement has no backward yet")
-    return ops.mv_scatter(seq, b, v, s)
+    return _MvScatter.apply(seq, b, v, s) if _needs_grad(seq) else ops.mv_scatter(seq, b, v, s)

@@ -275,3 +275,29 @@ def test_unet_full_width_context_gradient():
     rel = ((g - g_ref).norm() / g_ref.norm()).item()
     print(f"[bwd unet FULL] d/dcontext rel_l2 {rel:.3e}, |grad| max {g_ref.abs().max().item():.3e}")
     assert torch.isfinite(g).all() and rel <= 1e-2
+
+
+@pytest.mark.parametrize("V,concat,b,H,W", [(3, True, 1, 8, 16), (2, False, 2, 8, 8)], ids=["v3_concat_target", "v2_plain"])
+def test_multiview_unet_context_gradient(V, concat, b, H, W):
+    """Multi-view UNet (re-arranged cross-view self-attention): d loss / d context incl. the gather / scatter backward
+    (the shared target slot sums the gradients of every canvas' right half) vs torch.autograd on the CPU oracle."""
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from ldm.modules.diffusionmodules.multiview_unet import MultiViewUnetModel
+    from oracle import unet_ref
+    cfg = G.mv_config(V, concat)
+    sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV.")
+    m = MultiViewUnetModel(**cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev()).eval()
+    n = b * (V - 1 if concat else V)
+    x, t, ctx = G.unet_inputs(f"bwd_mv{V}", cfg, n, H, W, [501] * n)
+    deps = h16(G.T(f"bwd_mv{V}.deps", (n, 4, H, W)))
+    c = ctx.clone().requires_grad_(True)
+    unet_ref.unet_forward.__wrapped__(sd, cfg, x, t, c).backward(deps)
+    cd = ctx.to(dev()).requires_grad_(True)
+    m(x.to(dev()), t.to(dev()), context=cd).float().backward(deps.to(dev()))
+    g, g_ref = cd.grad.float().cpu(), c.grad
+    rel = ((g - g_ref).norm() / g_ref.norm()).item()
+    print(f"[bwd unet MV V={V} concat={concat}] d/dcontext rel_l2 {rel:.3e}, |grad| max {g_ref.abs().max().item():.3e}")
+    assert torch.isfinite(g).all() and rel <= 1e-2
