@@ -435,6 +435,9 @@ def main():
     if rank == 0 and not a.no_roofline and a.workload == "single":
         res["unet_step_events"] = unet_step_events(model, batch, B)
         res["vae_512x1024"] = vae_timing(B, device)
+        v = res["vae_512x1024"]
+        # caller view (log_images): 2 VAE encodes (image, masked image) + sampling + 1 decode per batch; never `value`
+        res["end_to_end_images_per_s_incl_vae"] = B / (ms_per_step + 2 * v["encode"]["ms"] + v["decode"]["ms"]) * 1e3
         if world == 1:      # next row 8f-2, reported beside the metric: one training step of the prompt tokens (see train_bench)
             tr = train_bench(a, rank, world, device, model=model, steps=3)
             res["training_256x512_b16"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
