@@ -231,6 +231,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     Bt, h, w = 16, 32, 64
     steps = steps or a.steps
     model = (model or build_model(device, "single")).train()
+    model.model.diffusion_model.recompute_in_backward = bool(getattr(a, "recompute", False))
     for p in model.parameters():
         p.requires_grad_(False)
     g = torch.Generator(device=device).manual_seed(99 + rank)
@@ -292,7 +293,8 @@ def train_bench(a, rank, world, device, model=None, steps=None):
             "config": {"workload": "configs[4]-like: canvas 256x512 (latent 32x64), per-GPU batch 16, fp16 + loss scale 2^14, "
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
-            "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb}
+            "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb,
+            "recompute_in_backward": bool(getattr(a, "recompute", False))}
 
 
 def cpu_baseline():
@@ -334,6 +336,7 @@ def main():
                          "(configs[4]-like) -- neither is the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--recompute", action="store_true", help="train workload: recompute blocks in the backward (use_checkpoint)")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
     a = ap.parse_args()
 

@@ -213,6 +213,12 @@ def test_unet_context_gradient_matches_oracle_autograd():
     cd2 = ctx.to(dev()).requires_grad_(True)
     m(x.to(dev()), t.to(dev()), context=cd2).float().backward(deps.to(dev()))
     assert torch.equal(cd2.grad, cd.grad)
+    # the reference's activation checkpointing (use_checkpoint: recompute every block in the backward) gives the same bits
+    m.recompute_in_backward = True
+    cd3 = ctx.to(dev()).requires_grad_(True)
+    m(x.to(dev()), t.to(dev()), context=cd3).float().backward(deps.to(dev()))
+    m.recompute_in_backward = False
+    assert torch.equal(cd3.grad, cd.grad)
 
 
 @pytest.mark.parametrize("case,B,h,w,ts", G.TRAIN_CASES, ids=[c[0] for c in G.TRAIN_CASES])
