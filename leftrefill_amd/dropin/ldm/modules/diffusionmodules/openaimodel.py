@@ -22,9 +22,7 @@ import torch.nn as nn
 from leftrefill_amd import engine
 from leftrefill_amd import train_ops as ops     # == leftrefill_amd.ops unless autograd records an input that requires grad
 from ldm.modules.attention import SpatialTransformer
-from ldm.modules.diffusionmodules.util import (checkpoint, conv_nd, linear, normalization, timestep_embedding,
-                                               zero_module)
-from ldm.util import exists
+from ldm.modules.diffusionmodules.util import conv_nd, linear, normalization, zero_module
 
 
 class TimestepBlock(nn.Module):

@@ -21,8 +21,8 @@ fp16 tensors; it is only used to size the fp16
 tolerance of the HIP path, never as ground truth.
 """
 import math
-from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from dataclasses import dataclass
+from typing import Sequence
 
 import torch
 import torch.nn.functional as F

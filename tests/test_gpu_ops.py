@@ -4,7 +4,6 @@ Tolerance (north star): fp16 outputs within rtol 2e-3 / atol 1e-3 of the fp32 re
 fp16-rounded inputs and weights; composite operators (several fp16 round trips inside) get a proportionally
 scaled absolute term, stated per test.
 """
-import math
 
 import numpy as np
 import pytest
