@@ -140,7 +140,8 @@ def test_geglu_backward():
     check("geglu dx", xd.grad, xr.grad)
 
 
-@pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 64, 64), (2, 2, 128, 128), (1, 3, 300, 200), (2, 5, 256, 77), (1, 2, 512, 1024)])
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 64, 64), (2, 2, 128, 128), (1, 3, 300, 200), (2, 5, 256, 77), (1, 2, 512, 1024),
+                                            (1, 2, 2048, 2048)])
 def test_attention_backward(B, heads, Nq, Nkv):
     """dQ, dK, dV of softmax(q k^T / 8) v per head vs torch.autograd on the fp32 formulation; q / k / v are strided column
     slices of one fused buffer like in the UNet; the forward output of the lse-saving kernel must equal the plain one."""
@@ -307,3 +308,24 @@ def test_multiview_unet_context_gradient(V, concat, b, H, W):
     rel = ((g - g_ref).norm() / g_ref.norm()).item()
     print(f"[bwd unet MV V={V} concat={concat}] d/dcontext rel_l2 {rel:.3e}, |grad| max {g_ref.abs().max().item():.3e}")
     assert torch.isfinite(g).all() and rel <= 1e-2
+
+
+def test_attention_backward_with_late_score_spike():
+    """A key that matches one query strongly late in the sequence: the forward's deferred running-max rescale and the saved
+    log-sum-exp must still give exact probabilities in the backward."""
+    from leftrefill_amd import train_ops as T
+    d = dev()
+    N = 512
+    q = h16(G.T("attbs.q", (1, N, 64)))
+    k = h16(G.T("attbs.k", (1, N, 64)))
+    v = h16(G.T("attbs.v", (1, N, 64)))
+    do = h16(G.T("attbs.do", (1, N, 64)))
+    k[0, 450] = q[0, 7] * 6.0
+    k[0, 70] = q[0, 300] * 4.0
+    qr, kr, vr = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+    F.scaled_dot_product_attention(qr[:, None], kr[:, None], vr[:, None], scale=0.125)[:, 0].backward(do)
+    qd, kd, vd = (t_.reshape(N, 64).half().to(d).requires_grad_(True) for t_ in (q, k, v))
+    T.attention(qd, kd, vd, 1, 1, N, N, 0.125).backward(do.reshape(N, 64).half().to(d))
+    check("spike dq", qd.grad.reshape(1, N, 64), qr.grad)
+    check("spike dk", kd.grad.reshape(1, N, 64), kr.grad)
+    check("spike dv", vd.grad.reshape(1, N, 64), vr.grad)
