@@ -242,15 +242,47 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     x_start = torch.randn(Bt, 4, h, w, device=device, generator=g)
     scale = 2.0 ** 14
 
-    def step():
+    t_buf = torch.zeros(Bt, device=device, dtype=torch.long)
+    noise_buf = torch.zeros(Bt, 4, h, w, device=device)
+
+    def draw():
+        t_buf.copy_(torch.randint(0, 1000, (Bt,), device=device, generator=g))
+        noise_buf.copy_(torch.randn(Bt, 4, h, w, device=device, generator=g))
+
+    def body():
         ctx = torch.cat([base_ctx[:, :1], base_ctx[:, 1:74] + tokens, base_ctx[:, 74:]], dim=1)
-        t = torch.randint(0, 1000, (Bt,), device=device, generator=g)
-        noise = torch.randn(Bt, 4, h, w, device=device, generator=g)
-        loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t, noise=noise)
+        loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t_buf, noise=noise_buf)
         (loss * scale).backward()
         lrd.allreduce_mean_grads([tokens])
         tokens.grad /= scale
         opt.step()
+        return loss
+
+    graph = None
+    if getattr(a, "train_graph", False):
+        # whole step (forward, HIP backward, token all-reduce, AdamW) captured into ONE hipGraph; t / noise are refreshed
+        # in place before every replay
+        opt = torch.optim.AdamW([tokens], lr=1e-4, capturable=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                draw()
+                opt.zero_grad(set_to_none=True)
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = body()
+
+    def step():
+        draw()
+        if graph is not None:
+            graph.replay()
+            return static_loss
+        loss = body()
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -294,7 +326,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
             "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb,
-            "recompute_in_backward": bool(getattr(a, "recompute", False))}
+            "recompute_in_backward": bool(getattr(a, "recompute", False)), "hip_graph": graph is not None}
 
 
 def cpu_baseline():
@@ -336,6 +368,7 @@ def main():
                          "(configs[4]-like) -- neither is the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train-graph", action="store_true", help="train workload: capture the whole step into one hipGraph")
     ap.add_argument("--recompute", action="store_true", help="train workload: recompute blocks in the backward (use_checkpoint)")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
     a = ap.parse_args()
