@@ -76,6 +76,12 @@ def mv_all_gather_canvases(x_local):
     world = mv_group_size()
     if world == 1:
         return x_local[:, None]
+    if x_local.is_cuda and dist.get_backend() == "gloo":
+        # test transport only (ranks sharing one GPU, tests/test_gpu_unet.py): gloo has no device all_gather -> stage on host
+        host = x_local.detach().cpu().contiguous()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        return torch.stack(bufs, dim=1).to(x_local.device)
     bufs = [torch.empty_like(x_local) for _ in range(world)]
     dist.all_gather(bufs, x_local.contiguous())
     return torch.stack(bufs, dim=1)

@@ -219,3 +219,59 @@ def test_full_size_properties_config2():
     rel = ((halves.float() - y.float()).norm() / y.float().norm()).item()
     print(f"[full size 64x128 N=8] |y| max {y.abs().max().item():.3f}; halves vs joint rel_l2 {rel:.3e}")
     assert rel < 4e-3
+
+
+def _mv_shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        install()
+        from ldm.modules.diffusionmodules.multiview_unet import MultiViewUnetModel
+        V, b, H, W = world + 1, 1, 8, 16
+        cfg = G.mv_config(V, True)
+        sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV.")
+        m = MultiViewUnetModel(**cfg.kwargs())
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev()).eval()
+        m.mv_shard = True
+        x, t, ctx = G.unet_inputs("mv_shard2", cfg, b * world, H, W, [501] * (b * world))
+        sl = slice(rank, rank + 1)                     # this rank's canvas [ref_rank | target]
+        with torch.no_grad():
+            y = m(x[sl].to(dev()), t[sl].to(dev()), ctx[sl].to(dev()))
+        q.put((rank, y.float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multiview_canvas_sharded_two_ranks_on_one_gpu():
+    """One canvas per rank (world = view_num - 1 = 2; both ranks share cuda:0 and exchange over gloo because a 1-GPU box has
+    no second RCCL peer): every transformer block all-gathers the canvases, builds K/V for [target, ref_0, ref_1] and
+    attends only for its own rows.  Each rank's canvas must match the CPU oracle of the joint multi-view UNet."""
+    import socket
+    import torch.multiprocessing as mp
+    world, H, W = 2, 8, 16
+    V = world + 1
+    cfg = G.mv_config(V, True)
+    sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV.")
+    x, t, ctx = G.unet_inputs("mv_shard2", cfg, world, H, W, [501] * world)
+    ref = unet_ref.unet_forward(sd, cfg, x, t, ctx)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_mv_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+    for r in range(world):
+        out = torch.from_numpy(res[r])
+        rel = ((out - ref[r:r + 1]).norm() / ref[r:r + 1].norm()).item()
+        print(f"[mv sharded 2 ranks] rank {r}: rel_l2 {rel:.3e}")
+        assert rel < 4e-3
