@@ -1,0 +1,46 @@
+"""bench.py contract (driver-facing): one JSON line on stdout with the required keys, at N=1 and through the multi-rank
+code path (two ranks sharing the single GPU over gloo via the LR_BENCH_SHARE_GPU test hook)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_bench_single_gpu_json_contract():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = lines[0]
+    assert REQUIRED <= set(r) and r["n_gpus"] == 1 and r["steps"] == 1 and r["unit"] == "images/s"
+    assert r["config"]["workload"].startswith("configs[1]") and r["dtype"] == "f16" and r["vs_baseline"] is None
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert r["value"] > 1.0 and abs(r["ms_per_step"] / 50 - r["per_unet_step_ms"]) < 1e-6
+    assert {"unet_step_events", "vae_512x1024", "training_256x512_b16", "kernels"} <= set(r)
+
+
+def test_bench_two_ranks_share_gpu():
+    env = dict(os.environ, LR_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--no-roofline", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-2000:]      # rank 0 only
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
