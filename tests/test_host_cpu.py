@@ -275,6 +275,29 @@ def test_training_gradient_allreduce_gloo_world2():
     assert res == [(0, True, True, True), (1, True, True, True)]
 
 
+def test_eval_glue_paste_crop_psnr():
+    """test_inpainting.py:143-158: paste known pixels, keep the target half, area down-sampling, per-image PSNR."""
+    from leftrefill_amd import evalglue
+    g = torch.Generator().manual_seed(0)
+    N, H, W = 2, 16, 32
+    out = {"pred": torch.rand(N, 3, H, W, generator=g) * 2 - 1, "origin_image": torch.rand(N, 3, H, W, generator=g) * 2 - 1}
+    mask = (torch.rand(N, H, W, 1, generator=g) < 0.4).float()
+    pred, origin = evalglue.compose_prediction(out, mask, test_size=16, metric_size=8)
+    m = mask.permute(0, 3, 1, 2)
+    full = out["pred"] * m + out["origin_image"] * (1 - m)
+    assert torch.equal(full[..., W // 2:].reshape(N, 3, 8, 2, 8, 2).mean((3, 5)), pred)       # area == 2x2 mean here
+    assert torch.equal(out["origin_image"][..., W // 2:].reshape(N, 3, 8, 2, 8, 2).mean((3, 5)), origin)
+    assert torch.equal((full == out["origin_image"]) | (m > 0).expand_as(full), torch.ones_like(full, dtype=torch.bool))
+    same, _ = evalglue.compose_prediction(out, mask, test_size=16, metric_size=16)
+    assert same.shape == (N, 3, 16, 16) and torch.equal(same, full[..., W // 2:])
+    ps = evalglue.psnr01(pred, origin)
+    ref = [10 * np.log10(1.0 / (((pred[i] - origin[i]) / 2) ** 2).mean().item()) for i in range(N)]
+    np.testing.assert_allclose(ps.numpy(), ref, rtol=1e-5)
+    sq, _ = evalglue.compose_prediction({"pred": out["pred"][..., :H], "origin_image": out["origin_image"][..., :H]},
+                                        mask[:, :, :H])
+    assert sq.shape == (N, 3, H, H)          # square inputs are not cropped
+
+
 def test_shard_range_partitions():
     from leftrefill_amd.dist import shard_range
     for total in (1, 4, 7, 32):

@@ -73,6 +73,7 @@ def main():
     import leftrefill_amd.dropin as dropin
     dropin.install()
     from inpainting_ldm.model import create_model, load_state_dict
+    from leftrefill_amd import evalglue
 
     model = create_model(os.path.join(a.model_path, "model_config.yaml")).cpu()
     ckpts = sorted(glob.glob(os.path.join(a.model_path, "ckpts", "epoch=*.ckpt")), key=os.path.getmtime)
@@ -89,18 +90,9 @@ def main():
         for bi, batch in enumerate(batches):
             batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
             out = model.log_images(batch, batch["image"].shape[0], unconditional_guidance_scale=a.cfg, ddim_eta=a.eta)
-            mask = batch["mask"].permute(0, 3, 1, 2)
-            pred = out["pred"].float() * mask + out["origin_image"] * (1 - mask)
-            origin = out["origin_image"]
-            if pred.shape[2] != pred.shape[3]:
-                w = pred.shape[3]
-                pred, origin = pred[..., w // 2:], origin[..., w // 2:]
-            if a.metric_size != pred.shape[-1]:
-                pred = torch.nn.functional.interpolate(pred, size=(a.metric_size, a.metric_size), mode="area")
-                origin = torch.nn.functional.interpolate(origin, size=(a.metric_size, a.metric_size), mode="area")
-            p01, o01 = (pred.clamp(-1, 1) + 1) / 2, (origin.clamp(-1, 1) + 1) / 2
-            mse = ((p01 - o01) ** 2).flatten(1).mean(1)
-            psnrs.extend((10 * torch.log10(1.0 / mse.clamp_min(1e-10))).tolist())
+            pred, origin = evalglue.compose_prediction(out, batch["mask"], a.test_size, a.metric_size)
+            psnrs.extend(evalglue.psnr01(pred, origin).tolist())
+            p01 = (pred.float().clamp(-1, 1) + 1) / 2
             try:
                 from PIL import Image
                 for j in range(p01.shape[0]):
