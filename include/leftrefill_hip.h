@@ -78,8 +78,9 @@ int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, const float* 
  *   rows m = (b*H + y)*W + x over the OUTPUT grid; A gathers from the source grid [Hs][Ws]:
  *     taps = 1: pointwise (Linear / 1x1);  taps = 9: 3x3 pad 1 with `stride` (1|2) and optional nearest-2x `up`sample.
  *   Source is the virtual channel concat [p1 (C1) | p2 (C2)];  C1, C2 multiples of 64.
- *   geglu != 0: Wt/bias rows are pre-interleaved in 16-row groups [u16 | g16 | ...]; output has N/2 columns:
+ *   geglu == 1: Wt/bias rows are pre-interleaved in 16-row groups [u16 | g16 | ...]; output has N/2 columns:
  *     out = (u + bu) * gelu_erf(g + bg).
+ *   geglu == 2: plain erf-GELU of (acc + bias [+ rowvec]) before the residual (the text tower's MLP, nn.GELU).
  */
 typedef struct lr_gemm_args {
   const lr_half* p1; int32_t C1;
@@ -115,6 +116,10 @@ int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
 int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                      int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 
+/* Causal self-attention (query i sees keys j <= i): the OpenCLIP text tower of the prompt encoder
+ * (ldm/modules/encoders/Refill_modules.py:189-201, model.attn_mask), N = 77 tokens, heads of 64. */
+int lr_attention_causal_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
+                            int ldo, int B, int heads, int N, float scale, lr_stream_t s);
 /* Same attention with V supplied pre-transposed: vt [B][heads*64][ld_vt] from lr_transpose_v_f16 (ld_vt = Nkv rounded up
  * to 64, tail keys zero, keys permuted inside every group of 16 to the MFMA k-slot order).  The V tile then streams into
  * LDS by DMA like K; worth it for long key sequences (self-attention), the transpose costs one read + write of V. */

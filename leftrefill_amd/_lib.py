@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -68,6 +68,8 @@ SIGNATURES = {
                          c_int, c_float, c_void_p],
     "lr_attention_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_float, c_void_p],
+    "lr_attention_causal_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                c_void_p],
     "lr_attention_lse_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_float, c_void_p],
     "lr_attention_bwd_f16": [ctypes.POINTER(AttnBwdArgs), c_void_p],

@@ -39,7 +39,8 @@ struct AttnParams {
 // VT = true: P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below):
 // the V tile then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment
 // is ONE ds_read_b128.
-template <bool VT>
+// CAUSAL = true: key j is visible to query i only if j <= i (the text tower's attn_mask); every tile takes the masked path.
+template <bool VT, bool CAUSAL = false>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams P) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KB * 128 + 2 * 64 * VT_PITCH];
   char* Ksm = smem;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   // One K/V tile.  TAIL is a compile-time tag: only a partial last tile carries the key-index compares of the -inf mask
   // (left in the common path they cost ~70 VALU instructions per tile -- the compiler hoists them above the branch).
   auto process_tile = [&](int tile, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value || CAUSAL;
     const int cur = tile & 1;
     const bool more = tile + 1 < ntiles;
     uint4 nv0 = make_uint4(0, 0, 0, 0), nv1 = nv0;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = tile * ATT_KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= P.Nkv) sacc[qb][kb][r] = -INFINITY;
+            if (key >= P.Nkv || (CAUSAL && key > qrow[qb])) sacc[qb][kb][r] = -INFINITY;
           }
       }
       // ---- online softmax, one query per lane (partner lane ^ 32 holds the other half of the keys).  The running max
@@ -311,6 +312,23 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
 extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                 lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
   return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false);
+}
+
+extern "C" int lr_attention_causal_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+                                       lr_half* o, int ldo, int B, int heads, int N, float scale, lr_stream_t s) {
+  if (!q || !k || !v || !o || B <= 0 || heads <= 0 || N <= 0) return LR_E_ARG;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
+  AttnParams P;
+  P.q = (const f16*)q; P.k = (const f16*)k; P.v = (const f16*)v; P.o = (f16*)o;
+  P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
+  P.heads = heads; P.Nq = N; P.Nkv = N;
+  P.nqt = (N + ATT_QB - 1) / ATT_QB;
+  P.nblocks = P.nqt * heads * B;
+  P.c = scale * 1.44269504088896340736f;
+  P.lse = nullptr;
+  hipLaunchKernelGGL((attention_kernel<false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  return lr_launch_status();
 }
 
 extern "C" int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,

@@ -24,7 +24,7 @@
 
 struct GemmParams {
   const f16* p1; const f16* p2; const f16* wt; const float* bias; const f16* rowvec; const f16* resid; f16* out;
-  int C1, C2, H, W, Hs, Ws, taps, stride, up, pad, zins, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, rows_per_batch;
+  int C1, C2, H, W, Hs, Ws, taps, stride, up, pad, zins, N, M, K, ld_rowvec, ld_resid, ld_out, geglu, gelu, rows_per_batch;
   int ntiles_n, nblocks;
   int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
   int ntiles_m, m_fastest; // tile order inside an XCD's contiguous chunk (see tile_order())
@@ -259,6 +259,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
         lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      if (P.gelu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
       }
       if (P.resid) {
         float e[8];
@@ -567,6 +571,10 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += e[i];
       }
+      if (P.gelu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
+      }
       if (P.resid) {
         float e[8];
         lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
@@ -625,6 +633,10 @@ __global__ void splitk_reduce_kernel(const GemmParams P) {
       lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += e[i];
+    }
+    if (P.gelu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
     }
     if (P.resid) {
       float e[8];
@@ -732,7 +744,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.rowvec = (const f16*)a->rowvec; P.ld_rowvec = a->ld_rowvec;
   P.resid = (const f16*)a->resid; P.ld_resid = a->ld_resid;
   P.out = (f16*)a->out; P.ld_out = a->ld_out;
-  P.geglu = a->geglu ? 1 : 0;
+  if (a->geglu < 0 || a->geglu > 2) return LR_E_ARG;
+  P.geglu = a->geglu == 1 ? 1 : 0;
+  P.gelu = a->geglu == 2 ? 1 : 0;      // plain erf-GELU of (acc + bias [+ rowvec]), applied before the residual
   P.rows_per_batch = a->H * a->W;
   const int N_out = P.geglu ? P.N / 2 : P.N;
   if (P.N % 8 || N_out % 8 || P.ld_out % 8 || (P.resid && P.ld_resid % 8) || (P.rowvec && P.ld_rowvec % 8))

@@ -1,9 +1,12 @@
 """`ldm.modules.encoders.Refill_modules.PromptCLIPEmbedder` (reference Refill_modules.py:91-204).
 
-Host-side prompt-token glue: OpenCLIP ViT-H/14 text tower (penultimate layer) with the 50 learned `<special-token>`
-embeddings spliced into the token embeddings.  It runs once per batch, its output [B, 77, 1024] is an INPUT of the hot
-path, and it needs the third-party `open_clip` package plus its pretrained weights -- neither exists in this image, so
-the class is a thin, import-gated implementation that cannot be exercised here ("next" row 3 of SURVEY.md section 8f).
+Prompt-token glue: OpenCLIP ViT-H/14 text tower (penultimate layer) with the 50 learned `<special-token>` embeddings
+spliced into the token embeddings.  It runs once per batch and its output [B, 77, 1024] is an INPUT of the hot path.
+Tokenizer, pretrained weights and the module definitions come from the third-party `open_clip` package, which is not in
+this image: the class is import-gated.  With it installed, the transformer part (positional embedding, residual attention
+blocks under the causal mask, ln_final) runs on the HIP kernels for CUDA inference (leftrefill_amd/text_engine.py: causal
+attention + GELU-epilogue GEMMs, checked against a PyTorch module of the published architecture, tests/test_gpu_text.py);
+when autograd is recording (training of the special tokens) the PyTorch modules run so that torch.autograd applies.
 """
 import torch
 import torch.nn as nn
@@ -11,6 +14,7 @@ import torch.nn as nn
 
 class PromptCLIPEmbedder(nn.Module):
     LAYERS = ["last", "penultimate"]
+    use_hip = True
 
     def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True,
                  layer="last", special_tokens=None, init_text=None, tokenwise_init=False, deep_prompt=False,
@@ -53,6 +57,12 @@ class PromptCLIPEmbedder(nn.Module):
         x = self.model.token_embedding(tokens.clamp(max=self.vocab_size - 1))
         if is_special.any():
             x = torch.where(is_special[..., None], self.special_embeddings((tokens - self.vocab_size).clamp(min=0)), x)
+        if x.is_cuda and self.use_hip and not (torch.is_grad_enabled() and x.requires_grad):
+            from leftrefill_amd import text_engine
+            sig = tuple((p_.data_ptr(), p_._version) for p_ in self.model.parameters())
+            if getattr(self, "_lr_tower", None) is None or self._lr_tower[0] != sig:
+                self._lr_tower = (sig, text_engine.PackedTextTower(self.model, self.layer_idx))
+            return text_engine.encode_with_transformer(x, self._lr_tower[1])
         x = x + self.model.positional_embedding
         x = x.permute(1, 0, 2)
         blocks = self.model.transformer.resblocks

@@ -112,7 +112,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, out=None, tile_n=0, tile_m=0, splits=0):
+              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
     lib = _lib.load()
     _chk16(x1, "x1")
@@ -144,14 +144,15 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     if resid is not None:
         assert resid.shape[0] == M and resid.dtype == torch.float16
     a.out, a.ld_out = _p(out), out.stride(0)
-    a.geglu = int(geglu)
+    assert not (geglu and gelu)
+    a.geglu = 2 if gelu else int(geglu)      # 1: fused GEGLU, 2: plain erf-GELU epilogue
     a.tile_n = tile_n
     a.tile_m = tile_m
     a.splits = splits
     a.workspace, a.workspace_bytes = 0, 0
     st = _stream()
     if tile_m == 0 and tile_n == 0 and AUTOTUNE:
-        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index, bool(asym))
+        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index, bool(asym), bool(gelu))
         best = _tile_cache.get(key)
         if best is None and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu)
@@ -231,6 +232,17 @@ def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
         return out
     _lib.check(lib.lr_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                     B, heads, Nq, Nkv, float(scale), _stream()), "attention")
+    return out
+
+
+def attention_causal(q, k, v, B, heads, N, scale):
+    """Causal self-attention (query i sees keys <= i), q/k/v [B*N, >=heads*64] strided column slices; the text tower."""
+    lib = _lib.load()
+    for t_ in (q, k, v):
+        assert t_.is_cuda and t_.dtype == torch.float16 and t_.stride(1) == 1
+    out = torch.empty(B * N, heads * 64, device=q.device, dtype=torch.float16)
+    _lib.check(lib.lr_attention_causal_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                           B, heads, N, float(scale), _stream()), "attention_causal")
     return out
 
 

@@ -95,6 +95,8 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
         raise NotImplementedError("gradient w.r.t. the time embedding is not produced (nothing trainable sits upstream of it)")
     if kw.get("out") is not None:
         raise ValueError("out= is not supported while autograd is recording")
+    if kw.get("gelu"):
+        raise NotImplementedError("the plain-GELU epilogue (text tower) has no backward; differentiate the PyTorch module instead")
     return _GemmConv.apply(x1, x2, resid, wt, bias, rowvec, kw)
 
 
