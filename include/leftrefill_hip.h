@@ -166,6 +166,8 @@ int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const
 /* GEGLU: pre = projection + bias in the packed [u16 | g16] column layout (lr_gemm_conv_f16 with geglu = 0 on the packed
  * weights), dy [M][H] -> dpre [M][2H] (same layout): du = dy * gelu(g), dg = dy * u * gelu'(g). */
 int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s);
+/* training forward: out [M][H] = u * gelu(g) from the stored packed projection (kept for lr_geglu_bwd instead of recomputing). */
+int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s);
 /* Attention: forward that also saves the log2-domain log-sum-exp (lse [B][heads][Nq] fp32), and the backward that
  * recomputes P from it (two deterministic kernels: dQ over key tiles; dK, dV over query tiles; plus D = rowsum(dO o O)).
  * qt / kt / dot are lr_transpose_v_f16 copies of q / k / dout ([B][heads*64][ld], ld = rows rounded up to 64);

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -55,6 +55,7 @@ SIGNATURES = {
                          c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "lr_mv_gather_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_scatter_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_geglu_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "lr_geglu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "lr_sumpool2x2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_softmax_rows_f16": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],

@@ -202,7 +202,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 9; }
+extern "C" int lr_abi_version(void) { return 10; }
 
 extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
                                        int H, int W, lr_stream_t s) {
@@ -322,6 +322,33 @@ __global__ void geglu_bwd_kernel(const f16* __restrict__ pre, const f16* __restr
     *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc) = lr_pack8(du);
     *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc + 16) = lr_pack8(dg);
   }
+}
+
+// GEGLU forward from the stored projection (training keeps `pre` for the backward instead of recomputing the GEMM):
+// out[m][c] = u * gelu_erf(g), same packed layout of pre as above.
+__global__ void geglu_fwd_kernel(const f16* __restrict__ pre, f16* __restrict__ out, long long total, int H) {
+  const int cpr = H >> 3;
+  for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const long long m = id / cpr;
+    const int c = (int)(id - m * cpr) * 8;
+    const int pc = (c >> 4) * 32 + (c & 15);
+    float u[8], g[8], o[8];
+    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
+    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = u[i] * lr_gelu_erf(g[i]);
+    *reinterpret_cast<uint4*>(out + m * H + c) = lr_pack8(o);
+  }
+}
+
+extern "C" int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s) {
+  if (!pre || !out || M <= 0 || H <= 0) return LR_E_ARG;
+  if (H % 16) return LR_E_ALIGN;
+  const long long total = (long long)M * (H / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)pre, (f16*)out, total, H);
+  return lr_launch_status();
 }
 
 extern "C" int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) {

@@ -4,8 +4,8 @@ Same call signatures as `leftrefill_amd.ops`; every function falls straight thro
 and an input requires grad, in which case it runs as a `torch.autograd.Function` whose backward is made of HIP kernels:
 
   conv / linear    dX = lr_gemm_conv_f16 on flipped, transposed weights (stride 2: zero-insertion gather, `up = 2`;
-                   nearest-up conv: dgrad at the fine resolution + lr_sumpool2x2); GEGLU epilogue: the projection is
-                   recomputed without the epilogue, lr_geglu_bwd, then the same dgrad GEMM
+                   nearest-up conv: dgrad at the fine resolution + lr_sumpool2x2); GEGLU: the training forward keeps the
+                   projection (lr_geglu_fwd applies the gate), lr_geglu_bwd, then the same dgrad GEMM
   GroupNorm(+SiLU) lr_groupnorm_stats (recomputed) + lr_groupnorm_bwd
   LayerNorm        lr_layernorm_bwd
   attention        lr_attention_bwd_f16 (flash-style recomputation from the saved log-sum-exp)
@@ -46,13 +46,19 @@ def dgrad_weight(wt, taps, lo, hi):
 class _GemmConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, resid, wt, bias, rowvec, kw):
-        out = ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
         ctx.kw, ctx.wt, ctx.bias = kw, wt, bias
         ctx.C1 = x1.shape[-1]
         ctx.C2 = 0 if x2 is None else x2.shape[-1]
         ctx.has_resid = resid is not None
-        ctx.save_for_backward(*((x1, x2) if kw.get("geglu") else ()))      # plain conv / linear: dX needs only dY and W
-        return out
+        if kw.get("geglu"):
+            # training: keep the projection (u | g, packed layout) for the backward and apply the gate in a second kernel --
+            # one elementwise pass now instead of recomputing the [M, 8C] GEMM later
+            assert resid is None and rowvec is None
+            pre = ops.gemm_conv(x1, wt, x2=x2, bias=bias, **{k: v for k, v in kw.items() if k != "geglu"})
+            ctx.save_for_backward(pre)
+            return geglu_fwd(pre)
+        ctx.save_for_backward()                                            # plain conv / linear: dX needs only dY and W
+        return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
 
     @staticmethod
     def backward(ctx, dy):
@@ -65,9 +71,7 @@ class _GemmConv(torch.autograd.Function):
             raise NotImplementedError("asymmetric-pad stride-2 conv (VAE encoder) has no backward: the VAE is frozen and not differentiated")
         g = dy
         if kw.get("geglu"):
-            x1, x2 = ctx.saved_tensors
-            pre = ops.gemm_conv(x1, wt, x2=x2, bias=ctx.bias, B=B, H=H, W=W, taps=taps)          # u | g, packed layout
-            g = geglu_bwd(pre, dy)
+            g = geglu_bwd(ctx.saved_tensors[0], dy)
         dxs = []
         for lo, hi in ((0, ctx.C1), (ctx.C1, ctx.C1 + ctx.C2)):
             if hi == lo or not ctx.needs_input_grad[0 if lo == 0 else 1]:
@@ -98,6 +102,14 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
     if kw.get("gelu"):
         raise NotImplementedError("the plain-GELU epilogue (text tower) has no backward; differentiate the PyTorch module instead")
     return _GemmConv.apply(x1, x2, resid, wt, bias, rowvec, kw)
+
+
+def geglu_fwd(pre):
+    lib = _lib.load()
+    M, H2 = pre.shape
+    out = torch.empty(M, H2 // 2, device=pre.device, dtype=torch.float16)
+    _lib.check(lib.lr_geglu_fwd(_p(pre), _p(out), M, H2 // 2, _stream()), "geglu_fwd")
+    return out
 
 
 def geglu_bwd(pre, dy):
