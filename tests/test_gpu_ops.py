@@ -383,3 +383,36 @@ def test_ddim_step_golden(golden, case, S, eta, index):
                                    tabs["sqrt_one_minus_alphas"][index])
     np.testing.assert_allclose(xp16.cpu().numpy(), xr.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(p016.cpu().numpy(), pr.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_argument_errors_are_reported_not_launched():
+    """Error behaviour of the C ABI (include/leftrefill_hip.h): negative codes for bad arguments / alignment / unsupported
+    shapes -- surfaced as RuntimeError by the Python binding -- and no launch happens (the output stays untouched)."""
+    import ctypes
+    from leftrefill_amd import _lib, ops
+    lib = _lib.load()
+    d = dev()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.zeros(64, 96, device=d, dtype=torch.float16)          # 96 channels: not a multiple of 64
+    w = torch.zeros(64, 96, device=d, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="gemm_conv"):
+        ops.gemm_conv(x, w, B=1, H=1, W=64, taps=1)
+    a = _lib.GemmArgs()
+    assert lib.lr_gemm_conv_f16(a, st) == -1                          # null pointers -> LR_E_ARG
+    x64 = torch.zeros(64, 64, device=d, dtype=torch.float16)
+    out = torch.full((64, 64), 7.0, device=d, dtype=torch.float16)
+    a.p1, a.C1, a.B, a.H, a.W, a.Hs, a.Ws, a.taps, a.stride = x64.data_ptr(), 64, 1, 1, 64, 1, 64, 4, 1   # taps = 4
+    a.wt, a.N, a.out, a.ld_out = x64.data_ptr(), 64, out.data_ptr(), 64
+    assert lib.lr_gemm_conv_f16(a, st) == -3                          # LR_E_UNSUPPORTED
+    a.taps, a.ld_out = 1, 60
+    assert lib.lr_gemm_conv_f16(a, st) == -2                          # LR_E_ALIGN (ld_out % 8)
+    a.ld_out, a.geglu = 64, 5
+    assert lib.lr_gemm_conv_f16(a, st) == -1
+    torch.cuda.synchronize()
+    assert torch.all(out == 7.0)
+    q = torch.zeros(128, 64, device=d, dtype=torch.float16)
+    assert lib.lr_attention_f16(q.data_ptr(), 60, q.data_ptr(), 64, q.data_ptr(), 64, out.data_ptr(), 64, 1, 1, 128, 128,
+                                ctypes.c_float(0.125), st) == -2       # ldq % 8
+    assert lib.lr_layernorm(q.data_ptr(), None, None, ctypes.c_float(1e-5), q.data_ptr(), 128, 64, st) == -1
+    assert lib.lr_groupnorm_stats(q.data_ptr(), 48, None, 0, 1, 128, q.data_ptr(), st) == -2     # C % 32
+    assert lib.lr_softmax_rows_f16(q.data_ptr(), q.data_ptr(), 4, 20000, ctypes.c_float(1.0), st) == -3
