@@ -44,3 +44,18 @@ def test_bench_two_ranks_share_gpu():
     assert len(lines) == 1, p.stdout[-2000:]      # rank 0 only
     r = lines[0]
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
+
+
+def test_train_workload_two_ranks_share_gpu():
+    """Data-parallel training step (token-gradient all-reduce) through the multi-rank path, two ranks on the one GPU."""
+    env = dict(os.environ, LR_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                        "train", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 32 and r["unit"] == "samples/s"
+    assert 0.5 < r["final_loss"] < 3.0 and r["value"] > 50
