@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is a build artefact (git-ignored): compile it when a fresh checkout has none or the sources are
+    newer (hipcc cross-compiles gfx950 without a GPU).  On the GPU box the prebuilt .so travels with the tree."""
+    from leftrefill_amd import build as b
+    try:
+        b.build(verbose=False)
+    except Exception as e:      # no hipcc: the tests that need the library fail loudly on their own
+        print(f"[conftest] could not (re)build the HIP library: {e}")
+
+
 @pytest.fixture(scope="session")
 def golden():
     class _G:
