@@ -506,10 +506,10 @@ __global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f1
     mu[i] = s_mean[g]; rs[i] = s_rstd[g]; ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
     s1[i] = 0.f; s2[i] = 0.f;
   }
-  for (int p = p0 + r; p < p1; p += R) {
+  auto accum = [&](const uint4& ux, const uint4& ug) {
     float xv[8], gv[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(src + (size_t)p * cs), xv);
-    lr_unpack8(*reinterpret_cast<const uint4*>(gsrc + (size_t)p * C), gv);
+    lr_unpack8(ux, xv);
+    lr_unpack8(ug, gv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float xh = (xv[i] - mu[i]) * rs[i];
@@ -518,7 +518,20 @@ __global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f1
       s1[i] += g;
       s2[i] = fmaf(g, xh, s2[i]);
     }
+  };
+  int p = p0 + r;
+  for (; p + 3 * R < p1; p += 4 * R) {      // eight 16-byte loads in flight per thread
+    uint4 ux[4], ug[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ux[k] = *reinterpret_cast<const uint4*>(src + (size_t)(p + k * R) * cs);
+      ug[k] = *reinterpret_cast<const uint4*>(gsrc + (size_t)(p + k * R) * C);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accum(ux[k], ug[k]);
   }
+  for (; p < p1; p += R)
+    accum(*reinterpret_cast<const uint4*>(src + (size_t)p * cs), *reinterpret_cast<const uint4*>(gsrc + (size_t)p * C));
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     s_part[((size_t)r * C + c0 + i) * 2 + 0] = s1[i];
@@ -576,10 +589,10 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
     mu[i] = s_mean[g]; rs[i] = s_rstd[g]; ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
     k1[i] = s_c1[g]; k2[i] = s_c2[g];
   }
-  for (int p = p0 + r; p < p1; p += R) {
+  auto emit = [&](int pp, const uint4& ux, const uint4& ug) {
     float xv[8], gv[8], f[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(src + (size_t)p * cs), xv);
-    lr_unpack8(*reinterpret_cast<const uint4*>(gsrc + (size_t)p * C), gv);
+    lr_unpack8(ux, xv);
+    lr_unpack8(ug, gv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float xh = (xv[i] - mu[i]) * rs[i];
@@ -587,8 +600,21 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
       const float g = gv[i] * gn_act_grad(z, silu) * ga[i];
       f[i] = rs[i] * (g - k1[i] - xh * k2[i]);
     }
-    *reinterpret_cast<uint4*>(dst + (size_t)p * cs) = lr_pack8(f);
+    *reinterpret_cast<uint4*>(dst + (size_t)pp * cs) = lr_pack8(f);
+  };
+  int p = p0 + r;
+  for (; p + 3 * R < p1; p += 4 * R) {
+    uint4 ux[4], ug[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ux[k] = *reinterpret_cast<const uint4*>(src + (size_t)(p + k * R) * cs);
+      ug[k] = *reinterpret_cast<const uint4*>(gsrc + (size_t)(p + k * R) * C);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) emit(p + k * R, ux[k], ug[k]);
   }
+  for (; p < p1; p += R)
+    emit(p, *reinterpret_cast<const uint4*>(src + (size_t)p * cs), *reinterpret_cast<const uint4*>(gsrc + (size_t)p * C));
 }
 
 extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
