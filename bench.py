@@ -469,16 +469,29 @@ def main():
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline and a.workload == "single":
-        res["unet_step_events"] = unet_step_events(model, batch, B)
-        res["vae_512x1024"] = vae_timing(B, device)
+        # side measurements, reported beside the metric and never inside `value`; a failure here must not cost the bench line
+        def side(name, fn):
+            try:
+                res[name] = fn()
+            except Exception as e:      # noqa: BLE001
+                res[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        side("unet_step_events", lambda: unet_step_events(model, batch, B))
+        side("vae_512x1024", lambda: vae_timing(B, device))
         v = res["vae_512x1024"]
-        # caller view (log_images): 2 VAE encodes (image, masked image) + sampling + 1 decode per batch; never `value`
-        res["end_to_end_images_per_s_incl_vae"] = B / (ms_per_step + 2 * v["encode"]["ms"] + v["decode"]["ms"]) * 1e3
-        if world == 1:      # next row 8f-2, reported beside the metric: one training step of the prompt tokens (see train_bench)
-            tr = train_bench(a, rank, world, device, model=model, steps=3)
-            res["training_256x512_b16"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
+        if "error" not in v:
+            # caller view (log_images): 2 VAE encodes (image, masked image) + sampling + 1 decode per batch
+            res["end_to_end_images_per_s_incl_vae"] = B / (ms_per_step + 2 * v["encode"]["ms"] + v["decode"]["ms"]) * 1e3
+        if world == 1:      # next row 8f-2: one training step of the prompt tokens (see train_bench)
+            def train():
+                tr = train_bench(a, rank, world, device, model=model, steps=3)
+                return {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
+            side("training_256x512_b16", train)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline()
+        try:
+            res["cpu_baseline"] = cpu_baseline()
+        except Exception as e:      # noqa: BLE001
+            res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
