@@ -1,0 +1,52 @@
+"""Aggregate rocprofv3 --pmc counter CSVs per kernel family over the LAST eager UNet step of tools/pmc_step.py.
+
+    python tools/pmc_util.py <dir_with_counter_collection_csv> [<dir2> ...]
+
+Prints, per kernel family, the summed counters and the ratios used in DESIGN.md:
+  MFMA busy    = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)   [rocprofv3 reports GRBM_GUI_ACTIVE summed
+                 over the 8 XCDs; calibrated on the long-K convs: 1000-1200 TFLOP/s <-> 40-48 % busy]
+  wave parked  = SQ_WAIT_ANY / SQ_WAVE_CYCLES,  issue stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+  LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    for key in ("gemm_conv256_kernel<320, 2, 2>", "gemm_conv256_kernel<256, 2, 2>", "gemm_conv256_kernel", "gemm_conv_kernel",
+                "attention_kernel<true", "attention_kernel<false", "gn_apply", "gn_stats", "layernorm", "splitk_reduce",
+                "transpose_v"):
+        if key in name:
+            return key
+    return None
+
+
+tot = defaultdict(lambda: defaultdict(float))
+for d in sys.argv[1:]:
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # last step = everything after the second-to-last timestep_embedding launch's dispatch
+    marks = sorted({int(r["Dispatch_Id"]) for r in rows if "timestep_embedding" in r["Kernel_Name"]})
+    start = marks[-1]
+    for r in rows:
+        if int(r["Dispatch_Id"]) < start:
+            continue
+        fam = family(r["Kernel_Name"])
+        if fam:
+            tot[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+            tot[fam]["launches:" + r["Counter_Name"]] += 1
+for fam, c in sorted(tot.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+    out = [f"{fam:34s}"]
+    if c.get("GRBM_GUI_ACTIVE"):
+        out.append(f"MFMA busy {100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (c['GRBM_GUI_ACTIVE'] / 8 * 256 * 4):5.1f}%")
+    if c.get("SQ_WAVE_CYCLES"):
+        out.append(f"parked {100 * c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:5.1f}%  issue-stall "
+                   f"{100 * c.get('SQ_WAIT_INST_ANY', 0) / c['SQ_WAVE_CYCLES']:5.1f}%  active {100 * c.get('SQ_ACTIVE_INST_ANY', 0) / c['SQ_WAVE_CYCLES']:5.1f}%")
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        out.append(f"LDS conflict {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:5.2f}%")
+    print("  ".join(out))
