@@ -5,6 +5,8 @@ fp16-rounded inputs and weights; composite operators (several fp16 round trips i
 scaled absolute term, stated per test.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -416,3 +418,19 @@ def test_argument_errors_are_reported_not_launched():
     assert lib.lr_layernorm(q.data_ptr(), None, None, ctypes.c_float(1e-5), q.data_ptr(), 128, 64, st) == -1
     assert lib.lr_groupnorm_stats(q.data_ptr(), 48, None, 0, 1, 128, q.data_ptr(), st) == -2     # C % 32
     assert lib.lr_softmax_rows_f16(q.data_ptr(), q.data_ptr(), 4, 20000, ctypes.c_float(1.0), st) == -3
+
+
+def test_c_abi_from_plain_cpp_without_torch(tmp_path):
+    """The boundary is a C ABI: a stand-alone C++ host program (no Python, no torch types) links the shared library, owns
+    its buffers and stream, and gets correct results."""
+    import shutil
+    import subprocess
+    from leftrefill_amd import build as b
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(b.HERE, "..", "include"),
+                    os.path.join(b.HERE, "..", "tests", "cabi", "cabi_smoke.cpp"), "-L", b.LIBDIR, "-lleftrefill_hip",
+                    "-Wl,-rpath," + b.LIBDIR, "-o", exe], check=True, capture_output=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(p.stdout.strip())
+    assert p.returncode == 0, p.stdout + p.stderr
