@@ -460,7 +460,7 @@ def main():
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> (implicit-GEMM conv3x3/1x1/linear)",
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> / gemm_conv256_kernel<BN,..> (implicit-GEMM conv3x3 / 1x1 / linear family, tile picked per shape)",
                            "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
