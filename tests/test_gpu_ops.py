@@ -434,3 +434,90 @@ def test_c_abi_from_plain_cpp_without_torch(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(p.stdout.strip())
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_gemm_conv_randomised_shapes():
+    """60 random problems (seeded): odd spatial sizes, every gather mode, concat sources, ragged N, random tile / split-K
+    requests, random epilogue combinations -- each against F.conv2d on the fp16-rounded operands."""
+    import random
+    from leftrefill_amd import ops, packing
+    rng = random.Random(1234)
+    d = dev()
+    tiles = [(0, 0), (128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)]
+    n_checked = 0
+    for case in range(60):
+        taps = rng.choice([1, 9, 9])
+        mode = rng.choice(["s1", "s1", "s2", "up", "asym"]) if taps == 9 else "s1"
+        C1 = rng.choice([64, 128, 192, 320])
+        C2 = rng.choice([0, 0, 64, 128])
+        N = rng.choice([64, 72, 128, 200, 320, 384])
+        B = rng.randint(1, 3)
+        H, W = rng.randint(1, 12), rng.randint(1, 14)
+        Hs, Ws, stride, up, asym = H, W, 1, 0, False
+        if mode in ("s2", "asym"):
+            Hs, Ws, stride, asym = 2 * H, 2 * W, 2, mode == "asym"
+        elif mode == "up":
+            H, W = 2 * rng.randint(1, 6), 2 * rng.randint(1, 7)
+            Hs, Ws, up = H // 2, W // 2, 1
+        tm, tn = rng.choice(tiles)
+        splits = rng.choice([0, 0, 1, 2, 3])
+        use_bias, use_rv, use_res = rng.random() < 0.8, rng.random() < 0.3, rng.random() < 0.5
+        name = f"fz{case}"
+        Ct = C1 + C2
+        k = 3 if taps == 9 else 1
+        x = h16(G.T(name + ".x", (B, Ct, Hs, Ws)))
+        w = h16(torch.from_numpy(weights.fill_like(name + ".w", (N, Ct, k, k))))
+        b = torch.from_numpy(weights.fill_like(name + ".b", (N,))) if use_bias else None
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+        if asym:
+            ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, b, stride=2, padding=0)
+        else:
+            ref = F.conv2d(xin, w, b, stride=stride, padding=1 if taps == 9 else 0)
+        rv = rs = None
+        if use_rv:
+            rv = h16(G.T(name + ".rv", (B, N)))
+            ref = ref + rv[:, :, None, None]
+        if use_res:
+            rs = h16(G.T(name + ".rs", (B, N, H, W)))
+            ref = ref + rs
+        wp = packing.pack_conv(w, cin_pad=Ct, cout_pad=N).to(d)
+        try:
+            y = ops.gemm_conv(to_tok(x[:, :C1]), wp, B=B, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym,
+                              x2=to_tok(x[:, C1:]) if C2 else None, bias=b.to(d) if use_bias else None,
+                              rowvec=rv.half().to(d) if use_rv else None, resid=to_tok(rs) if use_res else None,
+                              tile_m=tm, tile_n=tn, splits=splits)
+        except RuntimeError as e:        # an explicit split request that the shape cannot honour is an argument error
+            assert splits > 1 and "gemm_conv" in str(e), (case, str(e))
+            continue
+        got = from_tok(y, B, H, W)
+        err = (got - ref).abs()
+        tol = 2e-3 * ref.abs() + 2e-3 * max(1.0, ref.abs().max().item())
+        assert (err <= tol).all(), (case, mode, taps, C1, C2, N, B, H, W, tm, tn, splits, err.max().item())
+        n_checked += 1
+    assert n_checked >= 50
+
+
+def test_attention_randomised_shapes():
+    """30 random (B, heads, Nq, Nkv) problems, ragged in both dimensions, on both V paths (register-transposed and
+    pre-transposed), against the oracle's attention."""
+    import random
+    from leftrefill_amd import ops
+    rng = random.Random(99)
+    d = dev()
+    old = ops.VT_MIN_KEYS
+    try:
+        for case in range(30):
+            B, heads = rng.randint(1, 3), rng.randint(1, 4)
+            Nq, Nkv = rng.randint(1, 400), rng.randint(1, 600)
+            ops.VT_MIN_KEYS = rng.choice([1, 1 << 30])
+            C = heads * 64
+            q = h16(G.T(f"attfz{case}.q", (B, Nq, C)))
+            k = h16(G.T(f"attfz{case}.k", (B, Nkv, C)))
+            v = h16(G.T(f"attfz{case}.v", (B, Nkv, C)))
+            ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))
+            kv = torch.cat([k, v], -1).reshape(B * Nkv, 2 * C).half().to(d)
+            o = ops.attention(q.reshape(B * Nq, C).half().to(d), kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, 64 ** -0.5)
+            err = (o.float().cpu().reshape(B, Nq, C) - ref).abs().max().item()
+            assert err < 3e-3, (case, B, heads, Nq, Nkv, ops.VT_MIN_KEYS, err)
+    finally:
+        ops.VT_MIN_KEYS = old
