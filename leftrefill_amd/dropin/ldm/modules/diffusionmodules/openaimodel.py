@@ -319,8 +319,10 @@ class UNetModel(nn.Module):
         ctx = context.reshape(N * L, D)
         res = []
         for i, pt in enumerate(P["tblocks"]):
-            o = None if out is None else out[i]
-            res.append(ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=N * L, taps=1, out=o))
+            o, ot = (None, None) if out is None else out[i]
+            kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=N * L, taps=1, out=o)
+            C = kv.shape[1] // 2
+            res.append((kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot)))   # V^T: the V tile streams by LDS-DMA
         return res
 
     def _run_plan(self, x, timesteps, context, kv_cache=None):

@@ -182,12 +182,15 @@ def self_attention(x, pa: PackedAttn, B, L, resid):
 
 
 def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid, kv=None):
-    """kv: optional precomputed [B*Lc, 2C] = ctx @ [Wk; Wv]^T (constant over the DDIM steps, see UNetModel)."""
-    C = x.shape[1]
+    """kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T, V^T in the attention kernel's layout) -- constant over the
+    DDIM steps, see UNetModel._context_kv."""
     q = linear(x, pa.q)
+    vt = None
     if kv is None:
         kv = linear(ctx, pa.kv)
-    a = ops.attention_q_kv(q, kv, B, pa.heads, L, Lc, pa.dim_head ** -0.5)
+    else:
+        kv, vt = kv
+    a = ops.attention_q_kv(q, kv, B, pa.heads, L, Lc, pa.dim_head ** -0.5, vt=vt)
     return linear(a, pa.out, resid=resid)
 
 

@@ -204,12 +204,13 @@ def _tune_tiles(lib, a, device, geglu, reps=4, rounds=2):
 VT_MIN_KEYS = int(os.environ.get("LEFTREFILL_VT_MIN_KEYS", "1024"))   # pre-transpose V for key sequences at least this long
 
 
-def transpose_v(v, B, heads, Nkv):
+def transpose_v(v, B, heads, Nkv, out=None):
     """v [B*Nkv, >=heads*64] (row stride ldv) -> V^T [B, heads*64, pad64(Nkv)] in the attention kernel's key order."""
     lib = _lib.load()
     assert v.is_cuda and v.dtype == torch.float16 and v.stride(1) == 1
     ld = ((Nkv + 63) // 64) * 64
-    vt = torch.empty(B, heads * 64, ld, device=v.device, dtype=torch.float16)
+    vt = torch.empty(B, heads * 64, ld, device=v.device, dtype=torch.float16) if out is None else out
+    assert vt.shape == (B, heads * 64, ld) and vt.is_contiguous()
     _lib.check(lib.lr_transpose_v_f16(_p(v), v.stride(0), _p(vt), ld, B, heads, Nkv, _stream()), "transpose_v")
     return vt
 
@@ -252,10 +253,11 @@ def attention_qkv(qkv, B, heads, L, scale):
     return attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, heads, L, L, scale)
 
 
-def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale):
-    """Cross-attention: q [B*Nq, C], fused context projection kv [B*Nkv, 2C] (k | v column blocks)."""
+def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=None):
+    """Cross-attention: q [B*Nq, C], fused context projection kv [B*Nkv, 2C] (k | v column blocks); vt: optional cached
+    transpose_v of the v block (the context is constant over the DDIM steps)."""
     C = heads * 64
-    return attention(q, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, scale)
+    return attention(q, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, scale, vt=vt)
 
 
 def softmax_rows(s, scale, out=None):

@@ -314,9 +314,9 @@ def attention_qkv(qkv, B, heads, L, scale):
     return _AttentionQKV.apply(qkv.contiguous(), B, heads, L, scale)
 
 
-def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale):
+def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=None):
     if not _needs_grad(q, kv):
-        return ops.attention_q_kv(q, kv, B, heads, Nq, Nkv, scale)
+        return ops.attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=vt)
     return _AttentionQ_KV.apply(q.contiguous(), kv.contiguous(), B, heads, Nq, Nkv, scale)
 
 
