@@ -104,7 +104,23 @@ typedef struct lr_gemm_args {
    * splits: 0 = auto, 1 = off.  workspace may be NULL (=> no split).  Not available with geglu. */
   int32_t splits;
   float* workspace; int64_t workspace_bytes;
+  /* LayerNorm folded into a pointwise GEMM (replaces nn.LayerNorm norm1/2/3 + the Linear that follows it,
+   * attention.py:271-283): p1 is the RAW x [M][K], wt = W * gamma (gamma folded along K), bias = W beta + b,
+   * ln_colsum[n] = sum_k wt[n][k] (fp32, of the fp16-rounded wt):
+   *     out[m][n] = rstd[m] * (acc[m][n] - mean[m] * ln_colsum[n]) + bias[n]
+   * mean / rstd of row m are finalised inside the kernel from ln_stats [M][ln_parts][2] = per-row partial (sum, sumsq)
+   * written by the GEMM that produced x (stats_out below).  ln_stats == NULL: plain GEMM. */
+  const float* ln_stats; int32_t ln_parts; float ln_eps;
+  const float* ln_colsum;
+  /* stats_out != NULL: per-row (sum, sumsq) of the fp16-rounded output over each wave's column range,
+   * [M][lr_gemm_stats_parts(args)][2] fp32 (fixed order, no atomics). Not with split-K. */
+  float* stats_out;
 } lr_gemm_args;
+/* plan[0..2] = (tile_m, tile_n, splits) the call would use: explicit requests as given, zeros resolved by the static
+ * heuristics (a pure function of the shape -- never of timing; the Python front end ships its tuned choices as a table). */
+int lr_gemm_plan(const lr_gemm_args* args, int32_t* plan);
+/* number of per-row partials this call writes to stats_out (a function of N and the tile that will be used) */
+int lr_gemm_stats_parts(const lr_gemm_args* args);
 /* bytes of workspace lr_gemm_conv_f16 would like for this problem (0 if it will not split) */
 int64_t lr_gemm_workspace_bytes(const lr_gemm_args* args);
 int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -32,6 +32,9 @@ class GemmArgs(ctypes.Structure):
         ("tile_m", ctypes.c_int32),
         ("splits", ctypes.c_int32),
         ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("ln_stats", c_void_p), ("ln_parts", ctypes.c_int32), ("ln_eps", ctypes.c_float),
+        ("ln_colsum", c_void_p),
+        ("stats_out", c_void_p),
     ]
 
 
@@ -64,6 +67,8 @@ SIGNATURES = {
     "lr_linear_small_m": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_void_p],
     "lr_gemm_workspace_bytes": [ctypes.POINTER(GemmArgs)],
+    "lr_gemm_stats_parts": [ctypes.POINTER(GemmArgs)],
+    "lr_gemm_plan": [ctypes.POINTER(GemmArgs), ctypes.POINTER(ctypes.c_int32)],
     "lr_gemm_conv_f16": [ctypes.POINTER(GemmArgs), c_void_p],
     "lr_attention_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_float, c_void_p],

@@ -41,6 +41,27 @@ __device__ __forceinline__ float lr_erf(float x) {
 }
 __device__ __forceinline__ float lr_gelu_erf(float x) { return 0.5f * x * (1.0f + lr_erf(x * 0.70710678118654752f)); }
 
+// Two erf-GELUs per instruction stream: the polynomial / scaling steps as packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32,
+// two values per VALU issue), only rcp / exp2 stay scalar.  Same formula and constants as lr_gelu_erf (bit-identical
+// results are not required between the two, both are within 1.5e-7 of erf).  The GEGLU epilogue is VALU-bound on this.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t lr_gelu_erf2(const f32x2_t x) {
+  const f32x2_t z = x * 0.70710678118654752f;
+  const f32x2_t az = {fabsf(z[0]), fabsf(z[1])};
+  const f32x2_t one = {1.0f, 1.0f};
+  const f32x2_t d = __builtin_elementwise_fma(az, (f32x2_t){0.3275911f, 0.3275911f}, one);
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t){1.061405429f, 1.061405429f}, (f32x2_t){-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.254829592f, 0.254829592f});
+  const f32x2_t a2 = az * az * -1.44269504088896340736f;          // exp(-z^2) = exp2(-z^2 log2 e)
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+  const f32x2_t r = __builtin_elementwise_fma(-(p * t), e, one);   // erf(|z|)
+  const f32x2_t er = {copysignf(r[0], z[0]), copysignf(r[1], z[1])};
+  return (x * 0.5f) * (er + one);
+}
+
 __device__ __forceinline__ float lr_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -28,7 +28,23 @@ struct GemmParams {
   int ntiles_n, nblocks;
   int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
   int ntiles_m, m_fastest; // tile order inside an XCD's contiguous chunk (see tile_order())
+  // LayerNorm folded into this GEMM (A = raw x, Wt = W * gamma): out = rstd[m] * (acc - mean[m] * ln_cs[n]) + bias'[n];
+  // (mean, rstd) of row m come from the producer's per-row partial (sum, sumsq): ln_part[m][ln_parts][2]
+  const float* ln_part; const float* ln_cs; int ln_parts; float ln_eps, ln_invc;
+  // per-row (sum, sumsq) of THIS GEMM's fp16 output over each wave's column range: st_out[m][st_parts][2]
+  float* st_out; int st_parts;
+#ifdef LR_GEMM_TRACE
+  unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
+#endif
 };
+
+#ifdef LR_GEMM_TRACE
+#define LR_STAMP(k) do { if (P.trace && threadIdx.x == 0) P.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+static unsigned long long* g_trace = nullptr;
+extern "C" void lr_gemm_set_trace(void* p) { g_trace = (unsigned long long*)p; }
+#else
+#define LR_STAMP(k) do { } while (0)
+#endif
 
 // Blocks are handed to XCDs in contiguous logical chunks (bijective remap of blockIdx).  Inside a chunk the order is
 //   m-fastest: neighbours share the WEIGHT slice (BN x K) -- right when that slice is MBs (3x3 convs at 1280 channels:
@@ -54,8 +70,255 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, si
 }
 #endif
 
-template <int BN>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParams P) {
+// =====================================================================================================================
+// Register epilogue shared by both kernels: no LDS staging, no barriers, every wave drains its own accumulators.
+//
+// With the swapped product a lane (fr = lane & 15, fq = lane >> 4) holds D[n = 16 j + 4 fq + r][m = 16 i + fr], r < 4:
+// four consecutive channels of one output row per MFMA tile.  `v_permlane16_swap` of two tiles (A, B) exchanges the odd
+// 16-lane rows of A with the even rows of B, after which the lane owns EIGHT consecutive channels (16 bytes of fp16) of
+// tile (fq & 1 ? B : A): residual / per-sample row vector come in as one 16-byte load, the result leaves as one 16-byte
+// store, and a wave-wide store covers 16 rows x 64 contiguous bytes (tile pairs adjacent in n) -- L2 merges the two
+// halves of every 128-byte line.  An odd leftover tile column is paired along m instead.  Loads of the next unit are
+// independent of the current one, so the residual latency overlaps across units and across the block's waves.
+//   optional: LayerNorm fold (see GemmParams), per-row (sum, sumsq) of the rounded output for the NEXT LayerNorm.
+// =====================================================================================================================
+__device__ __forceinline__ void swap_rows16(f32x4& a, f32x4& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ar = a[r], br = b[r];   // plain floats: __builtin_bit_cast of a vector-element lvalue reads element 0
+    const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ar), __builtin_bit_cast(unsigned, br),
+                                                    false, false);
+    a[r] = __builtin_bit_cast(float, (unsigned)s[0]);
+    b[r] = __builtin_bit_cast(float, (unsigned)s[1]);
+  }
+#endif
+}
+
+// rs : LDS [rows of the block][2] = (mean, rstd), already offset to this wave's first row (LayerNorm fold only)
+// par: LDS [2][PAR_LD] floats = bias and ln_colsum of the block's columns (zeros where absent), already offset to this
+//      wave's first column; filled by LDS-DMA in the kernel prologue (stage_params) so that the epilogue issues NO
+//      per-lane parameter loads -- a VGPR load in the unit loop makes hipcc wait vmcnt(0), which on gfx950 also waits
+//      for every store already issued (one full store round trip per unit: 65k cycles per 256x320 tile, measured).
+//
+// Units: one unit = one swapped tile pair = one 16-byte store per lane.  TE = emitted tile columns per wave (TN, or TN/2
+// with GEGLU where tiles (2 jo, 2 jo + 1) = (value, gate) of output tile jo).  Units 0 .. TM*(TE/2)-1 pair columns
+// (2 jp, 2 jp + 1) of row tile i; an odd last column is paired along m: rows (2 ip, 2 ip + 1).
+// Residual / row-vector come through buffer descriptors (absent operand = 0 records = zeros, row / column tails =
+// out-of-range offsets: no branches around memory ops, so the compiler's counted vmcnt stays exact); the loads run G
+// units ahead of their use and the stores never block.
+//
+// MODE (compile time, keeps the unrolled epilogue small: the erf polynomial is only instantiated where it is used):
+//   0 plain | 1 GEGLU (value * gelu(gate)) | 2 erf-GELU of (acc + bias [+ rowvec]) before the residual
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Which 16-column tile of the block's EMITTED column space wave `wn` accumulates in its je-th tile column (TE per wave,
+// WNW waves along n).  Contiguous ranges, except TE = 5 (80-column wave tiles of the 160 / 320-wide blocks): 80 columns
+// are 160 bytes of fp16, so contiguous ranges would start in the middle of 128-byte lines and every 64-byte store
+// segment of waves 1 and 3 would straddle two lines.  Instead wave wn takes tiles 4 wn .. 4 wn + 3 (one whole line)
+// plus tile 4 WNW + wn of the last line: the paired stores are 64-byte aligned halves of a line owned by one wave.
+// The permutation only changes which B_s rows a wave reads (weights are staged in natural row order).
+template <int TE, int WNW>
+__device__ __forceinline__ constexpr int emit_tile(const int wn, const int je) {
+  return TE == 5 ? (je < 4 ? 4 * wn + je : 4 * WNW + wn) : wn * TE + je;
+}
+// accumulator tile column j of wave wn -> 16-row tile of the staged weight rows
+template <int TN, int WNW, bool GEGLU>
+__device__ __forceinline__ constexpr int weight_tile(const int wn, const int j) {
+  return GEGLU ? 2 * emit_tile<TN / 2, WNW>(wn, j >> 1) + (j & 1) : emit_tile<TN, WNW>(wn, j);
+}
+
+template <int TM, int TN, int MODE, int PAR_LD, int WNW>
+__device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)[TN][TM], const int m_w0, const int n0,
+                                               const int wn, const int lane, const float* rs, const float* par,
+                                               const int part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool GEGLU = MODE == 1;
+  constexpr int TE = GEGLU ? TN / 2 : TN;
+  constexpr int NPJ = TE / 2;
+  constexpr int NUJ = TM * NPJ;
+  constexpr int NU = NUJ + (TE & 1) * (TM / 2);
+  constexpr int G = TM * TN >= 40 ? 6 : 8;   // residual loads in flight per wave (16 B per lane each)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int odd = fq & 1, ch8 = (fq >> 1) * 8;
+  const int N_out = GEGLU ? P.N >> 1 : P.N;
+  const int no0 = GEGLU ? n0 >> 1 : n0;      // block's first emitted column
+  const bool ln = P.ln_part != nullptr;
+  const bool fin = P.splits == 1;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsR = uniform_rsrc(P.resid ? (const void*)P.resid : (const void*)P.out,
+                                                  (P.resid && fin) ? ((size_t)(P.M - 1) * P.ld_resid + N_out) * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc(P.rowvec ? (const void*)P.rowvec : (const void*)P.out,
+                                                  (P.rowvec && fin) ? ((size_t)((P.M - 1) / P.rows_per_batch) * P.ld_rowvec + N_out) * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rsO = uniform_rsrc(P.out, fin ? ((size_t)(P.M - 1) * P.ld_out + N_out) * 2 : 0);
+  float s1[TM], s2[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  auto rowstat = [&](const int i) -> float2 { return *reinterpret_cast<const float2*>(rs + 2 * (i * 16 + fr)); };
+  auto par4 = [&](const int which, const int col) -> f32x4 { return *reinterpret_cast<const f32x4*>(par + which * PAR_LD + col); };
+  // accumulator tile (i, je) of the EMITTED grid, with LayerNorm fold, bias and the GEGLU gate applied (pre-swap layout:
+  // lane holds channels 4 fq .. 4 fq + 3 of the tile)
+  auto tile = [&](const int i, const int je) -> f32x4 {
+    if constexpr (!GEGLU) {
+      const int c = weight_tile<TN, WNW, false>(wn, je) * 16 + fq * 4;
+      f32x4 r = acc[je][i];
+      if (ln) { const float2 mr = rowstat(i); r = (r - par4(1, c) * mr.x) * mr.y; }
+      if (fin) r += par4(0, c);
+      return r;
+    } else {
+      const int c = weight_tile<TN, WNW, true>(wn, 2 * je) * 16 + fq * 4;
+      f32x4 u = acc[2 * je][i], g = acc[2 * je + 1][i];
+      if (ln) {
+        const float2 mr = rowstat(i);
+        u = (u - par4(1, c) * mr.x) * mr.y;
+        g = (g - par4(1, c + 16) * mr.x) * mr.y;
+      }
+      u += par4(0, c); g += par4(0, c + 16);
+      const f32x2_t g01 = lr_gelu_erf2((f32x2_t){g[0], g[1]}), g23 = lr_gelu_erf2((f32x2_t){g[2], g[3]});
+      const f32x4 o = {u[0] * g01[0], u[1] * g01[1], u[2] * g23[0], u[3] * g23[1]};
+      return o;
+    }
+  };
+  // lane's output coordinates for unit u
+  auto coords = [&](const int u, int& m, int& n) {
+    if (u < NUJ) {
+      const int jp = u / TM, i = u - jp * TM;
+      m = m_w0 + i * 16 + fr;
+      n = no0 + emit_tile<TE, WNW>(wn, 2 * jp + odd) * 16 + ch8;
+    } else {
+      const int ip = u - NUJ;
+      m = m_w0 + (2 * ip + odd) * 16 + fr;
+      n = no0 + emit_tile<TE, WNW>(wn, TE - 1) * 16 + ch8;
+    }
+  };
+  // sample index of row m for the per-sample row vector: one division per wave, then boundary compares
+  const int b_w0 = P.rowvec ? m_w0 / P.rows_per_batch : 0;
+  auto fetch = [&](const int u, u32x4& rres, u32x4& rvec) {
+    int m, n;
+    coords(u, m, n);
+    const bool ok = m < P.M && n < N_out;
+    rres = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? (unsigned)(((size_t)m * P.ld_resid + n) * 2) : OOB, 0, 0);
+    int b = b_w0;
+    if (P.rowvec)
+      for (int lim = (b_w0 + 1) * P.rows_per_batch; m >= lim; lim += P.rows_per_batch) ++b;
+    rvec = __builtin_amdgcn_raw_buffer_load_b128(rsV, ok ? (unsigned)(((size_t)b * P.ld_rowvec + n) * 2) : OOB, 0, 0);
+  };
+  auto finish = [&](const int u, const u32x4& rres, const u32x4& rvec) {
+    f32x4 a, b;
+    int ia, ib;          // statistics slots of the even / odd lane rows
+    if (u < NUJ) {
+      const int jp = u / TM, i = u - jp * TM;
+      a = tile(i, 2 * jp); b = tile(i, 2 * jp + 1);
+      ia = i; ib = i;
+    } else {
+      const int ip = u - NUJ;
+      a = tile(2 * ip, TE - 1); b = tile(2 * ip + 1, TE - 1);
+      ia = 2 * ip; ib = 2 * ip + 1;
+    }
+    swap_rows16(a, b);
+    int m, n;
+    coords(u, m, n);
+    const bool ok = m < P.M && n < N_out;
+    if (!fin) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
+      if (ok) {
+        float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + 4) = b;
+      }
+      return;
+    }
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float e[8];
+    lr_unpack8(__builtin_bit_cast(uint4, rvec), e);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] += e[q];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = lr_gelu_erf(v[q]);
+    }
+    lr_unpack8(__builtin_bit_cast(uint4, rres), e);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] += e[q];
+    const uint4 pk = lr_pack8(v);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rsO,
+                                           ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, 0);
+    if (P.st_out) {
+      float f[8], t1 = 0.f, t2 = 0.f;
+      lr_unpack8(pk, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { t1 += f[q]; t2 = fmaf(f[q], f[q], t2); }
+      if (!ok) { t1 = 0.f; t2 = 0.f; }
+      if (ia == ib) { s1[ia] += t1; s2[ia] += t2; }
+      else {
+        s1[ia] += odd ? 0.f : t1; s2[ia] += odd ? 0.f : t2;
+        s1[ib] += odd ? t1 : 0.f; s2[ib] += odd ? t2 : 0.f;
+      }
+    }
+  };
+
+  // software pipeline: the loads of unit u + G are issued right after unit u is finished (a ring of G register sets)
+  u32x4 rr[G], rv[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+    if (k < NU) fetch(k, rr[k], rv[k]);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    finish(u, rr[u % G], rv[u % G]);
+    if (u + G < NU) fetch(u + G, rr[u % G], rv[u % G]);
+  }
+  if (P.st_out) {   // row sums over this wave's column range: the four fq lanes of an fr hold pieces of the same row
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float a = s1[i], b = s2[i];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      const int m = m_w0 + i * 16 + fr;
+      if (fq == 0 && m < P.M) {
+        float2 o; o.x = a; o.y = b;
+        *reinterpret_cast<float2*>(P.st_out + ((size_t)m * P.st_parts + part) * 2) = o;
+      }
+    }
+  }
+#endif
+}
+
+// Kernel prologue: bias and ln_colsum of the block's BN columns -> LDS par[2][PAR_LD] by 4-byte LDS-DMA (wave w covers
+// columns 64 w .. 64 w + 63; a missing operand or a column >= N reads as 0 through the descriptor's bounds check).
+// Issued BEFORE the first K stage, so every later counted vmcnt wait covers it.
+template <int BN, int PAR_LD>
+__device__ __forceinline__ void stage_params(const GemmParams& P, float* par, const int n0, const int w, const int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w < (BN + 63) / 64) {
+    const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(P.bias ? (const void*)P.bias : (const void*)P.wt,
+                                                   (P.bias && P.splits == 1) ? (size_t)P.N * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.ln_cs ? (const void*)P.ln_cs : (const void*)P.wt,
+                                                   P.ln_cs ? (size_t)P.N * 4 : 0);
+    const unsigned off = (unsigned)(n0 + w * 64 + lane) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(par + w * 64), 4, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lptr_t)(par + PAR_LD + w * 64), 4, off, 0, 0, 0);
+  }
+#endif
+}
+
+// (mean, rstd) of the block's rows from the producer's partial sums -> LDS rs[row][2]; one thread per row.
+__device__ __forceinline__ void ln_rows_to_lds(const GemmParams& P, float* rs, const int m0, const int rows, const int t) {
+  if (t < rows) {
+    const int m = m0 + t;
+    float s = 0.f, q = 0.f;
+    if (m < P.M) {
+      const float2* p = reinterpret_cast<const float2*>(P.ln_part) + (size_t)m * P.ln_parts;
+      for (int k = 0; k < P.ln_parts; ++k) { const float2 v = p[k]; s += v.x; q += v.y; }
+    }
+    const float mean = s * P.ln_invc;
+    const float var = fmaxf(fmaf(-mean, mean, q * P.ln_invc), 0.f);
+    rs[2 * t] = mean;
+    rs[2 * t + 1] = rsqrtf(var + P.ln_eps);
+  }
+}
+
+// 2nd launch-bounds argument = waves per SIMD the register allocation must leave room for (= resident blocks per CU here)
+template <int BN, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) void gemm_conv_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = 4;            // 16-row MFMA tiles per wave along M (64 rows)
   constexpr int TN = BN / 32;      // 16-col MFMA tiles per wave along N (BN/2 cols)
@@ -159,6 +422,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  constexpr int PAR_LD = ((BN + 63) / 64) * 64;
+  float* rs = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* par = rs + 2 * BM;
+  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
   if (k_begin < nk) stage(0, k_begin);
   __syncthreads();
   int cur = 0;
@@ -178,7 +445,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / 2) + j * 16 + fr;
+        const int row = weight_tile<TN, 2, MODE == 1>(wn, j) * 16 + fr;
         wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
@@ -191,89 +458,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_conv_kernel(const GemmParam
     cur ^= 1;
   }
 
-  // ---- epilogue: accumulators (+bias, GEGLU) -> fp32 tile in LDS -> whole-line stores with the fused per-sample row
-  // vector and residual.  Lane holds D[n = fq*4 + r][m = fr].  BN = 160 runs two passes of 64 rows so the staging tile
-  // (64 x 164 floats) stays inside the 72 KB of the two K-stages and two blocks fit on a CU.
-  constexpr int NPASS = BN > 128 ? 2 : 1;
-  constexpr int ROWS = BM / NPASS;
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int BNo = P.geglu ? BN / 2 : BN;
-  const int ldc = BNo + 4;
-  const int n_out0 = P.geglu ? n0 / 2 : n0;
-  const int N_out = P.geglu ? P.N / 2 : P.N;
-  const int cpr = BNo >> 3;  // 16-byte chunks per tile row
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    if (NPASS == 1 || wm == pass) {
-      const int wml = NPASS == 1 ? wm : 0;
-      if (!P.geglu) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nl = wn * (BN / 2) + j * 16 + fq * 4;
-          f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int ml = wml * 64 + i * 16 + fr;
-            *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
-          }
-        }
-      } else if constexpr (TN % 2 == 0) {
-#pragma unroll
-        for (int jp = 0; jp < TN / 2; ++jp) {
-          const int nl_u = wn * (BN / 2) + (2 * jp) * 16 + fq * 4;   // packed row of u; g is 16 rows further
-          f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
-          if (P.bias && n0 + nl_u + 16 < P.N) {
-            bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
-            bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
-          }
-          const int ol = wn * (BN / 4) + jp * 16 + fq * 4;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int ml = wml * 64 + i * 16 + fr;
-            const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
-            *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
-          }
-        }
-      }
-    }
+  // ---- epilogue straight from the accumulators (see epilogue_direct)
+  if (P.ln_part) {
+    ln_rows_to_lds(P, rs, m0, BM, t);
     __syncthreads();
-    for (int id = t; id < ROWS * cpr; id += GEMM_THREADS) {
-      const int row = id / cpr, cch = id - row * cpr;
-      const int m = m0 + pass * ROWS + row, n = n_out0 + cch * 8;
-      if (m >= P.M || n >= N_out) continue;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
-      const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
-      if (P.splits > 1) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
-        float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
-        *reinterpret_cast<f32x4*>(dst) = c0;
-        *reinterpret_cast<f32x4*>(dst + 4) = c1;
-        continue;
-      }
-      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      if (P.rowvec) {
-        float e[8];
-        lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += e[i];
-      }
-      if (P.gelu) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
-      }
-      if (P.resid) {
-        float e[8];
-        lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += e[i];
-      }
-      *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
-    }
-    if (NPASS > 1) __syncthreads();
   }
+  epilogue_units<TM, TN, MODE, PAR_LD, 2>(P, acc, m0 + wm * 64, n0, wn, lane, rs + 2 * (wm * 64), par, tile_n * 2 + wn);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -299,7 +489,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //                            L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
 //   <256, 2, 2>            : wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
 //   <320, 4, 2>            : wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
-template <int BN, int WMW, int NSTAGE>
+template <int BN, int WMW, int NSTAGE, int MODE>
 __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WNW = 8 / WMW;
@@ -430,7 +620,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int row = wn * (TN * 16) + j * 16 + fr;
+      const int row = weight_tile<TN, WNW, MODE == 1>(wn, j) * 16 + fr;
       wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     }
   };
@@ -455,15 +645,22 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   };
 
   const int nsteps = nk - k_begin;
+  LR_STAMP(0);
+  constexpr int PAR_LD = ((BN + 63) / 64) * 64;
+  float* rs = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+  float* par = rs + 2 * BM2;
+  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE; ++sidx)
     if (sidx < nsteps) stage(sidx, k_begin + sidx);
+  LR_STAMP(1);
   f16x8 xa[TM], wa[TN];
   if (nsteps > 0) {
     wait_stages(nsteps > NSTAGE - 1 ? NSTAGE - 1 : nsteps - 1);
     __builtin_amdgcn_s_barrier();
     if constexpr (DB) read_frags(xa, wa, 0, 0);
   }
+  LR_STAMP(2);
   int cur = 0;
   if constexpr (DB) {
     f16x8 xb[TM], wb[TN];
@@ -502,93 +699,24 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
       cur = nxt;
     }
   }
-  __syncthreads();   // every wave is done with the stage buffers before they become the epilogue tile
-
-  // ---- epilogue in four passes of 64 rows (fp32 tile in LDS: 64 x (BNo + 4) floats <= 83 KB)
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int BNo = P.geglu ? BN / 2 : BN;
-  const int ldc = BNo + 4;
-  const int n_out0 = P.geglu ? n0 / 2 : n0;
-  const int N_out = P.geglu ? P.N / 2 : P.N;
-  const int cpr = BNo >> 3;
-  constexpr int UNITS = TM / 4;            // 64-row units per wave tile
-  for (int pass = 0; pass < 4; ++pass) {
-    if (wm == pass / UNITS) {
-      const int i0 = (pass % UNITS) * 4;   // accumulator tile rows i0 .. i0+3 belong to this pass
-      if (!P.geglu) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nl = wn * (TN * 16) + j * 16 + fq * 4;
-          f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (P.bias && P.splits == 1 && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            if (i < i0 || i >= i0 + 4) continue;
-            const int ml = (i - i0) * 16 + fr;
-            *reinterpret_cast<f32x4*>(Cs + ml * ldc + nl) = acc[j][i] + bv;
-          }
-        }
-      } else if constexpr (TN % 2 == 0) {
-#pragma unroll
-        for (int jp = 0; jp < TN / 2; ++jp) {
-          const int nl_u = wn * (TN * 16) + (2 * jp) * 16 + fq * 4;
-          f32x4 bu = (f32x4){0.f, 0.f, 0.f, 0.f}, bg = bu;
-          if (P.bias && n0 + nl_u + 16 < P.N) {
-            bu = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u);
-            bg = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl_u + 16);
-          }
-          const int ol = wn * (TN * 8) + jp * 16 + fq * 4;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            if (i < i0 || i >= i0 + 4) continue;
-            const int ml = (i - i0) * 16 + fr;
-            const f32x4 u = acc[2 * jp][i] + bu, g = acc[2 * jp + 1][i] + bg;
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = u[r] * lr_gelu_erf(g[r]);
-            *reinterpret_cast<f32x4*>(Cs + ml * ldc + ol) = o;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int id = t; id < 64 * cpr; id += GEMM2_THREADS) {
-      const int row = id / cpr, cch = id - row * cpr;
-      const int m = m0 + pass * 64 + row, n = n_out0 + cch * 8;
-      if (m >= P.M || n >= N_out) continue;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8);
-      const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + row * ldc + cch * 8 + 4);
-      if (P.splits > 1) {
-        float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
-        *reinterpret_cast<f32x4*>(dst) = c0;
-        *reinterpret_cast<f32x4*>(dst + 4) = c1;
-        continue;
-      }
-      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      if (P.rowvec) {
-        float e[8];
-        lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += e[i];
-      }
-      if (P.gelu) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
-      }
-      if (P.resid) {
-        float e[8];
-        lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += e[i];
-      }
-      *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
-    }
+  // ---- epilogue straight from the accumulators (see epilogue_units)
+  LR_STAMP(3);
+  if (P.ln_part) {
+    ln_rows_to_lds(P, rs, m0, BM2, t);
     __syncthreads();
   }
+  LR_STAMP(4);
+  epilogue_units<TM, TN, MODE, PAR_LD, WNW>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
+                                            tile_n * WNW + wn);
+  LR_STAMP(5);
+#ifdef LR_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LR_STAMP(6);
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BN, int WMW, int NSTAGE>
+template <int BN, int WMW, int NSTAGE, int MODE>
 static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
@@ -596,16 +724,15 @@ static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
   P.ntiles_m = ntm;
   P.m_fastest = 0;   // measured on MI355X: n-fastest wins even for 3.7 MB weight slices (1038 vs 928 TFLOP/s)
   P.nblocks = P.ntiles_n * ntm;
-  size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128;
-  const size_t epi = (size_t)64 * (BN + 4) * sizeof(float);
-  if (epi > smem) smem = epi;
+  // stages + (mean, rstd) rows + (bias, ln_colsum) columns
+  const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE, MODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE, MODE>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
@@ -648,7 +775,7 @@ __global__ void splitk_reduce_kernel(const GemmParams P) {
   }
 }
 
-template <int BN>
+template <int BN, int MODE>
 static int launch_gemm(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
@@ -656,17 +783,15 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
   P.ntiles_m = ntm;
   P.m_fastest = 0;   // measured on MI355X: n-fastest wins even for 3.7 MB weight slices (1038 vs 928 TFLOP/s)
   P.nblocks = P.ntiles_n * ntm;
-  constexpr int NPASS = BN > 128 ? 2 : 1;
-  size_t smem = 2 * (size_t)(BM + BN) * 128;
-  const size_t epi = (size_t)(BM / NPASS) * (BN + 4) * sizeof(float);
-  if (epi > smem) smem = epi;
+  // stages + (mean, rstd) rows + (bias, ln_colsum) columns
+  const size_t smem = 2 * (size_t)(BM + BN) * 128 + BM * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_conv_kernel<BN>, dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv_kernel<BN, MODE>), dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
@@ -679,6 +804,7 @@ static int launch_reduce(const GemmParams& P, hipStream_t st) {
 }
 
 // split-K heuristic: only when the tile grid cannot fill the chip (256 CUs x 2 resident blocks) and K is long.
+// geglu: the GEGLU / erf-GELU epilogue modes, which are not instantiated for the 160-column tiles
 static void choose_tile(int M, int N, int geglu, int* tm, int* tn) {
   // explicit requests win; otherwise: the 256-row 8-wave kernel for large M when BN divides N, else the 128-row one
   if (*tm == 0 && *tn == 0) {
@@ -707,13 +833,39 @@ static int choose_splits(int M, int N, int K, int tm, int tn, int geglu) {
   return s < 1 ? 1 : s;
 }
 
+// waves along N of the instance that serves tile (tm, tn): each writes one (sum, sumsq) partial per row
+static int tile_wnw(int tm, int tn, int geglu) {
+  if (tm == 128) return 2;
+  if (tn == 256) return 4;
+  if (tn == 320) return geglu ? 2 : 4;
+  return 2;   // 256 x {128, 160}: 4 x 2 waves
+}
+
+extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
+  if (!a || !plan) return LR_E_ARG;
+  const int M = a->B * a->H * a->W;
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  int tn = a->tile_n, tm = a->tile_m;
+  choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
+  plan[0] = tm; plan[1] = tn;
+  plan[2] = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1);
+  return 0;
+}
+
+extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
+  if (!a) return 0;
+  int tn = a->tile_n, tm = a->tile_m;
+  choose_tile(a->B * a->H * a->W, a->N, a->geglu != 0, &tm, &tn);
+  return ((a->N + tn - 1) / tn) * tile_wnw(tm, tn, a->geglu == 1);
+}
+
 extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   if (!a) return 0;
   const int M = a->B * a->H * a->W;
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
   int tn = a->tile_n, tm = a->tile_m;
-  choose_tile(M, a->N, a->geglu, &tm, &tn);
-  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu);
+  choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
+  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1);
   return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
@@ -756,7 +908,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
        (uintptr_t)P.rowvec | (uintptr_t)P.bias) & 15)
     return LR_E_ALIGN;
   int tn = a->tile_n, tm = a->tile_m;
-  choose_tile(P.M, P.N, P.geglu, &tm, &tn);
+  choose_tile(P.M, P.N, P.geglu || P.gelu, &tm, &tn);
   int splits = a->splits;
   if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu);
   if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
@@ -769,17 +921,44 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   }
   P.splits = splits;
   P.ws = a->workspace;
+  // LayerNorm fold (pointwise, single source, K = normalised width) and per-row output statistics
+  P.ln_part = a->ln_stats; P.ln_cs = a->ln_colsum; P.ln_parts = a->ln_parts; P.ln_eps = a->ln_eps;
+  P.ln_invc = 1.0f / (float)P.K;
+  if (P.ln_part) {
+    if (!P.ln_cs || P.ln_parts <= 0 || P.taps != 1 || P.C2 || splits > 1) return LR_E_ARG;
+    if (((uintptr_t)P.ln_part & 7) || ((uintptr_t)P.ln_cs & 15)) return LR_E_ALIGN;
+  }
+#ifdef LR_GEMM_TRACE
+  P.trace = g_trace;
+#endif
+  P.st_out = a->stats_out;
+  P.st_parts = ((P.N + tn - 1) / tn) * tile_wnw(tm, tn, P.geglu);
+  if (P.st_out && (splits > 1 || ((uintptr_t)P.st_out & 7))) return LR_E_ARG;
   hipStream_t st = (hipStream_t)s;
   int rc;
-  if (tm == 128 && tn == 128) rc = launch_gemm<128>(P, st);
-  else if (tm == 128 && tn == 64) rc = launch_gemm<64>(P, st);
-  else if (tm == 128 && tn == 160 && !P.geglu) rc = launch_gemm<160>(P, st);
-  else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3>(P, st);
-  else if (tm == 256 && tn == 160 && !P.geglu) rc = launch_gemm256<160, 4, 3>(P, st);
-  else if (tm == 256 && tn == 256) rc = launch_gemm256<256, 2, 2>(P, st);                 // wave tile 128 x 64
-  else if (tm == 256 && tn == 320 && !P.geglu) rc = launch_gemm256<320, 2, 2>(P, st);
-  else if (tm == 256 && tn == 320 && P.geglu) rc = launch_gemm256<320, 4, 2>(P, st);   // wave tile 64 x 160: even TN
-  else return LR_E_UNSUPPORTED;
+  const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
+  if (mode == 0) {
+    if (tm == 128 && tn == 128) rc = launch_gemm<128, 0>(P, st);
+    else if (tm == 128 && tn == 64) rc = launch_gemm<64, 0>(P, st);
+    else if (tm == 128 && tn == 160) rc = launch_gemm<160, 0>(P, st);
+    else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 0>(P, st);
+    else if (tm == 256 && tn == 160) rc = launch_gemm256<160, 4, 3, 0>(P, st);
+    else if (tm == 256 && tn == 256) rc = launch_gemm256<256, 2, 2, 0>(P, st);                 // wave tile 128 x 64
+    else if (tm == 256 && tn == 320) rc = launch_gemm256<320, 2, 2, 0>(P, st);                 // wave tile 128 x 80
+    else return LR_E_UNSUPPORTED;
+  } else if (mode == 1) {
+    if (tm == 128 && tn == 128) rc = launch_gemm<128, 1>(P, st);
+    else if (tm == 128 && tn == 64) rc = launch_gemm<64, 1>(P, st);
+    else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 1>(P, st);
+    else if (tm == 256 && tn == 256) rc = launch_gemm256<256, 2, 2, 1>(P, st);
+    else if (tm == 256 && tn == 320) rc = launch_gemm256<320, 4, 2, 1>(P, st);                 // wave tile 64 x 160: even TN
+    else return LR_E_UNSUPPORTED;
+  } else {   // erf-GELU epilogue (text tower MLP): the small-tile instances only
+    if (tm == 128 && tn == 128) rc = launch_gemm<128, 2>(P, st);
+    else if (tm == 128 && tn == 64) rc = launch_gemm<64, 2>(P, st);
+    else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 2>(P, st);
+    else return LR_E_UNSUPPORTED;
+  }
   if (rc || P.splits == 1) return rc;
   return launch_reduce(P, st);
 }

@@ -96,12 +96,12 @@ class CrossAttention(nn.Module):
         tok, B, L = engine.to_tokens(x)
         if context is None:
             pa = _cached(self, "self", lambda: engine.PackedAttn(self, True))
-            y = engine.self_attention(tok, pa, B, L, None)
+            y = engine.attention_plain(tok, None, pa, B, L)
         else:
             ctok, Bc, Lc = engine.to_tokens(context)
             assert Bc == B
             pa = _cached(self, "cross", lambda: engine.PackedAttn(self, False))
-            y = engine.cross_attention(tok, ctok, pa, B, L, Lc, None)
+            y = engine.attention_plain(tok, ctok, pa, B, L, Lc)
         return y.reshape(B, L, -1).to(x.dtype)
 
 
@@ -132,7 +132,7 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, context=None):
         tok, B, L = engine.to_tokens(x)
         ctok, _, Lc = engine.to_tokens(context)
-        y = engine.transformer_block(tok, ctok, self._packed(), B, L, Lc)
+        y, _ = engine.transformer_block(tok, ctok, self._packed(), B, L, Lc)
         return y.reshape(B, L, -1).to(x.dtype)
 
 

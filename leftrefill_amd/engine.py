@@ -60,7 +60,10 @@ class PackedConv:
 
 
 class PackedLinear:
-    def __init__(self, lin=None, weight=None, bias=None):
+    """norm: the nn.LayerNorm that feeds this Linear -- a second, LayerNorm-folded copy of the weights is packed next
+    to the plain one (`wf`, `bf`, `cs`, see packing.fold_layernorm) for the inference path."""
+
+    def __init__(self, lin=None, weight=None, bias=None, norm=None):
         if lin is not None:
             weight, bias = lin.weight, lin.bias
         w = weight.detach()
@@ -68,6 +71,11 @@ class PackedLinear:
             w = w.reshape(w.shape[0], w.shape[1])
         self.w = packing.pack_linear(w)
         self.b = f32(bias) if bias is not None else None
+        self.wf = None
+        if norm is not None:
+            self.wf, self.bf, self.cs = packing.fold_layernorm(w, None if bias is None else bias.detach(),
+                                                               norm.weight.detach(), norm.bias.detach())
+            self.eps = float(norm.eps)
 
 
 class PackedNorm:
@@ -94,13 +102,13 @@ class PackedRes:
 class PackedAttn:
     """attn1: fused [q;k;v] projection; attn2: q projection + fused [k;v] projection of the context."""
 
-    def __init__(self, attn, is_self):
+    def __init__(self, attn, is_self, norm=None):
         self.heads = attn.heads
         self.is_self = is_self
         if is_self:
-            self.qkv = PackedLinear(weight=torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0))
+            self.qkv = PackedLinear(weight=torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0), norm=norm)
         else:
-            self.q = PackedLinear(weight=attn.to_q.weight)
+            self.q = PackedLinear(weight=attn.to_q.weight, norm=norm)
             self.kv = PackedLinear(weight=torch.cat([attn.to_k.weight, attn.to_v.weight], 0))
         self.out = PackedLinear(attn.to_out[0])
         self.dim_head = attn.to_q.weight.shape[0] // attn.heads
@@ -112,11 +120,16 @@ class PackedTBlock:
     def __init__(self, blk):
         if getattr(blk, "disable_self_attn", False):
             raise RuntimeError("disable_self_attn=True is not used by LeftRefill configs and is unsupported")
-        self.attn1 = PackedAttn(blk.attn1, True)
-        self.attn2 = PackedAttn(blk.attn2, False)
+        self.attn1 = PackedAttn(blk.attn1, True, blk.norm1)
+        self.attn2 = PackedAttn(blk.attn2, False, blk.norm2)
         self.n1, self.n2, self.n3 = PackedNorm(blk.norm1), PackedNorm(blk.norm2), PackedNorm(blk.norm3)
         proj = blk.ff.net[0].proj
         self.geglu_w, self.geglu_b = packing.pack_geglu(proj.weight.detach(), proj.bias.detach())
+        # LayerNorm(norm3)-folded copy of the GEGLU projection (rows in the same interleaved order)
+        wf, bf, cs = packing.fold_layernorm(proj.weight.detach(), proj.bias.detach(), blk.norm3.weight.detach(),
+                                            blk.norm3.bias.detach())
+        perm = packing.geglu_perm(proj.weight.shape[0] // 2, proj.weight.device)
+        self.geglu_wf, self.geglu_bf, self.geglu_cs = wf[perm].contiguous(), bf[perm].contiguous(), cs[perm].contiguous()
         self.ff2 = PackedLinear(blk.ff.net[2])
         # multi-view attributes (None for the single-view block)
         self.kv_slot = None   # index into the per-context K/V projection cache (set by UNetModel.prepare)
@@ -136,9 +149,22 @@ class PackedST:
 # ---------------------------------------------------------------------------------------------------------------
 # functional blocks
 # ---------------------------------------------------------------------------------------------------------------
-def linear(x, pl: PackedLinear, resid=None, M=None):
+def linear(x, pl: PackedLinear, resid=None, M=None, want_stats=False):
     M = x.shape[0] if M is None else M
-    return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid)
+    return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid, want_stats=want_stats)
+
+
+def fold_ok(x):
+    """The LayerNorm-folded GEMMs are inference kernels (no backward): use them unless autograd needs the LayerNorm."""
+    return LN_FOLD and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear):
+    """Linear(LayerNorm(x)).  st: per-row (sum, sumsq) partials of x from the GEMM that produced it, or None.
+    With st the LayerNorm is folded into the GEMM (no normalised tensor is written); otherwise the LayerNorm kernel runs."""
+    if st is not None and pl.wf is not None and fold_ok(x):
+        return ops.gemm_conv(x, pl.wf, B=1, H=1, W=x.shape[0], taps=1, bias=pl.bf, ln=(st, pl.eps, pl.cs))
+    return linear(ops.layer_norm(x, pn.g, pn.b, pn.eps), pl)
 
 
 def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False):
@@ -174,32 +200,44 @@ def resblock(act: Act, pr: PackedRes, emb_out):
     return conv(h, pr.c2, resid=resid)
 
 
-def self_attention(x, pa: PackedAttn, B, L, resid):
-    C = x.shape[1]
-    qkv = linear(x, pa.qkv)
+def attention_plain(x, ctx, pa: PackedAttn, B, L, Lc=None):
+    """CrossAttention.forward on its own (attention.py:165-196): to_out(attention(x Wq, c Wk, c Wv)), c = x when self."""
+    if pa.is_self:
+        a = ops.attention_qkv(linear(x, pa.qkv), B, pa.heads, L, pa.dim_head ** -0.5)
+    else:
+        a = ops.attention_q_kv(linear(x, pa.q), linear(ctx, pa.kv), B, pa.heads, L, Lc, pa.dim_head ** -0.5)
+    return linear(a, pa.out)
+
+
+def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False):
+    """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None)."""
+    qkv = ln_linear(x, st, pn, pa.qkv)
     a = ops.attention_qkv(qkv, B, pa.heads, L, pa.dim_head ** -0.5)
-    return linear(a, pa.out, resid=resid)
+    return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def cross_attention(x, ctx, pa: PackedAttn, B, L, Lc, resid, kv=None):
-    """kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T, V^T in the attention kernel's layout) -- constant over the
-    DDIM steps, see UNetModel._context_kv."""
-    q = linear(x, pa.q)
+def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False):
+    """x + to_out(attention(LayerNorm(x) Wq, ctx Wk, ctx Wv)).  kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T,
+    V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv."""
+    q = ln_linear(x, st, pn, pa.q)
     vt = None
     if kv is None:
         kv = linear(ctx, pa.kv)
     else:
         kv, vt = kv
     a = ops.attention_q_kv(q, kv, B, pa.heads, L, Lc, pa.dim_head ** -0.5, vt=vt)
-    return linear(a, pa.out, resid=resid)
+    return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None):
-    """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468."""
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False):
+    """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468.
+    st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None)."""
+    ws = fold_ok(x)       # ask the residual GEMMs for the row statistics the next LayerNorm needs
     if pt.view_num is None:
-        x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, N, L, x)
+        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws)
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
         x = _mv_sharded_self_attention(x, pt, N, L)
+        ws = False
     elif pt.concat_target and not pt.no_rearrange:
         v = pt.view_num - 1
         b = N // v
@@ -207,18 +245,31 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None):
         assert 2 * s * s == L and b * v == N, "concat_target needs square halves and batch = b*(view_num-1)"
         seq = ops.mv_gather(x, b, v, s)
         Ls = pt.view_num * s * s
-        seq = self_attention(ops.layer_norm(seq, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, b, Ls, seq)
+        seq = self_attention(seq, None, pt.n1, pt.attn1, b, Ls)
         x = ops.mv_scatter(seq, b, v, s)
+        ws = False
     else:
         v = pt.view_num - 1 if pt.concat_target else pt.view_num
         b = N // v
         assert b * v == N
-        x = self_attention(ops.layer_norm(x, pt.n1.g, pt.n1.b, pt.n1.eps), pt.attn1, b, v * L, x)
-    x = cross_attention(ops.layer_norm(x, pt.n2.g, pt.n2.b, pt.n2.eps), ctx, pt.attn2, N, L, Lc, x, kv)
-    n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
-    g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
-    return linear(g, pt.ff2, resid=x)
+        x = self_attention(x, st, pt.n1, pt.attn1, b, v * L, want_stats=ws)
+    x, st = x if ws else (x, None)
+    ws = fold_ok(x)
+    x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws)
+    x, st = x if ws else (x, None)
+    if st is not None:
+        g = ops.gemm_conv(x, pt.geglu_wf, B=1, H=1, W=x.shape[0], taps=1, bias=pt.geglu_bf, geglu=True,
+                          ln=(st, pt.n3.eps, pt.geglu_cs))
+    else:
+        n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
+        g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
+    ws = want_stats and fold_ok(x)
+    y = linear(g, pt.ff2, resid=x, want_stats=ws)
+    return y if ws else (y, None)
 
+
+# LayerNorm folded into the consuming GEMM (inference path); LEFTREFILL_LN_FOLD=0 runs the stand-alone LayerNorm kernel.
+LN_FOLD = __import__("os").environ.get("LEFTREFILL_LN_FOLD", "1") != "0"
 
 # One canvas per rank (torch.distributed world == view_num - 1): set by UNetModel when `mv_shard=True`.
 MV_SHARDED = False
@@ -251,10 +302,12 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
 def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):
     x_in = act.materialize()
     h = gn(Act(x_in, act.N, act.H, act.W), ps.norm, False).tok
-    h = linear(h, ps.proj_in)
-    for pt in ps.blocks:
+    ws = fold_ok(h)
+    h = linear(h, ps.proj_in, want_stats=ws)
+    h, st = h if ws else (h, None)
+    for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
-        h = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv)
+        h, st = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=i + 1 < len(ps.blocks))
     y = linear(h, ps.proj_out, resid=x_in)
     return Act(y, act.N, act.H, act.W)
 

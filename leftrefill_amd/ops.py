@@ -3,6 +3,7 @@
 PyTorch is used only for device memory and streams (`torch.cuda.current_stream()` is the HIP stream on ROCm).
 Activations are NHWC / token-major fp16: a tensor [M, C] with M = N*H*W rows.
 """
+import ctypes
 import os
 
 import torch
@@ -12,16 +13,34 @@ from ._lib import GemmArgs
 
 GN_CHUNKS = 256
 
-# ---- tile autotuner for lr_gemm_conv_f16 ------------------------------------------------------------------------
-# The UNet has ~50 distinct static GEMM shapes.  On first sight of a shape (eager warm-up before hipGraph capture) every
-# tile configuration is timed with HIP events and the fastest is cached.  All tile configurations accumulate K in the
-# same order, so the choice never changes results bit-wise (split-K stays a deterministic function of the shape).
-AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "1") != "0"
+# ---- tile plan of lr_gemm_conv_f16 ----------------------------------------------------------------------------------
+# The UNet has ~60 distinct static GEMM shapes.  Their (tile_m, tile_n, splits) come from an IN-TREE table
+# (tile_table.json, produced on an MI355X by tools/tune_tiles.py and committed): the plan is a pure function of the
+# shape, identical in every process and on every rank, so results are bit-reproducible across runs (the split-K factor
+# changes fp32 rounding) and the replicated rows of the sharded multi-view path are bit-identical on every rank.
+# Shapes missing from the table use the library's static heuristic (also a pure function of the shape).
+# LEFTREFILL_AUTOTUNE=1 is a developer mode: unknown shapes are timed on first sight and added to the in-memory table
+# (dump it with tile_cache()); it is never on by default.
+AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "0") == "1"
 TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320))
-_tile_cache = {}
+TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+_tile_cache = None
+
+
+def tile_key(M, N, K, taps=1, stride=1, up=0, geglu=False, concat=False, asym=False, gelu=False, ln=False, stats=False):
+    return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (M, N, K, taps, stride, up, int(geglu), int(concat), int(asym),
+                                                      int(gelu), int(ln), int(stats))
 
 
 def tile_cache():
+    """shape key -> [tile_m, tile_n, splits]; loaded once from the in-tree table."""
+    global _tile_cache
+    if _tile_cache is None:
+        _tile_cache = {}
+        if os.path.exists(TILE_TABLE_PATH) and os.environ.get("LEFTREFILL_TILE_TABLE", "1") != "0":
+            import json
+            with open(TILE_TABLE_PATH) as f:
+                _tile_cache = {k: tuple(v) for k, v in json.load(f).items()}
     return _tile_cache
 
 
@@ -112,8 +131,12 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0):
-    """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16."""
+              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, ln=None, want_stats=False):
+    """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
+
+    ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
+    are the gamma / beta folded weights, see lr_gemm_args).  want_stats: also return the per-row (sum, sumsq) partials of
+    the output, [M, parts, 2] fp32 -- the `stats` a following LayerNorm-folded GEMM consumes; returns (out, stats)."""
     lib = _lib.load()
     _chk16(x1, "x1")
     _chk16(wt, "wt")
@@ -150,18 +173,47 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.tile_m = tile_m
     a.splits = splits
     a.workspace, a.workspace_bytes = 0, 0
+    a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out = 0, 0, 0.0, 0, 0
+    if ln is not None:
+        st_in, eps, colsum = ln
+        assert st_in.dtype == torch.float32 and st_in.is_contiguous() and st_in.shape[0] == M and st_in.shape[2] == 2
+        assert colsum.dtype == torch.float32 and colsum.numel() == Nw and taps == 1 and x2 is None
+        a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum = _p(st_in), st_in.shape[1], float(eps), _p(colsum)
     st = _stream()
-    if tile_m == 0 and tile_n == 0 and AUTOTUNE:
-        key = (M, Nw, wt.shape[1], taps, stride, up, bool(geglu), C2 > 0, x1.device.index, bool(asym), bool(gelu))
-        best = _tile_cache.get(key)
-        if best is None and not torch.cuda.is_current_stream_capturing():
-            best = _tune_tiles(lib, a, x1.device, geglu)
-            _tile_cache[key] = best
+    if tile_m == 0 and tile_n == 0 and splits == 0:
+        key = tile_key(M, Nw, wt.shape[1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
+        best = tile_cache().get(key)
+        if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)
+            tile_cache()[key] = best
         if best is not None:
-            a.tile_m, a.tile_n = best
+            a.tile_m, a.tile_n, a.splits = best
+    stats = None
+    if want_stats:
+        if a.splits == 0:
+            a.splits = 1     # row statistics come out of the epilogue: no split-K
+        parts = lib.lr_gemm_stats_parts(a)
+        stats = torch.empty(M, parts, 2, device=x1.device, dtype=torch.float32)
+        a.stats_out = _p(stats)
+    if ln is not None and a.splits == 0:
+        a.splits = 1
     ws = _workspace(lib, a, x1.device)
     _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
-    return out
+    return (out, stats) if want_stats else out
+
+
+def gemm_plan(M, N, K, **kw):
+    """(tile_m, tile_n, splits) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
+    best = tile_cache().get(tile_key(M, N, K, **kw))
+    if best is not None:
+        return tuple(best)
+    lib = _lib.load()
+    a = GemmArgs()
+    a.B, a.H, a.W, a.N, a.taps, a.C1 = 1, 1, M, N, kw.get("taps", 1), K // kw.get("taps", 1)
+    a.geglu = int(kw.get("geglu", False))
+    plan = (ctypes.c_int32 * 3)()
+    _lib.check(lib.lr_gemm_plan(a, plan), "gemm_plan")
+    return tuple(plan)
 
 
 def _workspace(lib, a, device):
@@ -175,29 +227,47 @@ def _workspace(lib, a, device):
     return ws
 
 
-def _tune_tiles(lib, a, device, geglu, reps=4, rounds=2):
-    """Time every tile configuration (best of `rounds` x `reps` launches) and return the fastest."""
+def _time_launch(lib, a, st, reps, rounds):
+    t = float("inf")
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.lr_gemm_conv_f16(a, st)
+        e1.record()
+        e1.synchronize()
+        t = min(t, e0.elapsed_time(e1))
+    return t
+
+
+def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
+    """Developer mode: time every (tile, split-K) configuration and return the fastest (tile_m, tile_n, splits)."""
     st = _stream()
     best, best_t = None, float("inf")
+    plan = (ctypes.c_int32 * 3)()
     for tm, tn in TILE_CANDIDATES:
         if geglu and tn == 160:
             continue
-        a.tile_m, a.tile_n = tm, tn
-        ws = _workspace(lib, a, device)
-        if lib.lr_gemm_conv_f16(a, st) != 0:
-            continue
-        t = float("inf")
-        for _ in range(rounds):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                lib.lr_gemm_conv_f16(a, st)
-            e1.record()
-            e1.synchronize()
-            t = min(t, e0.elapsed_time(e1))
-        del ws
-        if t < best_t:
-            best, best_t = (tm, tn), t
+        a.tile_m, a.tile_n, a.splits = tm, tn, 0
+        lib.lr_gemm_plan(a, plan)
+        cands = {1} if no_split else {1, int(plan[2])}
+        for sp in sorted(cands):
+            a.splits = sp
+            stats = None
+            if want_stats:
+                parts = lib.lr_gemm_stats_parts(a)
+                stats = torch.empty(a.B * a.H * a.W, parts, 2, device=device, dtype=torch.float32)
+                a.stats_out = stats.data_ptr()
+            ws = _workspace(lib, a, device)
+            if sp > 1 and ws is None:
+                continue
+            if lib.lr_gemm_conv_f16(a, st) != 0:
+                continue
+            t = _time_launch(lib, a, st, reps, rounds)
+            del ws, stats
+            if t < best_t:
+                best, best_t = (tm, tn, sp), t
+    a.stats_out = 0
     return best
 
 

@@ -46,3 +46,16 @@ def pack_geglu(w, b):
     n_half = w.shape[0] // 2
     perm = geglu_perm(n_half, w.device)
     return w[perm].to(torch.float16).contiguous(), b[perm].float().contiguous()
+
+
+def fold_layernorm(w, b, gamma, beta):
+    """Linear(LayerNorm(x)) as ONE GEMM on the raw x (lr_gemm_args.ln_stats):
+        y = rstd * (x @ Wf^T - mean * cs) + bf,   Wf = W * gamma (fp16),  cs[n] = sum_k Wf[n][k],  bf = W @ beta + b.
+    cs is taken from the fp16-ROUNDED Wf so that it cancels exactly what the matrix cores accumulate."""
+    w32 = w.float()
+    wf = (w32 * gamma.float()[None, :]).to(torch.float16).contiguous()
+    cs = wf.float().sum(dim=1).contiguous()
+    bf = w32 @ beta.float()
+    if b is not None:
+        bf = bf + b.float()
+    return wf, bf.contiguous(), cs

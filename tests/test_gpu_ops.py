@@ -261,6 +261,79 @@ def test_conv_golden_cases(golden):
         report("golden " + name, from_tok(y, N, H, W), torch.from_numpy(g[name]), rtol=4e-3, atol=4e-3)
 
 
+ALL_TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)]
+
+
+@pytest.mark.parametrize("tm,tn", ALL_TILES)
+def test_gemm_row_stats_and_layernorm_fold(tm, tn):
+    """LayerNorm folded into the consumer GEMM (lr_gemm_args.ln_stats): the producer's epilogue writes per-row
+    (sum, sumsq) partials of its fp16 output, the consumer normalises inside its own epilogue.  Checked against
+    F.linear(F.layer_norm(x)) in fp32 on the same fp16-rounded x (attention.py:271-283 semantics), every tile."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    for C, N2, M in ((320, 960, 700), (640, 640, 300), (1280, 320, 130)):
+        name = f"lnf{C}_{tm}x{tn}"
+        a = h16(G.T(name + ".a", (M, C)))
+        w0 = h16(torch.from_numpy(weights.fill_like(name + ".w0", (C, C))))
+        b0 = torch.from_numpy(weights.fill_like(name + ".b0", (C,)))
+        r0 = h16(G.T(name + ".r0", (M, C)) * 3.0 + 0.7)          # non-zero mean rows
+        x_ref = (F.linear(a, w0, b0) + r0).half()                 # what the producer stores
+        x, st = ops.gemm_conv(a.half().to(d), w0.half().to(d), B=1, H=1, W=M, taps=1, bias=b0.to(d), resid=r0.half().to(d),
+                              tile_m=tm, tile_n=tn, want_stats=True)
+        report(name + " producer", x, x_ref.float())
+        xs = x.float()
+        s = st.sum(dim=1)
+        assert torch.allclose(s[:, 0].cpu(), xs.sum(1).cpu(), rtol=1e-5, atol=1e-3), name
+        assert torch.allclose(s[:, 1].cpu(), (xs * xs).sum(1).cpu(), rtol=1e-5, atol=1e-3), name
+        # consumer: Linear(LayerNorm(x)) with non-trivial gamma / beta
+        gam = 1.0 + 0.3 * G.T(name + ".g", (C,))
+        bet = 0.2 * G.T(name + ".be", (C,))
+        w1 = h16(torch.from_numpy(weights.fill_like(name + ".w1", (N2, C))))
+        b1 = torch.from_numpy(weights.fill_like(name + ".b1", (N2,)))
+        xc = x.float().cpu()
+        ref = F.linear(F.layer_norm(xc, (C,), gam, bet, 1e-5), w1, b1)
+        wf, bf, cs = packing.fold_layernorm(w1, b1, gam, bet)
+        y = ops.gemm_conv(x, wf.to(d), B=1, H=1, W=M, taps=1, bias=bf.to(d), ln=(st, 1e-5, cs.to(d)), tile_m=tm, tile_n=tn)
+        # two fp16 roundings differ from the reference pipeline (gamma folded into W; no rounded LayerNorm output)
+        report(name + " consumer", y, ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("tm,tn", [(128, 64), (128, 128), (256, 128), (256, 256), (256, 320)])
+def test_geglu_layernorm_fold(tm, tn):
+    from leftrefill_amd import ops, packing
+    d = dev()
+    C, M = 320, 520
+    name = f"lng_{tm}x{tn}"
+    x = h16(G.T(name + ".x", (M, C)) * 2.0 + 0.3)
+    gam = 1.0 + 0.3 * G.T(name + ".g", (C,))
+    bet = 0.2 * G.T(name + ".be", (C,))
+    w = h16(torch.from_numpy(weights.fill_like(name + ".w", (8 * C, C))))
+    b = torch.from_numpy(weights.fill_like(name + ".b", (8 * C,)))
+    u, gate = F.linear(F.layer_norm(x, (C,), gam, bet, 1e-5), w, b).chunk(2, dim=-1)
+    ref = u * F.gelu(gate)
+    st = torch.stack([x.sum(1), (x * x).sum(1)], dim=1).reshape(M, 1, 2).contiguous().to(d)
+    wf, bf, cs = packing.fold_layernorm(w, b, gam, bet)
+    perm = packing.geglu_perm(4 * C)
+    y = ops.gemm_conv(x.half().to(d), wf[perm].contiguous().to(d), B=1, H=1, W=M, taps=1, bias=bf[perm].contiguous().to(d),
+                      geglu=True, ln=(st, 1e-5, cs[perm].contiguous().to(d)), tile_m=tm, tile_n=tn)
+    report(name, y, ref, rtol=4e-3, atol=4e-3)
+
+
+def test_tile_plan_is_static_and_tiles_agree_bitwise():
+    """The (tile, split-K) plan is a pure function of the shape (in-tree table or the static heuristic -- never timing),
+    and with the split factor pinned every tile gives bit-identical results (same K order per output element)."""
+    from leftrefill_amd import ops
+    d = dev()
+    assert not ops.AUTOTUNE, "timing-based tile selection must be opt-in"
+    assert ops.gemm_plan(1024, 1280, 11520, taps=9) == ops.gemm_plan(1024, 1280, 11520, taps=9)
+    x = h16(G.T("tp.x", (300, 2560))).half().to(d)
+    w = h16(torch.from_numpy(weights.fill_like("tp.w", (640, 2560)))).half().to(d)
+    for splits in (1, 4):
+        ys = [ops.gemm_conv(x, w, B=1, H=1, W=300, taps=1, tile_m=tm, tile_n=tn, splits=splits) for tm, tn in ALL_TILES]
+        for (tm, tn), y in zip(ALL_TILES[1:], ys[1:]):
+            assert torch.equal(y, ys[0]), f"tile {tm}x{tn} differs bitwise from {ALL_TILES[0]} at splits={splits}"
+
+
 def test_geglu_epilogue():
     from leftrefill_amd import ops, packing
     d = dev()

@@ -1,0 +1,80 @@
+"""Developer tool (MI355X only): time every (tile, split-K) plan for every GEMM shape of the shipped workloads and write
+the table that `leftrefill_amd/tile_table.json` ships in-tree.
+
+    LEFTREFILL_AUTOTUNE=1 python tools/tune_tiles.py [--out gpurun_out/tile_table.json] [--workloads single,cfg0,mv5,train,vae]
+
+The product never times anything: ops.gemm_conv looks the plan up in the committed table (a pure function of the shape).
+"""
+import argparse
+import json
+import os
+import sys
+
+os.environ["LEFTREFILL_AUTOTUNE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from leftrefill_amd import ops  # noqa: E402
+
+
+def unet_pass(model, B, h, w, device):
+    unet = model.model.diffusion_model
+    batch = bench.synthetic_batch(B, h, w, device, 7)
+    c_concat, c_cross, uc_cross, x_T = batch
+    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+    t = torch.full((2 * B,), 501, device=device, dtype=torch.long)
+    ctx = torch.cat([uc_cross, c_cross]).half()
+    unet.use_hip_graph = False
+    with torch.no_grad():
+        unet(x, t, ctx)
+    torch.cuda.synchronize()
+    unet.use_hip_graph = True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table.json"))
+    ap.add_argument("--workloads", default="single,cfg0,mv5,train,vae")
+    ap.add_argument("--fresh", action="store_true", help="ignore the committed table (re-tune every shape)")
+    a = ap.parse_args()
+    assert ops.AUTOTUNE
+    if a.fresh:
+        ops.tile_cache().clear()
+    device = torch.device("cuda:0")
+    wl = a.workloads.split(",")
+    model = None
+    if "single" in wl or "cfg0" in wl or "train" in wl:
+        model = bench.build_model(device, "single")
+    if "single" in wl:
+        unet_pass(model, 4, 64, 128, device)
+        print("single:", len(ops.tile_cache()), "shapes", flush=True)
+    if "cfg0" in wl:
+        unet_pass(model, 1, 32, 64, device)
+        print("cfg0:", len(ops.tile_cache()), "shapes", flush=True)
+    if "train" in wl:
+        class A:
+            steps, warmup, recompute, train_graph = 1, 1, False, False
+        bench.train_bench(A, 0, 1, device, model=model, steps=1)
+        print("train:", len(ops.tile_cache()), "shapes", flush=True)
+    if "mv5" in wl:
+        del model
+        torch.cuda.empty_cache()
+        mv = bench.build_model(device, "mv5")
+        unet_pass(mv, 4, 64, 128, device)
+        del mv
+        print("mv5:", len(ops.tile_cache()), "shapes", flush=True)
+    if "vae" in wl:
+        torch.cuda.empty_cache()
+        bench.vae_timing(4, device)
+        print("vae:", len(ops.tile_cache()), "shapes", flush=True)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump({k: list(v) for k, v in sorted(ops.tile_cache().items())}, f, indent=0)
+    print("wrote", a.out, len(ops.tile_cache()), "entries")
+
+
+if __name__ == "__main__":
+    main()
