@@ -86,3 +86,16 @@ __device__ __forceinline__ uint4 lr_pack8(const float* f) {
   for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
   return __builtin_bit_cast(uint4, h);
 }
+
+// Buffer descriptor from provably wave-uniform pieces (readfirstlane), otherwise hipcc wraps every buffer op in a
+// waterfall loop (guide T20).  The descriptor type only exists in the device pass of hipcc, hence the guard (the host
+// pass still has to see the kernel declaration to emit its launch stub).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, size_t bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+}
+#endif

@@ -57,18 +57,6 @@ __device__ __forceinline__ void tile_order(const GemmParams& P, int bid, int& ti
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Buffer descriptor from provably wave-uniform pieces (readfirstlane), otherwise hipcc wraps every buffer op in a
-// waterfall loop (guide T20).  The descriptor type only exists in the device pass of hipcc, hence the guard (the host
-// pass still has to see the kernel declaration to emit its launch stub).
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, size_t bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const int n = __builtin_amdgcn_readfirstlane((int)bytes);
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
-}
-#endif
 
 // =====================================================================================================================
 // Register epilogue shared by both kernels: no LDS staging, no barriers, every wave drains its own accumulators.
