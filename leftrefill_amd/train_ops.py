@@ -95,6 +95,10 @@ class _GemmConv(torch.autograd.Function):
 def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
     if not _needs_grad(x1, x2, resid):
         return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
+    if kw.get("ln") is not None:
+        raise NotImplementedError("the LayerNorm-folded GEMM is an inference kernel; differentiate layer_norm + gemm_conv")
+    if kw.pop("want_stats", False):     # row statistics feed the LayerNorm fold of the NEXT GEMM: not used under autograd
+        return gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw), None
     if rowvec is not None and rowvec.requires_grad:
         raise NotImplementedError("gradient w.r.t. the time embedding is not produced (nothing trainable sits upstream of it)")
     if kw.get("out") is not None:
