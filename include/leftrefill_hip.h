@@ -53,6 +53,14 @@ int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int
                        lr_stream_t s);
 int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                        const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
+/* Statistics from the producers instead of a pass over x: p1 / p2 = gn_stats_out of the GEMMs that wrote x1 / x2
+ * ([M / R1][C1][2], [M / R2][C2][2], M = N*HW; R1, R2 must divide HW).  finalize reduces them (fp64, fixed order) to
+ * group sums in the layout lr_groupnorm_apply_n reads with nchunks = 1: partials [N][1][32][2]. */
+int lr_groupnorm_finalize(const float* p1, int C1, int R1, const float* p2, int C2, int R2, int N, int HW, float* partials,
+                          lr_stream_t s);
+/* lr_groupnorm_apply with an explicit chunk count of `partials` ([N][nchunks][32][2]) */
+int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
+                         int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
 
 /* ---- LayerNorm over the channel dimension -------------------------------------------------------------------------
  * replaces: nn.LayerNorm norm1/2/3 in BasicTransformerBlock (attention.py:271-273, eps 1e-5). x,y [M][C] fp16. */
@@ -115,7 +123,14 @@ typedef struct lr_gemm_args {
   /* stats_out != NULL: per-row (sum, sumsq) of the fp16-rounded output over each wave's column range,
    * [M][lr_gemm_stats_parts(args)][2] fp32 (fixed order, no atomics). Not with split-K. */
   float* stats_out;
+  /* gn_stats_out != NULL: per-channel (sum, sumsq) of the fp16-rounded output over each block of R = lr_gemm_gn_rows(args)
+   * consecutive rows, [ceil(M / R)][N][2] fp32 -- the statistics pass of the GroupNorm that consumes this tensor
+   * (openaimodel.py:254-274) comes out of the producer's epilogue; lr_groupnorm_finalize turns the blocks of one sample
+   * (H*W must be a multiple of R) into per-group sums.  Fixed order, no atomics.  Not with split-K or GEGLU. */
+  float* gn_stats_out;
 } lr_gemm_args;
+/* rows per block of gn_stats_out (a function of the tile that will be used) */
+int lr_gemm_gn_rows(const lr_gemm_args* args);
 /* plan[0..2] = (tile_m, tile_n, splits) the call would use: explicit requests as given, zeros resolved by the static
  * heuristics (a pure function of the shape -- never of timing; the Python front end ships its tuned choices as a table). */
 int lr_gemm_plan(const lr_gemm_args* args, int32_t* plan);

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -35,6 +35,7 @@ class GemmArgs(ctypes.Structure):
         ("ln_stats", c_void_p), ("ln_parts", ctypes.c_int32), ("ln_eps", ctypes.c_float),
         ("ln_colsum", c_void_p),
         ("stats_out", c_void_p),
+        ("gn_stats_out", c_void_p),
     ]
 
 
@@ -68,6 +69,10 @@ SIGNATURES = {
                           c_void_p],
     "lr_gemm_workspace_bytes": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_stats_parts": [ctypes.POINTER(GemmArgs)],
+    "lr_gemm_gn_rows": [ctypes.POINTER(GemmArgs)],
+    "lr_groupnorm_finalize": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "lr_groupnorm_apply_n": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float,
+                             c_int, c_void_p, c_void_p],
     "lr_gemm_plan": [ctypes.POINTER(GemmArgs), ctypes.POINTER(ctypes.c_int32)],
     "lr_gemm_conv_f16": [ctypes.POINTER(GemmArgs), c_void_p],
     "lr_attention_f16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,

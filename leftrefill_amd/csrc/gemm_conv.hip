@@ -33,6 +33,9 @@ struct GemmParams {
   const float* ln_part; const float* ln_cs; int ln_parts; float ln_eps, ln_invc;
   // per-row (sum, sumsq) of THIS GEMM's fp16 output over each wave's column range: st_out[m][st_parts][2]
   float* st_out; int st_parts;
+  // per-channel (sum, sumsq) of this GEMM's fp16 output over each wave's rows: gs_out[row block][N][2], row block =
+  // m / (rows per wave tile); feeds the GroupNorm of the consumer (lr_groupnorm_finalize) instead of a statistics pass
+  float* gs_out;
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
 #endif
@@ -126,7 +129,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   constexpr int NPJ = TE / 2;
   constexpr int NUJ = TM * NPJ;
   constexpr int NU = NUJ + (TE & 1) * (TM / 2);
-  constexpr int G = TM * TN >= 40 ? 6 : 8;   // residual loads in flight per wave (16 B per lane each)
+  constexpr int G = TM * TN >= 40 ? 4 : 8;   // residual loads in flight per wave (16 B per lane each)
   const int fr = lane & 15, fq = lane >> 4;
   const int odd = fq & 1, ch8 = (fq >> 1) * 8;
   const int N_out = GEGLU ? P.N >> 1 : P.N;
@@ -139,9 +142,51 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc(P.rowvec ? (const void*)P.rowvec : (const void*)P.out,
                                                   (P.rowvec && fin) ? ((size_t)((P.M - 1) / P.rows_per_batch) * P.ld_rowvec + N_out) * 2 : 0);
   const __amdgpu_buffer_rsrc_t rsO = uniform_rsrc(P.out, fin ? ((size_t)(P.M - 1) * P.ld_out + N_out) * 2 : 0);
-  float s1[TM], s2[TM];
+  // one register array serves both kinds of output statistics (a GEMM feeds a LayerNorm or a GroupNorm, never both):
+  // row mode (P.st_out): s1[i] = sg[i], s2[i] = sg[SGH + i];  channel mode (P.gs_out): g1[q] = sg[q], g2[q] = sg[SGH + q]
+  constexpr int SGH = TM > 8 ? TM : 8;
+  float sg[2 * SGH];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < 2 * SGH; ++i) sg[i] = 0.f;
+#define s1(i) sg[(i)]
+#define s2(i) sg[SGH + (i)]
+#define g1(q) sg[(q)]
+#define g2(q) sg[SGH + (q)]
+  // GroupNorm statistics of the consumer: per-channel sums over the wave's rows.  All units of a column group (the TM
+  // units of a tile-column pair, or the TM/2 units of the odd last column) put the SAME eight channels in a lane, so the
+  // lane accumulates over them and the group is reduced over the 16 row lanes (4 DPP adds per value) when it completes.
+  const bool gstat = !GEGLU && P.gs_out != nullptr && P.st_out == nullptr;
+  auto row16_sum = [&](float v) -> float {   // sum over the 16 lanes of a DPP row, result in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+  };
+  auto flush_group = [&](const int n_lane, const bool pair_fq) {
+    const int rb = m_w0 / (TM * 16);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float a = row16_sum(g1(q)), b = row16_sum(g2(q));
+      if (pair_fq) {   // odd last column: lane rows (fq, fq ^ 1) hold the same channels for different output rows
+        const auto sa = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, a), false, false);
+        a = __builtin_bit_cast(float, (unsigned)sa[0]) + __builtin_bit_cast(float, (unsigned)sa[1]);
+        const auto sb = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, b), false, false);
+        b = __builtin_bit_cast(float, (unsigned)sb[0]) + __builtin_bit_cast(float, (unsigned)sb[1]);
+      }
+      g1(q) = a; g2(q) = b;
+    }
+    if (fr == 0 && (!pair_fq || !odd) && n_lane < N_out && m_w0 < P.M) {
+      float* dst = P.gs_out + ((size_t)rb * N_out + n_lane) * 2;
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        const f32x4 o = {g1(q), g2(q), g1(q + 1), g2(q + 1)};
+        *reinterpret_cast<f32x4*>(dst + 2 * q) = o;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { g1(q) = 0.f; g2(q) = 0.f; }
+  };
   auto rowstat = [&](const int i) -> float2 { return *reinterpret_cast<const float2*>(rs + 2 * (i * 16 + fr)); };
   auto par4 = [&](const int which, const int col) -> f32x4 { return *reinterpret_cast<const f32x4*>(par + which * PAR_LD + col); };
   // accumulator tile (i, je) of the EMITTED grid, with LayerNorm fold, bias and the GEGLU gate applied (pre-swap layout:
@@ -230,16 +275,24 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     const uint4 pk = lr_pack8(v);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rsO,
                                            ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, 0);
+    if (gstat) {
+      float f[8];
+      lr_unpack8(pk, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float x = ok ? f[q] : 0.f; g1(q) += x; g2(q) = fmaf(x, x, g2(q)); }
+      if (u < NUJ) { if (u % TM == TM - 1) flush_group(n, false); }
+      else if (u == NU - 1) flush_group(n, true);
+    }
     if (P.st_out) {
       float f[8], t1 = 0.f, t2 = 0.f;
       lr_unpack8(pk, f);
 #pragma unroll
       for (int q = 0; q < 8; ++q) { t1 += f[q]; t2 = fmaf(f[q], f[q], t2); }
       if (!ok) { t1 = 0.f; t2 = 0.f; }
-      if (ia == ib) { s1[ia] += t1; s2[ia] += t2; }
+      if (ia == ib) { s1(ia) += t1; s2(ia) += t2; }
       else {
-        s1[ia] += odd ? 0.f : t1; s2[ia] += odd ? 0.f : t2;
-        s1[ib] += odd ? t1 : 0.f; s2[ib] += odd ? t2 : 0.f;
+        s1(ia) += odd ? 0.f : t1; s2(ia) += odd ? 0.f : t2;
+        s1(ib) += odd ? t1 : 0.f; s2(ib) += odd ? t2 : 0.f;
       }
     }
   };
@@ -257,7 +310,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   if (P.st_out) {   // row sums over this wave's column range: the four fq lanes of an fr hold pieces of the same row
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      float a = s1[i], b = s2[i];
+      float a = s1(i), b = s2(i);
       a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
       a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
       const int m = m_w0 + i * 16 + fr;
@@ -267,6 +320,10 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
       }
     }
   }
+#undef s1
+#undef s2
+#undef g1
+#undef g2
 #endif
 }
 
@@ -840,6 +897,21 @@ extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
   return 0;
 }
 
+// rows per wave tile of the instance that serves tile (tm, tn): the row-block size of gn_stats_out
+static int tile_wave_rows(int tm, int tn, int geglu) {
+  if (tm == 128) return 64;
+  if (tn == 256) return 128;
+  if (tn == 320) return geglu ? 64 : 128;
+  return 64;   // 256 x {128, 160}: 4 x 2 waves
+}
+
+extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
+  if (!a) return 0;
+  int tn = a->tile_n, tm = a->tile_m;
+  choose_tile(a->B * a->H * a->W, a->N, a->geglu != 0, &tm, &tn);
+  return tile_wave_rows(tm, tn, a->geglu == 1);
+}
+
 extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
   if (!a) return 0;
   int tn = a->tile_n, tm = a->tile_m;
@@ -919,6 +991,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
 #ifdef LR_GEMM_TRACE
   P.trace = g_trace;
 #endif
+  P.gs_out = a->gn_stats_out;
+  if (P.gs_out && (splits > 1 || P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
   P.st_out = a->stats_out;
   P.st_parts = ((P.N + tn - 1) / tn) * tile_wnw(tm, tn, P.geglu);
   if (P.st_out && (splits > 1 || ((uintptr_t)P.st_out & 7))) return LR_E_ARG;

@@ -306,9 +306,76 @@ extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, 
   return lr_launch_status();
 }
 
+// GroupNorm statistics from the producing GEMMs' epilogues (lr_gemm_args.gn_stats_out): per-channel partial sums over
+// row blocks -> per-group (sum, sumsq) of each sample, fixed order.  grid = (32 groups, N), block = 256: the (channel, row
+// block) pairs of the group are strided over the threads (independent loads in flight), then a fixed tree combines them.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p1, int C1, int R1,
+                                                          const float* __restrict__ p2, int C2, int R2, int HW,
+                                                          float* __restrict__ partials) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int C = C1 + C2, Cg = C / 32;
+  double s = 0.0, q = 0.0;
+  // the group's channels split into the part that lives in source 1 and the part in source 2 (a group may straddle the
+  // concat boundary); each part is a [row blocks][channels] patch flattened over the threads
+  const int c_lo = g * Cg, c_hi = c_lo + Cg;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    const float* src = part ? p2 : p1;
+    const int cs = part ? C2 : C1, R = part ? R2 : R1;
+    const int lo = part ? max(c_lo - C1, 0) : min(c_lo, C1), hi = part ? max(c_hi - C1, 0) : min(c_hi, C1);
+    const int w = hi - lo;
+    if (w <= 0 || !src) continue;
+    const int nb = HW / R;
+    const float* base = src + ((size_t)n * nb * cs + lo) * 2;
+    const int total = nb * w;
+#pragma unroll 4
+    for (int e = t; e < total; e += 256) {
+      const int b = e / w, cc = e - b * w;
+      const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)b * cs + cc) * 2);
+      s += (double)v.x; q += (double)v.y;
+    }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+  if ((t & 63) == 0) { red[0][t >> 6] = s; red[1][t >> 6] = q; }
+  __syncthreads();
+  if (t == 0) {
+    partials[((size_t)n * 32 + g) * 2] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));   // fp32 like the statistics kernel
+    partials[((size_t)n * 32 + g) * 2 + 1] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+extern "C" int lr_groupnorm_finalize(const float* p1, int C1, int R1, const float* p2, int C2, int R2, int N, int HW,
+                                     float* partials, lr_stream_t s) {
+  if (!p1 || !partials || N <= 0 || HW <= 0 || R1 <= 0 || HW % R1) return LR_E_ARG;
+  if (!p2) C2 = 0;
+  if (p2 && (R2 <= 0 || HW % R2)) return LR_E_ARG;
+  if ((C1 + C2) % 32) return LR_E_ALIGN;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, N), dim3(256), 0, (hipStream_t)s, p1, C1, R1, p2, C2, p2 ? R2 : 1, HW, partials);
+  return lr_launch_status();
+}
+
+static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
+                                int nchunks_in, const float* gamma, const float* beta, float eps, int silu, lr_half* y,
+                                lr_stream_t s);
+
 extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
                                   const float* partials, const float* gamma, const float* beta, float eps, int silu,
                                   lr_half* y, lr_stream_t s) {
+  return groupnorm_apply_impl(x1, C1, x2, C2, N, HW, partials, 0, gamma, beta, eps, silu, y, s);
+}
+
+extern "C" int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
+                                    const float* partials, int nchunks, const float* gamma, const float* beta, float eps,
+                                    int silu, lr_half* y, lr_stream_t s) {
+  if (nchunks <= 0) return LR_E_ARG;
+  return groupnorm_apply_impl(x1, C1, x2, C2, N, HW, partials, nchunks, gamma, beta, eps, silu, y, s);
+}
+
+static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
+                                int nchunks_in, const float* gamma, const float* beta, float eps, int silu, lr_half* y,
+                                lr_stream_t s) {
   if (!x1 || !partials || !gamma || !beta || !y || N <= 0 || HW <= 0) return LR_E_ARG;
   if (!x2) C2 = 0;
   const int C = C1 + C2;
@@ -332,7 +399,7 @@ extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, 
   dim3 grid((HW + ppb - 1) / ppb, N);
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, (hipStream_t)s, (const f16*)x1, C1, (const f16*)x2, C2,
-                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, gn_nchunks(N, HW, C));
+                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, nchunks_in > 0 ? nchunks_in : gn_nchunks(N, HW, C));
   return lr_launch_status();
 }
 

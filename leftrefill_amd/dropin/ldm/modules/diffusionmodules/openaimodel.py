@@ -367,11 +367,11 @@ class UNetModel(nn.Module):
                 elif kind == "st":
                     act = ckpt(lambda a_, c_, p=p: E.spatial_transformer(a_, c_, L, p, kv_cache), act, ctx)
                 elif kind == "down":
-                    act = E.conv(act, p)
+                    act = E.conv(act, p, gn_stats=True)
                 elif kind == "up":
-                    act = E.conv(act, p, up=1)
+                    act = E.conv(act, p, up=1, gn_stats=True)
                 elif kind == "conv":
-                    act = E.conv(act, p)
+                    act = E.conv(act, p, gn_stats=True)
             return act
 
         taps = self.__dict__.get("_lr_taps")   # debugging hook: {name: NCHW fp32 block output} (eager mode only)
@@ -390,7 +390,7 @@ class UNetModel(nn.Module):
         tap("mid", act)
         for i, steps in enumerate(P["output"]):
             skip = hs.pop()
-            act = run(steps, E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok))   # virtual th.cat([h, hs.pop()], 1)
+            act = run(steps, E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok, gs=act.gs, gs2=skip.gs))   # virtual th.cat([h, hs.pop()], 1)
             tap(f"out{i}", act)
         act = E.gn(act, P["out_norm"], True)
         act = E.conv(act, P["out_conv"])

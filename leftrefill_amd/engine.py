@@ -31,6 +31,8 @@ class Act:
     H: int
     W: int
     tok2: Optional[torch.Tensor] = None
+    gs: Optional[tuple] = None       # GroupNorm statistics of tok from its producer's epilogue: (partials, rows per block)
+    gs2: Optional[tuple] = None      # ... of tok2
 
     @property
     def HW(self):
@@ -167,8 +169,17 @@ def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear):
     return linear(ops.layer_norm(x, pn.g, pn.b, pn.eps), pl)
 
 
-def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False):
-    """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample; asym: pad bottom/right only) or 1x1 conv over an Act."""
+# GroupNorm statistics out of the producing GEMM's epilogue (inference path); LEFTREFILL_GN_FUSE=0 runs the statistics pass.
+GN_FUSE = __import__("os").environ.get("LEFTREFILL_GN_FUSE", "1") != "0"
+
+
+def gn_fuse_ok(x):
+    return GN_FUSE and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False):
+    """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample; asym: pad bottom/right only) or 1x1 conv over an Act.
+    gn_stats: the output feeds a GroupNorm -- let the epilogue produce its statistics (Act.gs)."""
     if pc.taps == 9:
         if up:
             H, W = act.H * 2, act.W * 2
@@ -178,26 +189,35 @@ def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False):
             H, W = act.H, act.W
     else:
         H, W = act.H, act.W
+    want = gn_stats and gn_fuse_ok(act.tok) and pc.cout == pc.w.shape[0]
     y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
-                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid)
-    return Act(y, act.N, H, W)
+                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want)
+    y, gs = y if want else (y, None)
+    return Act(y, act.N, H, W, gs=gs)
 
 
 def gn(act: Act, pn: PackedNorm, silu):
-    y = ops.group_norm(act.tok, act.N, act.HW, pn.g, pn.b, pn.eps, silu, act.tok2)
+    """GroupNorm(32)(+SiLU) of the (virtually concatenated) activation; statistics from the producers when they came along."""
+    HW = act.HW
+    fused = (act.gs is not None and HW % act.gs[1] == 0 and gn_fuse_ok(act.tok)
+             and (act.tok2 is None or (act.gs2 is not None and HW % act.gs2[1] == 0)))
+    if fused:
+        y = ops.group_norm_fused(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.gs, act.tok2, act.gs2)
+    else:
+        y = ops.group_norm(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.tok2)
     return Act(y, act.N, act.H, act.W)
 
 
 def resblock(act: Act, pr: PackedRes, emb_out):
     """emb_out: [N, Cout] fp16 (row stride may exceed Cout) = emb_layers(emb), added to every pixel of sample n."""
     h = gn(act, pr.n1, True)
-    h = conv(h, pr.c1, rowvec=emb_out)
+    h = conv(h, pr.c1, rowvec=emb_out, gn_stats=True)
     h = gn(h, pr.n2, True)
     if pr.skip is not None:
         resid = conv(act, pr.skip).tok
     else:
         resid = act.materialize()
-    return conv(h, pr.c2, resid=resid)
+    return conv(h, pr.c2, resid=resid, gn_stats=True)
 
 
 def attention_plain(x, ctx, pa: PackedAttn, B, L, Lc=None):
@@ -301,15 +321,17 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
 
 def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):
     x_in = act.materialize()
-    h = gn(Act(x_in, act.N, act.H, act.W), ps.norm, False).tok
+    h = gn(Act(x_in, act.N, act.H, act.W, gs=act.gs if act.tok2 is None else None), ps.norm, False).tok
     ws = fold_ok(h)
     h = linear(h, ps.proj_in, want_stats=ws)
     h, st = h if ws else (h, None)
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
         h, st = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=i + 1 < len(ps.blocks))
-    y = linear(h, ps.proj_out, resid=x_in)
-    return Act(y, act.N, act.H, act.W)
+    want = gn_fuse_ok(h)
+    y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want)
+    y, gs = y if want else (y, None)
+    return Act(y, act.N, act.H, act.W, gs=gs)
 
 
 def to_tokens(x):

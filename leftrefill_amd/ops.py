@@ -97,6 +97,29 @@ def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None):
     return y
 
 
+def group_norm_fused(x1, N, HW, gamma, beta, eps, silu, gs1, x2=None, gs2=None):
+    """GroupNorm(32)(+SiLU) whose statistics come from the producers' epilogues: gs* = (partials [M/R, C, 2] fp32, R) as
+    returned by gemm_conv(..., want_gn_stats=True) for x1 / x2.  One tiny finalize launch replaces the pass over x."""
+    lib = _lib.load()
+    _chk16(x1, "x1")
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    p1, r1 = gs1
+    p2, r2 = gs2 if x2 is not None else (None, 1)
+    assert p1.shape == (N * HW // r1, C1, 2) and HW % r1 == 0
+    if x2 is not None:
+        _chk16(x2, "x2")
+        assert p2.shape == (N * HW // r2, C2, 2) and HW % r2 == 0
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C1 + C2
+    partials = torch.empty(N * 64, device=x1.device, dtype=torch.float32)
+    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+    st = _stream()
+    _lib.check(lib.lr_groupnorm_finalize(_p(p1), C1, r1, _p(p2), C2, r2, N, HW, _p(partials), st), "groupnorm_finalize")
+    _lib.check(lib.lr_groupnorm_apply_n(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), 1, _p(gamma), _p(beta), float(eps),
+                                        int(bool(silu)), _p(y), st), "groupnorm_apply_n")
+    return y
+
+
 def layer_norm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
     _chk16(x, "x")
@@ -131,12 +154,15 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, ln=None, want_stats=False):
+              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, ln=None, want_stats=False,
+              want_gn_stats=False):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
 
     ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
     are the gamma / beta folded weights, see lr_gemm_args).  want_stats: also return the per-row (sum, sumsq) partials of
-    the output, [M, parts, 2] fp32 -- the `stats` a following LayerNorm-folded GEMM consumes; returns (out, stats)."""
+    the output, [M, parts, 2] fp32 -- the `stats` a following LayerNorm-folded GEMM consumes; returns (out, stats).
+    want_gn_stats: also return per-channel (sum, sumsq) over row blocks for the GroupNorm that consumes the output:
+    returns (out, (partials [M / R, N, 2] fp32, R)), or (out, None) when the plan splits K (statistics need the whole sum)."""
     lib = _lib.load()
     _chk16(x1, "x1")
     _chk16(wt, "wt")
@@ -173,7 +199,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.tile_m = tile_m
     a.splits = splits
     a.workspace, a.workspace_bytes = 0, 0
-    a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out = 0, 0, 0.0, 0, 0
+    a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
     if ln is not None:
         st_in, eps, colsum = ln
         assert st_in.dtype == torch.float32 and st_in.is_contiguous() and st_in.shape[0] == M and st_in.shape[2] == 2
@@ -197,8 +223,19 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         a.stats_out = _p(stats)
     if ln is not None and a.splits == 0:
         a.splits = 1
+    gstats = None
+    if want_gn_stats:
+        plan = (ctypes.c_int32 * 3)()
+        lib.lr_gemm_plan(a, plan)
+        rows = lib.lr_gemm_gn_rows(a)
+        if plan[2] == 1 and (H * W) % rows == 0:     # whole K in one block; row blocks never straddle two samples
+            a.splits = 1
+            gstats = (torch.empty(M // rows, n_out, 2, device=x1.device, dtype=torch.float32), rows)
+            a.gn_stats_out = _p(gstats[0])
     ws = _workspace(lib, a, x1.device)
     _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
+    if want_gn_stats:
+        return out, gstats
     return (out, stats) if want_stats else out
 
 

@@ -97,7 +97,7 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
         return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
     if kw.get("ln") is not None:
         raise NotImplementedError("the LayerNorm-folded GEMM is an inference kernel; differentiate layer_norm + gemm_conv")
-    if kw.pop("want_stats", False):     # row statistics feed the LayerNorm fold of the NEXT GEMM: not used under autograd
+    if kw.pop("want_stats", False) or kw.pop("want_gn_stats", False):   # epilogue statistics feed inference-only fusions
         return gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw), None
     if rowvec is not None and rowvec.requires_grad:
         raise NotImplementedError("gradient w.r.t. the time embedding is not produced (nothing trainable sits upstream of it)")

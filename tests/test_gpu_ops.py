@@ -319,6 +319,42 @@ def test_geglu_layernorm_fold(tm, tn):
     report(name, y, ref, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("tm,tn", ALL_TILES)
+def test_groupnorm_statistics_from_gemm_epilogue(tm, tn):
+    """GroupNorm whose statistics come out of the producing GEMMs' epilogues (lr_gemm_args.gn_stats_out +
+    lr_groupnorm_finalize) instead of a pass over x: per-channel block sums match the stored tensor, and the normalised
+    output matches F.group_norm on the virtual concat of two producers with different block sizes (openaimodel.py:781)."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W = 2, 8, 16                      # HW = 128 rows per sample (the 8 x 16 level)
+    name = f"gnf_{tm}x{tn}"
+    outs = []
+    for k, (Cin, Cout, taps) in enumerate(((320, 320, 9), (128, 640, 1))):
+        x = h16(G.T(f"{name}.x{k}", (N, Cin, H, W)) * 1.5 + 0.4)
+        w = h16(torch.from_numpy(weights.fill_like(f"{name}.w{k}", (Cout, Cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1))))
+        b = torch.from_numpy(weights.fill_like(f"{name}.b{k}", (Cout,))) + 0.3
+        kw = dict(tile_m=tm, tile_n=tn, splits=1) if k == 0 else dict(tile_m=128, tile_n=64, splits=1)
+        y, gs = ops.gemm_conv(to_tok(x), packing.pack_conv(w, cin_pad=Cin).to(d), B=N, H=H, W=W, taps=taps,
+                              bias=packing.pack_bias(b).to(d), want_gn_stats=True, **kw)
+        assert gs is not None
+        part, R = gs
+        yf = y.float().reshape(N * H * W // R, R, Cout)
+        assert torch.allclose(part[..., 0], yf.sum(1), rtol=1e-5, atol=2e-3), name
+        assert torch.allclose(part[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=2e-3), name
+        outs.append((y, gs))
+    (y1, g1), (y2, g2) = outs
+    C = y1.shape[1] + y2.shape[1]
+    gam = 1.0 + 0.3 * G.T(name + ".g", (C,))
+    bet = 0.2 * G.T(name + ".be", (C,))
+    xcat = torch.cat([from_tok(y1, N, H, W), from_tok(y2, N, H, W)], 1)
+    ref = F.silu(F.group_norm(xcat, 32, gam, bet, 1e-5))
+    out = ops.group_norm_fused(y1, N, H * W, gam.to(d), bet.to(d), 1e-5, True, g1, y2, g2)
+    report(name + " gn(concat)", from_tok(out, N, H, W), ref)
+    ref1 = F.group_norm(from_tok(y1, N, H, W), 32, gam[:320], bet[:320], 1e-6)
+    out1 = ops.group_norm_fused(y1, N, H * W, gam[:320].contiguous().to(d), bet[:320].contiguous().to(d), 1e-6, False, g1)
+    report(name + " gn(single)", from_tok(out1, N, H, W), ref1)
+
+
 def test_tile_plan_is_static_and_tiles_agree_bitwise():
     """The (tile, split-K) plan is a pure function of the shape (in-tree table or the static heuristic -- never timing),
     and with the split factor pinned every tile gives bit-identical results (same K order per output element)."""
