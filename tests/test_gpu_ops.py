@@ -87,6 +87,26 @@ def test_groupnorm(C1, C2, N, H, W, eps, silu):
     assert torch.equal(y, y2), "groupnorm must be bitwise reproducible"
 
 
+def test_groupnorm_large_mean_small_variance():
+    """fp32 single-pass (sum, sumsq) statistics with mean 50, std 0.5 (variance 1e-4 of the mean square): the kernels
+    accumulate per-thread partials of few elements and combine them in fp64, so E[x^2] - mean^2 keeps ~4 digits here."""
+    from leftrefill_amd import ops
+    d = dev()
+    N, C, H, W = 2, 320, 16, 32
+    x = h16(50.0 + 0.5 * G.T("gn_big.x", (N, C, H, W)))
+    gam = 1.0 + 0.3 * G.T("gn_big.g", (C,))
+    bet = 0.2 * G.T("gn_big.b", (C,))
+    ref = F.silu(F.group_norm(x.double(), 32, gam.double(), bet.double(), 1e-5)).float()
+    y = ops.group_norm(to_tok(x), N, H * W, gam.to(d), bet.to(d), 1e-5, True)
+    # fp16 inputs near 50 are quantised to 1/32: the normalised values carry that input noise (6e-2 sigma); what is tested
+    # is the statistics: any loss in the variance shows up as a uniform scale error of the whole output
+    out = from_tok(y, N, H, W)
+    scale = (out * ref).sum() / (ref * ref).sum()
+    print(f"[gn large mean] fitted scale {scale.item():.6f}  max_abs_err {(out - ref).abs().max().item():.3e}")
+    assert abs(scale.item() - 1.0) < 2e-3
+    report("gn large mean", out, ref, rtol=4e-3, atol=4e-3)
+
+
 @pytest.mark.parametrize("M,C", [(256, 320), (77, 640), (130, 1280), (64, 128)])
 def test_layernorm(M, C):
     from leftrefill_amd import ops

@@ -133,6 +133,57 @@ def check_unet(golden, case, cname, N, H, W, ts, fname="unet", multiview=None, b
             print(f"    tap {k:6s} rel_l2 {e.item():.3e}")
     assert rel <= min(max(1.5 * rel_e, 1.5e-3), 4e-3), (rel, rel_e)
     assert mx <= max(2.0 * mx_e, 5e-3), (mx, mx_e)
+    # element-wise north-star tolerance (fp16 rtol 2e-3 / atol 1e-3) over the WHOLE network: the fraction of outputs
+    # outside it, for the HIP path and for the reference's own fp16-autocast numerics (oracle emulation), both against
+    # the fp32 golden, and HIP against the emulation.  No fp16 pipeline of ~60 layers meets it on every element; the bound
+    # is that the HIP path violates it no more often than the reference's own precision mode does.
+    v_hip, v_emu, v_he = viol_frac(y_eager, ref), viol_frac(emul, ref), viol_frac(y_eager, emul)
+    print(f"    north-star rtol 2e-3 / atol 1e-3 violations: HIP vs fp32 {100 * v_hip:.3f} %  autocast16-emulation vs fp32 "
+          f"{100 * v_emu:.3f} %  HIP vs emulation {100 * v_he:.3f} %  ({ref.numel()} elements)")
+    assert v_hip <= 1.25 * v_emu + 2e-3, (v_hip, v_emu)
+
+
+def viol_frac(out, ref, rtol=2e-3, atol=1e-3):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    return ((out - ref).abs() > atol + rtol * ref.abs()).float().mean().item()
+
+
+_DIGEST_SNIPPET = """
+import hashlib, sys, torch
+sys.path.insert(0, {root!r})
+import tests.test_gpu_unet as T
+from oracle import golden_spec as G
+case, cname, N, H, W, ts = [c for c in G.UNET_CASES if c[1] == "MID"][0]
+m, sd, cfg = T.get_model(cname)
+x, t, ctx = G.unet_inputs(case, cfg, N, H, W, ts)
+with torch.no_grad():
+    y = m(x.cuda(), t.cuda(), ctx.cuda())
+print("DIGEST", hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_two_fresh_processes_are_bit_identical():
+    """The tile / split-K plan is a pure function of the shape (in-tree table + static heuristic): two fresh processes
+    produce bit-identical eps on the MID config, and so does this process (what the sharded multi-view path relies on
+    for its replicated rows -- leftrefill_amd/dist.py)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", _DIGEST_SNIPPET.format(root=root)], capture_output=True, text=True,
+                             cwd=root, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    case, cname, N, H, W, ts = [c for c in G.UNET_CASES if c[1] == "MID"][0]
+    m, sd, cfg = get_model(cname)
+    x, t, ctx = G.unet_inputs(case, cfg, N, H, W, ts)
+    with torch.no_grad():
+        y = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
+    digests.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+    assert digests[0] == digests[1] == digests[2], digests
 
 
 @pytest.mark.parametrize("case,cname,N,H,W,ts", [c for c in G.UNET_CASES if c[1] == "MID"],
@@ -219,6 +270,43 @@ def test_full_size_properties_config2():
     rel = ((halves.float() - y.float()).norm() / y.float().norm()).item()
     print(f"[full size 64x128 N=8] |y| max {y.abs().max().item():.3f}; halves vs joint rel_l2 {rel:.3e}")
     assert rel < 4e-3
+
+
+def test_full_size_properties_config4_mv5():
+    """BASELINE configs[3] at full size: the shipped width, view_num = 5 with concat_target (4 canvases [ref_i | target] per
+    sample at latent 64x128, re-arranged self-attention sequence 5 x 4096 = 20480 tokens), 2 samples = UNet batch 8.  Too
+    large for the CPU oracle, so size-independent properties: finite output; hipGraph replay == rerun == eager launches
+    bit-exactly; bit-exact equivariance to swapping the two samples; swapping two REFERENCE canvases of a sample permutes
+    that sample's outputs up to fp16 noise (softmax over the same keys in another order)."""
+    install()
+    from ldm.modules.diffusionmodules.multiview_unet import MultiViewUnetModel
+    cfg = unet_ref.UNetConfig(multiview=True, view_num=5, concat_target=True)
+    sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV5.")
+    m = MultiViewUnetModel(**cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev()).eval()
+    N, H, W = 8, 64, 128
+    x, t, ctx = G.unet_inputs("mv5_full", cfg, N, H, W, [801] * 4 + [201] * 4)
+    d = dev()
+    x, t, ctx = x.to(d), t.to(d), ctx.to(d)
+    with torch.no_grad():
+        m.use_hip_graph = True
+        y = m(x, t, context=ctx)
+        assert y.shape == (N, 4, H, W) and torch.isfinite(y).all()
+        assert torch.equal(m(x, t, context=ctx), y)
+        m.use_hip_graph = False
+        assert torch.equal(m(x, t, context=ctx), y)
+        swap = torch.tensor([4, 5, 6, 7, 0, 1, 2, 3], device=d)
+        assert torch.equal(m(x[swap], t[swap], context=ctx[swap]), y[swap])
+        refswap = torch.tensor([0, 2, 1, 3, 4, 5, 6, 7], device=d)        # reference canvases 1 and 2 of sample 0 trade places
+        # (canvas 0 stays: its right half is the target the re-arranged sequence starts with, multiview_attention.py:436-448)
+        y2 = m(x[refswap], t[refswap], context=ctx[refswap])
+        m.use_hip_graph = True
+    rel = ((y2[refswap].float() - y.float()).norm() / y.float().norm()).item()
+    print(f"[mv5 full size] |y| max {y.abs().max().item():.3f}; reference-canvas swap rel_l2 {rel:.3e}")
+    assert rel < 4e-3
+    del m
+    torch.cuda.empty_cache()
 
 
 def _mv_shard_worker(rank, world, port, q):
