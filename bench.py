@@ -150,6 +150,21 @@ def kernel_roofline(model, batch, B, dump=None):
         out[name] = {"launches": len(rec[name]), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(rec[name])),
                      "tflops": n * fl[key] / (ms * 1e-3) / 1e12}
     out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
+    # per-shape table of this instrumented step (what tools/kernel_table.py prints from --dump-kernels)
+    agg = {}
+    for name in rec:
+        for a, b, d in rec[name]:
+            us = 1e3 * a.elapsed_time(b)
+            if name == "gemm_conv":
+                key = f'gemm {d["M"]}x{d["N"]}x{d["K"]} taps{d["taps"]} s{d["stride"]} up{d["up"]}' + (" geglu" if d["geglu"] else "") + (" cat" if d["cat"] else "")
+                fl_ = 2.0 * d["M"] * d["N"] * d["K"]
+            else:
+                key = f'attn B{d["B"]} h{d["heads"]} {d["Nq"]}x{d["Nkv"]}'
+                fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
+            e = agg.setdefault(key, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += us; e[2] += fl_
+    out["table"] = [dict(shape=k, n=v[0], total_us=round(v[1], 1), avg_us=round(v[1] / v[0], 1), tflops=round(v[2] / v[1] / 1e6, 1))
+                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
     if dump:
         rows = []
         for name in rec:
@@ -330,7 +345,9 @@ def train_bench(a, rank, world, device, model=None, steps=None):
 
 
 def cpu_baseline():
-    """Oracle (fp32 torch CPU restatement) on a bounded sample: ONE CFG UNet step (N=2) at latent 64x128."""
+    """Oracle (fp32 torch CPU restatement of the reference, oracle/unet_ref.py) on the host cores, SURVEY 8d: configs[0] fully
+    (256x512 canvas = latent 32x64, B = 1, 10 DDIM steps under CFG = 10 UNet forwards at batch 2) and ONE CFG step of configs[1]
+    (latent 64x128, batch 2), after a warm-up forward (thread pool, allocator)."""
     from oracle import unet_ref
     cfg = unet_ref.FULL
     g = torch.Generator().manual_seed(0)
@@ -338,23 +355,66 @@ def cpu_baseline():
     for k, shp in unet_ref.param_shapes(cfg).items():
         if len(shp) >= 2:
             fan = 1
-            for s in shp[1:]:
-                fan *= s
+            for s_ in shp[1:]:
+                fan *= s_
             sd[k] = torch.randn(shp, generator=g) * (1.0 / fan) ** 0.5
         elif k.endswith(".weight"):
             sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
         else:
             sd[k] = 0.02 * torch.randn(shp, generator=g)
-    x = torch.randn(2, 9, 64, 128, generator=g)
     ctx = torch.randn(2, 77, 1024, generator=g)
     t = torch.tensor([501, 501])
+    x0 = torch.randn(2, 9, 32, 64, generator=g)
+    unet_ref.unet_forward(sd, cfg, x0, t, ctx)                      # warm-up (not timed)
+    t0 = time.time()
+    xs = x0
+    for i in range(10):                                             # configs[0]: 10 CFG UNet steps + the DDIM / CFG update
+        eps = unet_ref.unet_forward(sd, cfg, xs, torch.tensor([901 - 100 * i] * 2), ctx)
+        e = eps[:1] + CFG * (eps[1:] - eps[:1])                    # classifier-free guidance, ddim.py:343
+        xs = torch.cat([xs[:, :4] - 0.1 * e, xs[:, 4:]], 1)        # stand-in for the x_{t-1} update (negligible time)
+    dt0 = time.time() - t0
+    x = torch.randn(2, 9, 64, 128, generator=g)
     t0 = time.time()
     unet_ref.unet_forward(sd, cfg, x, t, ctx)
     dt = time.time() - t0
     return {"value": 1.0 / (S_DDIM * dt), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 CFG UNet step (batch 2) at latent 64x128 with the fp32 torch CPU oracle: {dt:.2f} s/step, "
-                      f"extrapolated x{S_DDIM} steps per image",
-            "s_per_unet_step_b2": dt}
+            "sample": f"after one warm-up forward: configs[0] in full (latent 32x64, B=1, 10 CFG UNet steps) {dt0:.2f} s = "
+                      f"{1.0 / dt0:.4f} images/s; configs[1]: 1 CFG UNet step (batch 2) at latent 64x128 {dt:.2f} s/step, "
+                      f"extrapolated x{S_DDIM} steps per image for `value`",
+            "s_per_unet_step_b2": dt, "config0_full_s": dt0, "config0_images_per_s": 1.0 / dt0}
+
+
+def measure_traffic(launches):
+    """HBM traffic of the GEMM family, measured NOW: tools/pmc_step.py (one eager UNet step at batch 8) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains), FETCH doubled per the gfx950
+    correction of MI355X_MICROARCH.md.  Returns bytes per GEMM launch, or None when the profiler is not usable here."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            r = subprocess.run([prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, name), "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_step.py"), "run"], cwd=ROOT, env=env, capture_output=True,
+                               text=True, timeout=600)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} failed: {r.stderr[-200:]}"
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_step
+        out = os.path.join(tmp, "traffic.json")
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # stdout carries exactly one JSON line
+            pmc_step.reduce_(os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), out, launches)
+        res = json.load(open(out))
+        return res, None
+    except Exception as e:      # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -368,6 +428,7 @@ def main():
                          "(configs[4]-like) -- neither is the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--train-graph", action="store_true", help="train workload: capture the whole step into one hipGraph")
     ap.add_argument("--recompute", action="store_true", help="train workload: recompute blocks in the backward (use_checkpoint)")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
@@ -456,18 +517,24 @@ def main():
     if rank == 0 and not a.no_roofline:
         kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)
         g = kern["gemm_conv"]
-        traffic = None      # PMC-measured HBM bytes per GEMM launch (tools/pmc_step.py under rocprofv3 --pmc, committed)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+        traffic, traffic_note = None, "not measured (--no-traffic / multi-GPU / other workload)"
+        if a.workload == "single" and world == 1 and not a.no_traffic:
+            tr, err = measure_traffic(g["launches"])      # live: two rocprofv3 --pmc passes over one eager UNet step
+            if tr is not None:
+                traffic = tr["traffic_bytes_per_launch"]
+                traffic_note = (f"measured in this run: FETCH_SIZE x2 {tr['fetch_bytes_per_launch'] / 1e6:.1f} MB + WRITE_SIZE "
+                                f"{tr['write_bytes_per_launch'] / 1e6:.1f} MB per launch over {tr['fetch_launches']} launches")
+            else:
+                traffic_note = "measurement failed: " + str(err)
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> / gemm_conv256_kernel<BN,..> (implicit-GEMM conv3x3 / 1x1 / linear family, tile picked per shape)",
                            "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                           "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
                            "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
                            "launches_per_unet_step": g["launches"], "avg_launch_us": g["avg_us"],
                            "algorithmic_gflop_per_unet_step": 2 * B * fl["gemm"] / 1e9}
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
+        res["kernel_table"] = kern.get("table", [])[:48]
         res["kernels"] = {"attention_kernel": kern["attention"],
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
