@@ -181,3 +181,20 @@ MULTI_CASES = [("multi_k3_s10", 10, 1.0, 1, 8, 16, 3, 1234)]   # (case, S, eta, 
 TRAIN_CASES = [("train_b2", 2, 16, 32, [501, 21])]   # (case, B, h, w, timesteps): p_losses + backward to the context
 CFG_SCALE = 2.5
 TRAJ_CONFIG = "MID"
+
+
+# ---- prompt encoder: constructor kwargs as the shipped YAMLs pass them (configs/ref_inpainting.yaml:60-72,
+# novel_view_synthesis.yaml:61-75) + prompts; run through the reference's PromptCLIPEmbedder on oracle/clip_stub.py ----------
+_TXT = "The whole image is splited into two parts with the same size, they share the same scene captured with different viewpoints"
+TEXT_CASES = [
+    ("txt_repeat8_pen", dict(layer="penultimate", special_tokens=["repeat_8_<special-token>"], init_text=[_TXT]),
+     ["".join(f"<special-token{i}>" for i in range(8)), "", "a photo of <special-token3> and a cat"]),
+    ("txt_lr_last", dict(layer="last", special_tokens=["<left>", "<right>"], init_text=["left part", "right part"]),
+     ["<left> is the reference , <right> is the target", "plain prompt without special tokens " * 12]),
+    ("txt_tokenwise", dict(layer="penultimate", special_tokens=["repeat_5_<special-token>"], init_text=["alpha beta gamma"],
+                           tokenwise_init=True),
+     ["<special-token0><special-token1><special-token4> tail"]),
+    ("txt_deep", dict(layer="penultimate", special_tokens=["repeat_3_<special-token>"], init_text=["deep prompt init"],
+                      deep_prompt=True, cross_attn_layers=4),
+     [["".join(f"<special-token{i}-layer{l}>" for i in range(3)), ""] for l in range(4)]),
+]

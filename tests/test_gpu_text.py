@@ -1,7 +1,7 @@
 """Prompt-encoder text tower on the HIP kernels (causal attention, GELU-epilogue GEMM) vs a PyTorch module of the published
 OpenCLIP architecture (nn.MultiheadAttention residual blocks with the causal attn_mask).  open_clip is not installed in
-this image, so the checker is this restatement rather than the reference's own model: parity of the ROW is unpinned, the
-kernels' arithmetic is what is being checked."""
+this image; the reference's own PromptCLIPEmbedder code is pinned through oracle/clip_stub.py (a stand-in for the package's
+surface) and tests/golden/text.npz -- see test_prompt_embedder_on_hip_matches_reference_goldens and tests/test_text_cpu.py."""
 import pytest
 import torch
 import torch.nn as nn
@@ -64,6 +64,32 @@ def test_text_tower_matches_torch_restatement(layer_idx):
     rel = (err.norm() / ref.norm()).item()
     print(f"[text tower layer_idx={layer_idx}] rel_l2 {rel:.3e} max_abs {err.max().item():.3e} (|ref| max {ref.abs().max().item():.2f})")
     assert torch.isfinite(out).all() and rel < 3e-3 and err.max().item() < 3e-2
+
+
+@pytest.mark.parametrize("name,kw,prompts", G.TEXT_CASES, ids=[c[0] for c in G.TEXT_CASES])
+def test_prompt_embedder_on_hip_matches_reference_goldens(name, kw, prompts):
+    """Whole prompt encoder on the GPU (tokenise -> splice -> HIP text tower) against tests/golden/text.npz: outputs of the
+    REFERENCE's PromptCLIPEmbedder run on oracle/clip_stub.py (the stand-in for the un-vendored open_clip package)."""
+    import os
+    import sys
+    import numpy as np
+    import leftrefill_amd.dropin as dropin
+    from oracle import clip_stub
+    dropin.install()
+    sys.modules["open_clip"] = clip_stub
+    try:
+        from ldm.modules.encoders.Refill_modules import PromptCLIPEmbedder
+        emb = PromptCLIPEmbedder(device="cuda", **kw).to("cuda:0").eval()
+        with torch.no_grad():
+            z = emb(prompts)
+    finally:
+        sys.modules.pop("open_clip", None)
+    assert getattr(emb, "_lr_tower", None) is not None, "the HIP tower must have run"
+    ref = torch.from_numpy(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text.npz"))[name + ".z"])
+    err = (z.float().cpu() - ref).abs()
+    rel = (err.norm() / ref.norm()).item()
+    print(f"[prompt encoder {name}] rel_l2 {rel:.3e} max_abs {err.max().item():.3e} (|ref| max {ref.abs().max().item():.2f})")
+    assert z.shape == ref.shape and torch.isfinite(z).all() and rel < 3e-3 and err.max().item() < 3e-2
 
 
 def test_causal_attention_kernel():
