@@ -249,13 +249,17 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     model.model.diffusion_model.recompute_in_backward = bool(getattr(a, "recompute", False))
     for p in model.parameters():
         p.requires_grad_(False)
-    g = torch.Generator(device=device).manual_seed(99 + rank)
-    tokens = torch.nn.Parameter(0.02 * torch.randn(73, 1024, device=device, generator=g))
+    g0 = torch.Generator(device=device).manual_seed(99)            # parameters: the SAME initial tokens on every rank
+    tokens = torch.nn.Parameter(0.02 * torch.randn(73, 1024, device=device, generator=g0))
+    g = torch.Generator(device=device).manual_seed(1099 + rank)     # data: rank-dependent
     opt = torch.optim.AdamW([tokens], lr=1e-4)
     base_ctx = torch.randn(Bt, 77, 1024, device=device, generator=g)
     c_concat = torch.randn(Bt, 5, h, w, device=device, generator=g)
     x_start = torch.randn(Bt, 4, h, w, device=device, generator=g)
-    scale = 2.0 ** 14
+    # dynamic loss scale like the reference's fp16 AMP (Lightning precision=16 -> GradScaler, train_inpainting.py:52,127):
+    # a non-finite scaled gradient skips the step and halves the scale, 200 clean steps double it.  The hipGraph variant
+    # keeps the scale fixed (the decision needs the host).
+    scaler = {"scale": 2.0 ** 14, "good": 0, "skipped": 0}
 
     t_buf = torch.zeros(Bt, device=device, dtype=torch.long)
     noise_buf = torch.zeros(Bt, 4, h, w, device=device)
@@ -267,10 +271,18 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     def body():
         ctx = torch.cat([base_ctx[:, :1], base_ctx[:, 1:74] + tokens, base_ctx[:, 74:]], dim=1)
         loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t_buf, noise=noise_buf)
-        (loss * scale).backward()
-        lrd.allreduce_mean_grads([tokens])
-        tokens.grad /= scale
+        (loss * scaler["scale"]).backward()
+        lrd.allreduce_mean_grads([tokens])           # after the reduction every rank sees the same gradient -> same decision
+        if not torch.cuda.is_current_stream_capturing() and not bool(torch.isfinite(tokens.grad).all()):
+            scaler["scale"] *= 0.5
+            scaler["good"] = 0
+            scaler["skipped"] += 1
+            return loss
+        tokens.grad /= scaler["scale"]
         opt.step()
+        scaler["good"] += 1
+        if scaler["good"] % 200 == 0:
+            scaler["scale"] *= 2.0
         return loss
 
     graph = None
@@ -341,7 +353,8 @@ def train_bench(a, rank, world, device, model=None, steps=None):
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
             "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb,
-            "recompute_in_backward": bool(getattr(a, "recompute", False)), "hip_graph": graph is not None}
+            "recompute_in_backward": bool(getattr(a, "recompute", False)), "hip_graph": graph is not None,
+            "loss_scale": scaler["scale"], "skipped_steps": scaler["skipped"]}
 
 
 def cpu_baseline():

@@ -246,14 +246,31 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     # weight preparation: reference-shaped nn.Parameters -> packed fp16 kernel layouts (once, after loading)
     # ------------------------------------------------------------------------------------------------------
+    MAX_GRAPHS = 8        # captured step graphs kept per model (least recently used shape is dropped beyond that)
+
     def _sig(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._weights_dirty = True          # load_state_dict / copy into parameters: re-pack on the next forward
+
+    def invalidate_context_cache(self):
+        """Forget the cached cross-attention K/V projections of every captured step graph.
+
+        Contract of the cache: a context tensor is recognised by object identity + autograd `_version`.  Writes that bypass
+        version counting (`ctx.data.copy_`, raw-pointer kernels writing into it, e.g. `ops.* (out=ctx)`) are NOT seen --
+        call this after such a write (or pass a new tensor)."""
+        for g in self._graphs.values():
+            g.ctx_src = None
+
     def prepare(self, force=False):
-        """Pack all weights for the kernels; call again after (re)loading a state dict."""
-        sig = self._sig()
-        if self._plan is not None and not force and self._plan["sig"] == sig:
+        """Pack all weights for the kernels.  Re-packs when forced, after load_state_dict, or when a parameter was replaced /
+        modified in place through autograd-visible ops; `.data` writes need `prepare(force=True)`."""
+        sig = self._sig()      # ~0.3 ms of host time per call; the captured step keeps the GPU busy for ~20 ms
+        if self._plan is not None and not force and not getattr(self, "_weights_dirty", False) and self._plan["sig"] == sig:
             return self._plan
+        self._weights_dirty = False
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs on the HIP device only: call .to('cuda') first (no CPU fallback)")
@@ -411,10 +428,12 @@ class UNetModel(nn.Module):
             # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
         key = (tuple(x.shape), tuple(context.shape), x.device.index)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
             g = _StepGraph(self, x, timesteps, context)
-            self._graphs[key] = g
+            while len(self._graphs) >= self.MAX_GRAPHS:      # LRU: dicts keep insertion order, re-inserted on every use
+                self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g
         return g.replay(x, timesteps, context, ctx_src)
 
 

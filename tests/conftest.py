@@ -16,14 +16,16 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """The C-ABI library is a build artefact (git-ignored): compile it when a fresh checkout has none (hipcc cross-compiles
-    gfx950 without a GPU).  On the GPU box the prebuilt .so travels with the tree and is used as is."""
+    """The C-ABI library is a build artefact (git-ignored): (re)build it whenever a source is newer than it (hipcc
+    cross-compiles gfx950 without a GPU; nothing is recompiled when the tree that travelled to the GPU box is up to date)."""
     from leftrefill_amd import build as b
-    if os.path.exists(b.LIB):
-        return
     try:
-        b.build(verbose=False)
-    except Exception as e:      # no hipcc: the tests that need the library fail loudly on their own
+        b.hipcc()
+    except RuntimeError:
+        return                  # no compiler here: use the prebuilt .so that travelled with the tree (or fail loudly later)
+    try:
+        b.build(verbose=False)  # mtime-based incremental rebuild: never run the tests against a stale binary after editing csrc/
+    except Exception as e:
         print(f"[conftest] could not (re)build the HIP library: {e}")
 
 
