@@ -59,32 +59,78 @@ def sample_sharded(sample_fn, cond, uncond, x_T, batch_size):
 # ---------------------------------------------------------------------------------------------------------------
 # Multi-view inference, one stitched canvas [ref_i | target] per rank.
 #
-# Reference semantics (ldm/modules/multiview_attention.py:440-460, concat_target=True): the self-attention sequence of a
-# sample is [target(canvas 0), ref_0, ..., ref_{v-1}] ((v+1) s^2 tokens); afterwards the target rows are written to the
-# right half of EVERY canvas and ref_i to canvas i's left half.  Sharded form: every rank all-gathers the raw canvases
-# (one collective per transformer block), forms K/V for the whole sequence, computes Q / attention / out-projection only
-# for its own rows [target, ref_rank] (the target rows are replicated work, bit-identical on every rank, so no second
-# exchange is needed for the write-back), and rebuilds its own canvas.  Everything else in the UNet is canvas-local.
-# The helpers below are device-agnostic (torch + torch.distributed only) so the index logic is covered by gloo tests.
+# Reference semantics (ldm/modules/multiview_attention.py:436-462, concat_target=True): the self-attention sequence of a
+# sample is [target (right half of canvas 0), ref_0, ..., ref_{v-1}] ((v+1) s^2 tokens); afterwards the target rows are
+# written to the right half of EVERY canvas and ref_i to canvas i's left half.  Sharded form, per transformer block:
+#   * exchange ONLY what the sequence is made of: an all-gather of the reference halves (s^2 tokens per rank, into one
+#     preallocated buffer) and a broadcast of rank 0's target half -- the other ranks' target halves are never read;
+#   * every rank builds K/V for the whole sequence, but Q / attention / out-projection only for its own rows
+#     [target, ref_rank]; the target rows are replicated work with bit-identical inputs and a shape-static kernel plan
+#     (leftrefill_amd.ops tile table), hence bit-identical results on every rank: no second exchange for the write-back.
+# Everything else in the UNet is canvas-local.  The helpers are device-agnostic (torch + torch.distributed only) so the
+# index logic is covered by gloo tests on CPU; on GPUs the backend is `nccl` (RCCL over xGMI).
 # ---------------------------------------------------------------------------------------------------------------
 def mv_group_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _staged(x):
+    """gloo has no device collectives: ranks that share one GPU in the tests stage through the host."""
+    return x.is_cuda and dist.get_backend() == "gloo"
+
+
+def mv_gather_sequence(x_local, s, seq=None):
+    """x_local [b, 2*s*s, C]: this rank's canvas tokens (row-major s x 2s: left = ref_rank, right = its copy of the target)
+    of each of the b local samples -> the re-arranged sequence [b, (v+1)*s*s, C] = [target of rank 0, ref_0 .. ref_{v-1}].
+    `seq`: optional preallocated output (static buffer for hipGraph capture).  Two collectives, (v+1)*s*s*C elements
+    received per sample instead of the 2*v*s*s*C of an all-gather of whole canvases."""
+    b, T, C = x_local.shape
+    s2 = s * s
+    assert T == 2 * s2
+    world = mv_group_size()
+    rank = dist.get_rank() if world > 1 else 0
+    g = x_local.reshape(b, s, 2 * s, C)
+    if seq is None:
+        seq = torch.empty(b, world + 1, s2, C, dtype=x_local.dtype, device=x_local.device)
+    else:
+        seq = seq.reshape(b, world + 1, s2, C)
+    ref = g[:, :, :s, :].reshape(b, s2, C).contiguous()
+    tgt = g[:, :, s:, :].reshape(b, s2, C).contiguous()
+    if world == 1:
+        seq[:, 0] = tgt
+        seq[:, 1] = ref
+        return seq.reshape(b, 2 * s2, C)
+    if _staged(x_local):
+        ref_h, tgt_h = ref.cpu(), tgt.cpu()
+        allr = torch.empty(world * b, s2, C, dtype=ref_h.dtype)           # concatenation form (the one gloo accepts)
+        dist.all_gather_into_tensor(allr, ref_h)
+        dist.broadcast(tgt_h, src=0)
+        seq[:, 0] = tgt_h.to(x_local.device)
+        seq[:, 1:] = allr.reshape(world, b, s2, C).permute(1, 0, 2, 3).to(x_local.device)
+        return seq.reshape(b, (world + 1) * s2, C)
+    if b == 1:          # the gathered blocks are already in sequence order: receive straight into the sequence buffer
+        dist.all_gather_into_tensor(seq[0, 1:], ref)        # [world, s2, C] <- world x [1, s2, C]
+        if rank == 0:
+            seq[0, 0].copy_(tgt[0])
+        dist.broadcast(seq[0, 0], src=0)
+    else:
+        allr = torch.empty(world * b, s2, C, dtype=ref.dtype, device=ref.device)
+        dist.all_gather_into_tensor(allr, ref)
+        dist.broadcast(tgt, src=0)
+        seq[:, 0] = tgt
+        seq[:, 1:] = allr.reshape(world, b, s2, C).permute(1, 0, 2, 3)
+    return seq.reshape(b, (world + 1) * s2, C)
+
+
 def mv_all_gather_canvases(x_local):
-    """x_local [b, T, C] (this rank's canvas of each of the b local sample groups) -> [b, v, T, C] in rank order."""
+    """x_local [b, T, C] -> [b, v, T, C] in rank order (whole canvases; kept for tests of the index helpers)."""
     world = mv_group_size()
     if world == 1:
         return x_local[:, None]
-    if x_local.is_cuda and dist.get_backend() == "gloo":
-        # test transport only (ranks sharing one GPU, tests/test_gpu_unet.py): gloo has no device all_gather -> stage on host
-        host = x_local.detach().cpu().contiguous()
-        bufs = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(bufs, host)
-        return torch.stack(bufs, dim=1).to(x_local.device)
-    bufs = [torch.empty_like(x_local) for _ in range(world)]
-    dist.all_gather(bufs, x_local.contiguous())
-    return torch.stack(bufs, dim=1)
+    src = x_local.detach().cpu().contiguous() if _staged(x_local) else x_local.contiguous()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.reshape((world,) + tuple(src.shape)).transpose(0, 1).contiguous().to(x_local.device)
 
 
 def mv_sequence_from_canvases(x_all, s):

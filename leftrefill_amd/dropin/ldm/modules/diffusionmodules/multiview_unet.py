@@ -11,17 +11,24 @@ from ldm.modules.multiview_attention import MultiViewSpatialTransformer
 
 class MultiViewUnetModel(UNetModel):
     """`mv_shard = True` (attribute, not in the reference) runs ONE canvas per rank: torch.distributed world size must be
-    view_num - 1; every transformer block all-gathers the canvases over RCCL before the re-arranged self-attention
-    (leftrefill_amd.dist).  The step is then launched eagerly (collectives are not captured into the hipGraph)."""
+    view_num - 1; every transformer block exchanges the reference halves (all_gather_into_tensor) and rank 0's target half
+    (broadcast) over RCCL before the re-arranged self-attention (leftrefill_amd.dist.mv_gather_sequence).
+    `mv_shard_graph = True` captures the whole step INCLUDING those collectives into the hipGraph (every rank captures and
+    replays in lockstep; needs the `nccl` backend -- PyTorch records RCCL kernels like any other stream work); the default
+    launches the sharded step eagerly."""
     st_cls = MultiViewSpatialTransformer
     mv_shard = False
+    mv_shard_graph = False
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         from leftrefill_amd import engine
         if not self.mv_shard:
             return super().forward(x, timesteps, context, y, **kwargs)
+        import torch.distributed as tdist
+        graph_ok = (self.mv_shard_graph and self.use_hip_graph and tdist.is_available() and tdist.is_initialized()
+                    and tdist.get_backend() == "nccl")
         prev_graph, prev_flag = self.use_hip_graph, engine.MV_SHARDED
-        self.use_hip_graph, engine.MV_SHARDED = False, True
+        self.use_hip_graph, engine.MV_SHARDED = graph_ok, True
         try:
             return super().forward(x, timesteps, context, y, **kwargs)
         finally:

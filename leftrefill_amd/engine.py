@@ -296,8 +296,10 @@ MV_SHARDED = False
 
 
 def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
-    """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (one RCCL all-gather
-    per block; see leftrefill_amd.dist).  x [N*L, C] = this rank's canvas for each of its N local samples."""
+    """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (leftrefill_amd.dist:
+    all-gather of the reference halves + broadcast of rank 0's target half per block).  x [N*L, C] = this rank's canvas
+    for each of its N local samples.  K / V are built for the whole sequence, Q / attention / out-projection only for the
+    rows this rank owns ([target, ref_rank]); the target rows are replicated, bit-identical work on every rank."""
     import torch.distributed as tdist
     from . import dist as lrd
     C = x.shape[1]
@@ -307,14 +309,15 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
     world = lrd.mv_group_size()
     assert world == v, f"multi-view sharding needs world_size == view_num - 1 ({world} vs {v})"
     rank = tdist.get_rank() if world > 1 else 0
-    x_all = lrd.mv_all_gather_canvases(x.reshape(N, L, C))                    # [N, v, L, C]
-    seq = ops.mv_gather(x_all.reshape(N * v * L, C), N, v, s)                 # [N*(v+1)*s*s, C]
     Ls = (v + 1) * s * s
-    n_seq = ops.layer_norm(seq, pt.n1.g, pt.n1.b, pt.n1.eps)
-    qkv = linear(n_seq, pt.attn1.qkv)                                         # K/V needed for all rows; Q is cheap
-    own_q = lrd.mv_own_rows(qkv[:, :C].reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
-    own_x = lrd.mv_own_rows(seq.reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
-    a = ops.attention(own_q, qkv[:, C:2 * C], qkv[:, 2 * C:], N, pt.attn1.heads, L, Ls, pt.attn1.dim_head ** -0.5)
+    seq = lrd.mv_gather_sequence(x.reshape(N, L, C), s)                       # [N, Ls, C]
+    n_seq = ops.layer_norm(seq.reshape(N * Ls, C), pt.n1.g, pt.n1.b, pt.n1.eps)
+    w = pt.attn1.qkv.w                                                        # rows [Wq; Wk; Wv] of the fused projection
+    kv = ops.gemm_conv(n_seq, w[C:], B=1, H=1, W=N * Ls, taps=1)              # K | V for every row of the sequence
+    own_n = lrd.mv_own_rows(n_seq.reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
+    own_x = lrd.mv_own_rows(seq, rank, s).reshape(N * L, C).contiguous()
+    q = ops.gemm_conv(own_n, w[:C], B=1, H=1, W=N * L, taps=1)                # Q only for the rows this rank owns
+    a = ops.attention(q, kv[:, :C], kv[:, C:], N, pt.attn1.heads, L, Ls, pt.attn1.dim_head ** -0.5)
     y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target', ref_rank']
     return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
 

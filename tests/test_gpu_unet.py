@@ -309,12 +309,17 @@ def test_full_size_properties_config4_mv5():
     torch.cuda.empty_cache()
 
 
-def _mv_shard_worker(rank, world, port, q):
+def _mv_shard_worker(rank, world, port, q, backend="gloo"):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend.startswith("nccl"):          # one process per GPU, RCCL over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         install()
         from ldm.modules.diffusionmodules.multiview_unet import MultiViewUnetModel
@@ -323,21 +328,43 @@ def _mv_shard_worker(rank, world, port, q):
         sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MV.")
         m = MultiViewUnetModel(**cfg.kwargs())
         m.load_state_dict(sd, strict=True)
-        m = m.to(dev()).eval()
+        d = torch.device("cuda", rank) if backend.startswith("nccl") else dev()
+        m = m.to(d).eval()
         m.mv_shard = True
+        m.mv_shard_graph = backend == "nccl-graph"
         x, t, ctx = G.unet_inputs("mv_shard2", cfg, b * world, H, W, [501] * (b * world))
         sl = slice(rank, rank + 1)                     # this rank's canvas [ref_rank | target]
         with torch.no_grad():
-            y = m(x[sl].to(dev()), t[sl].to(dev()), ctx[sl].to(dev()))
+            y = m(x[sl].to(d), t[sl].to(d), ctx[sl].to(d))
+            if m.mv_shard_graph:
+                assert torch.equal(m(x[sl].to(d), t[sl].to(d), ctx[sl].to(d)), y)      # replay of the captured step
         q.put((rank, y.float().cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs for an RCCL (nccl backend) group")
+def test_multiview_canvas_sharded_over_rccl():
+    """The same one-canvas-per-rank run on two real GPUs over the `nccl` backend (RCCL / xGMI): all_gather_into_tensor of
+    the reference halves + broadcast of rank 0's target half per block; skipped on single-GPU boxes."""
+    _run_mv_sharded("nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs for an RCCL (nccl backend) group")
+def test_multiview_canvas_sharded_over_rccl_in_hipgraph():
+    """... with the whole step, collectives included, captured into a hipGraph on every rank (`mv_shard_graph`)."""
+    _run_mv_sharded("nccl-graph")
+
+
 def test_multiview_canvas_sharded_two_ranks_on_one_gpu():
     """One canvas per rank (world = view_num - 1 = 2; both ranks share cuda:0 and exchange over gloo because a 1-GPU box has
-    no second RCCL peer): every transformer block all-gathers the canvases, builds K/V for [target, ref_0, ref_1] and
-    attends only for its own rows.  Each rank's canvas must match the CPU oracle of the joint multi-view UNet."""
+    no second RCCL peer): every transformer block gathers the reference halves and rank 0's target half, builds K/V for
+    [target, ref_0, ref_1] and attends only for its own rows.  Each rank's canvas must match the CPU oracle of the joint
+    multi-view UNet."""
+    _run_mv_sharded("gloo")
+
+
+def _run_mv_sharded(backend):
     import socket
     import torch.multiprocessing as mp
     world, H, W = 2, 8, 16
@@ -352,7 +379,7 @@ def test_multiview_canvas_sharded_two_ranks_on_one_gpu():
     s.close()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    procs = [mpctx.Process(target=_mv_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [mpctx.Process(target=_mv_shard_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))

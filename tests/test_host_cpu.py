@@ -393,8 +393,13 @@ def _mv_worker(rank, world, port, q):
     # sharded: this rank only holds canvas `rank` of every sample
     x_local = x_full.reshape(b, v, L, C)[:, rank].contiguous()
     x_all = lrd.mv_all_gather_canvases(x_local)
-    sq = lrd.mv_sequence_from_canvases(x_all, s)
+    assert torch.equal(lrd.mv_sequence_from_canvases(x_all, s), seq)          # whole-canvas exchange (reference of the helper)
+    sq = lrd.mv_gather_sequence(x_local, s)                                    # minimal exchange: ref halves + rank 0's target
     assert torch.equal(sq, seq)
+    one = lrd.mv_gather_sequence(x_local[:1].contiguous(), s)                  # b == 1: receives straight into the sequence buffer
+    assert torch.equal(one, seq[:1])
+    buf = torch.empty(b, (v + 1) * s * s, C)
+    assert lrd.mv_gather_sequence(x_local, s, seq=buf).data_ptr() == buf.data_ptr() and torch.equal(buf, seq)
     n = unet_ref.layer_norm(sq, sd["m.norm1.weight"], sd["m.norm1.bias"])
     qq = torch.nn.functional.linear(n, sd["m.attn1.to_q.weight"])
     kk = torch.nn.functional.linear(n, sd["m.attn1.to_k.weight"])
