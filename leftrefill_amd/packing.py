@@ -55,7 +55,7 @@ def fold_layernorm(w, b, gamma, beta):
     w32 = w.float()
     wf = (w32 * gamma.float()[None, :]).to(torch.float16).contiguous()
     cs = wf.float().sum(dim=1).contiguous()
-    bf = w32 @ beta.float()
+    bf = (w32 * beta.float()[None, :]).sum(dim=1)     # not `@`: packing may run inside a caller's autocast region (fp16 matmul)
     if b is not None:
         bf = bf + b.float()
     return wf, bf.contiguous(), cs

@@ -1,0 +1,83 @@
+"""Caller glue either side of the hot path, CPU: the drop-in `dataloaders.test_dataset` loader and the
+SSIM restatement, both checked against independent brute-force computations."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_pairs(root, n=3, hw=(96, 80), seed=0):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        d = os.path.join(root, f"pair_{i:02d}")
+        os.makedirs(d)
+        for stem in ("source", "target"):
+            Image.fromarray(rng.randint(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)).save(os.path.join(d, stem + ".png"))
+        m = (rng.rand(hw[0], hw[1]) < 0.4).astype(np.uint8) * 255
+        Image.fromarray(np.stack([m, m, m], -1)).save(os.path.join(d, "mask.png"))
+    return root
+
+
+def test_dataset_contract_and_prompts(tmp_path):
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    from dataloaders.test_dataset import TestInpaintingDataset, resize_area, resize_nearest
+    from PIL import Image
+    root = _write_pairs(str(tmp_path / "pairs"))
+    ds = TestInpaintingDataset(root, img_size=32, repeat_sp_token=3, sp_token="<special-token>")
+    assert len(ds) == 3
+    it = ds[1]
+    assert it["image"].shape == (32, 64, 3) and it["image"].dtype == np.float32
+    assert it["mask"].shape == (32, 64, 1) and set(np.unique(it["mask"])) <= {0.0, 1.0}
+    assert it["image"].min() >= -1.0 and it["image"].max() <= 1.0
+    assert (it["mask"][:, :32] == 0).all() and it["mask"][:, 32:].mean() > 0.1      # left = reference: never masked
+    assert np.array_equal(it["masked_image"], it["image"] * (it["mask"] < 0.5))
+    assert it["txt"] == "<special-token0> <special-token1> <special-token2>"
+    # area resize == exact average over the source footprint (96 -> 32 rows: 3 rows each; 80 -> 32 columns: 2.5 columns)
+    src = np.asarray(Image.open(os.path.join(root, "pair_01", "source.png")).convert("RGB")).astype(np.float64)
+    rows = src.reshape(32, 3, 80, 3).mean(1)
+    col0 = (rows[:, 0] + rows[:, 1] + 0.5 * rows[:, 2]) / 2.5
+    got = (it["image"][:, 0] + 1.0) * 127.5
+    assert np.abs(got - np.rint(col0)).max() <= 1.0 + 1e-3
+    sq = src.astype(np.uint8)[:80, :80]
+    assert np.array_equal(resize_area(sq, 80), sq)          # identity size: untouched
+    # nearest: source index floor(dst * scale)
+    m = np.arange(96 * 80).reshape(96, 80)
+    r = resize_nearest(m, 32)
+    assert r[5, 7] == m[15, int(7 * 2.5)] and r[31, 31] == m[93, 77]
+    # batching through torch's DataLoader, as the harness does
+    from torch.utils.data import DataLoader
+    b = next(iter(DataLoader(ds, batch_size=2, shuffle=False)))
+    assert b["image"].shape == (2, 32, 64, 3) and b["mask"].shape == (2, 32, 64, 1) and len(b["txt"]) == 2
+    # deep prompts: one prompt per cross-attention layer; token-map prompt; legacy prompt; pair list file
+    dp = TestInpaintingDataset(root, img_size=32, repeat_sp_token=2, sp_token="<special-token>", deep_prompt=True).get_prompt()
+    assert len(dp) == 16 and dp[3] == "<special-token0-layer3> <special-token1-layer3>"
+    tm = dict(left_token="<left>", right_token="<right>", task_token="<task>", real_token="<real>")
+    assert TestInpaintingDataset(root, token_map=tm).get_prompt() == "Both <left> and <right> images show the <real> with different <task>."
+    assert TestInpaintingDataset(root).get_prompt() == "[REFERENCE_INPAINTING]"
+    lst = tmp_path / "pairs.txt"
+    lst.write_text("\n".join(sorted(os.path.join(root, d) for d in os.listdir(root))) + "\n")
+    assert len(TestInpaintingDataset(str(lst), img_size=32)) == 3
+
+
+def test_ssim_matches_bruteforce_definition():
+    from leftrefill_amd import evalglue
+    rng = np.random.RandomState(1)
+    a = rng.rand(24, 30).astype(np.float32)
+    b = np.clip(a + 0.1 * rng.randn(24, 30), 0, 1).astype(np.float32)
+    assert abs(evalglue.ssim_gray(torch.from_numpy(a), torch.from_numpy(a)) - 1.0) < 1e-12
+    # brute force over every fully-inside 7x7 window (the border windows are exactly the ones the mean excludes)
+    c1, c2 = (0.01 * 2.0) ** 2, (0.03 * 2.0) ** 2
+    vals = []
+    for y in range(3, 24 - 3):
+        for x in range(3, 30 - 3):
+            pa, pb = a[y - 3:y + 4, x - 3:x + 4].astype(np.float64), b[y - 3:y + 4, x - 3:x + 4].astype(np.float64)
+            ua, ub = pa.mean(), pb.mean()
+            va, vb = pa.var(ddof=1), pb.var(ddof=1)
+            vab = ((pa - ua) * (pb - ub)).sum() / 48.0
+            vals.append(((2 * ua * ub + c1) * (2 * vab + c2)) / ((ua * ua + ub * ub + c1) * (va + vb + c2)))
+    assert abs(evalglue.ssim_gray(torch.from_numpy(a), torch.from_numpy(b)) - np.mean(vals)) < 1e-9
+    g = evalglue.rgb_to_gray01(torch.tensor([[[1.0]], [[-1.0]], [[0.0]]]))
+    assert abs(g.item() - (0.2989 * 1.0 + 0.587 * 0.0 + 0.114 * 0.5)) < 1e-6

@@ -6,11 +6,13 @@
 Call sequence reproduced (reference line numbers): create_model(model_config.yaml).cpu() (82) -> load newest
 ckpts/epoch=*.ckpt, then pretrained_models/512-inpainting-ema.ckpt when `save_prompt_only` (84-97) -> .to("cuda").eval()
 (102-103) -> no_grad + autocast (126) -> model.log_images(batch, N, unconditional_guidance_scale=cfg, ddim_eta=eta) (141)
--> pred*mask + origin*(1-mask) (146-147) -> keep the right half (148-150) -> PSNR on (x+1)/2 (158) -> PNG (168-190).
-LPIPS / SSIM need third-party packages that are out of scope; PSNR is computed directly.
+-> pred*mask + origin*(1-mask) (146-147) -> keep the right half (148-150) -> PSNR on (x+1)/2 (158), SSIM on the luma (160-162)
+-> PNG (168-190).  LPIPS needs the pretrained AlexNet of the `lpips` package (no weights without network): not computed.
 
-Without --test_path (no dataset ships with the reference) `--synthetic N` builds N batches with the batch contract of
-dataloaders/test_dataset.py:91-105: image [B,512,1024,3] in [-1,1] (left reference | right target), mask [B,512,1024,1]
+--test_path DIR is read through `dataloaders.test_dataset.TestInpaintingDataset` (drop-in of the reference loader: pair
+directories with source / target / mask files) and torch's DataLoader, exactly like the reference (118-120).  Without it
+(no dataset ships with the reference) `--synthetic N` builds N batches with the same batch contract
+(dataloaders/test_dataset.py:91-105): image [B,512,1024,3] in [-1,1] (left reference | right target), mask [B,512,1024,1]
 (left half 0), masked_image = image*(mask<0.5), txt = "<special-token0> ... <special-token49>".
 """
 import argparse
@@ -36,22 +38,15 @@ def synthetic_batches(n, batch_size, size, sp_token="<special-token>", repeat=50
         yield {"image": img, "mask": mask, "masked_image": img * (mask < 0.5), "txt": [txt] * batch_size}
 
 
-def folder_batches(path, batch_size, size):
-    """<path>/*_ref.png + *_tgt.png + *_mask.png triplets, loaded with PIL (the reference uses cv2, test_dataset.py:62-90)."""
-    from PIL import Image
-    refs = sorted(glob.glob(os.path.join(path, "*_ref.png")))
-    items = []
-    for r in refs:
-        t, m = r.replace("_ref.png", "_tgt.png"), r.replace("_ref.png", "_mask.png")
-        ld = lambda p, mode: np.asarray(Image.open(p).convert(mode).resize((size, size)), dtype=np.float32) / 255.0
-        img = np.concatenate([ld(r, "RGB"), ld(t, "RGB")], axis=1) * 2 - 1
-        mask = np.concatenate([np.zeros((size, size, 1), np.float32), (ld(m, "L")[..., None] > 0.5).astype(np.float32)], 1)
-        items.append((img, mask))
-    for i in range(0, len(items), batch_size):
-        img = torch.from_numpy(np.stack([a for a, _ in items[i:i + batch_size]]))
-        mask = torch.from_numpy(np.stack([b for _, b in items[i:i + batch_size]]))
-        txt = " ".join(f"<special-token{j}>" for j in range(50))
-        yield {"image": img, "mask": mask, "masked_image": img * (mask < 0.5), "txt": [txt] * img.shape[0]}
+def dataset_batches(path, batch_size, size, model):
+    """The reference's loader + DataLoader (test_inpainting.py:118-120)."""
+    from torch.utils.data import DataLoader
+    from dataloaders.test_dataset import TestInpaintingDataset
+    cond_cfg = getattr(model, "cond_cfg", None) or {}
+    data_cfg = dict(getattr(model, "data_cfg", None) or {})
+    data_cfg.pop("img_size", None)
+    ds = TestInpaintingDataset(path, img_size=size, deep_prompt=cond_cfg.get("deep_prompt", False), **data_cfg)
+    return DataLoader(ds, batch_size=batch_size, shuffle=False)
 
 
 def main():
@@ -64,6 +59,7 @@ def main():
     ap.add_argument("--metric_size", type=int, default=512)
     ap.add_argument("--eta", type=float, default=1.0)
     ap.add_argument("--output_path", type=str, default="outputs")
+    ap.add_argument("--metric_output", type=str, default="metric_outputs")
     ap.add_argument("--ngpu", type=int, default=1)       # parsed but unused, like the reference (62, 99)
     ap.add_argument("--fp16", action="store_true")       # idem (63)
     ap.add_argument("--synthetic", type=int, default=0)
@@ -83,15 +79,20 @@ def main():
         print(model.load_state_dict(load_state_dict(a.pretrained), strict=False))
     model = model.to("cuda").eval()
     os.makedirs(a.output_path, exist_ok=True)
-    batches = folder_batches(a.test_path, a.batch_size, a.test_size) if a.test_path else \
+    batches = dataset_batches(a.test_path, a.batch_size, a.test_size, model) if a.test_path else \
         synthetic_batches(max(1, a.synthetic), a.batch_size, a.test_size)
-    psnrs = []
+    psnrs, ssims = [], []
     with torch.no_grad(), torch.autocast("cuda"):
         for bi, batch in enumerate(batches):
             batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
             out = model.log_images(batch, batch["image"].shape[0], unconditional_guidance_scale=a.cfg, ddim_eta=a.eta)
+            if not torch.isfinite(out["pred"]).all():
+                bad = (~torch.isfinite(out["pred"])).float().mean().item()
+                print(f"WARNING: {100 * bad:.2f} % of the decoded prediction is not finite (batch {bi})")
             pred, origin = evalglue.compose_prediction(out, batch["mask"], a.test_size, a.metric_size)
             psnrs.extend(evalglue.psnr01(pred, origin).tolist())
+            for j in range(pred.shape[0]):
+                ssims.append(evalglue.ssim_gray(evalglue.rgb_to_gray01(pred[j]), evalglue.rgb_to_gray01(origin[j])))
             p01 = (pred.float().clamp(-1, 1) + 1) / 2
             try:
                 from PIL import Image
@@ -101,9 +102,10 @@ def main():
             except ImportError:
                 pass
     print(f"PSNR: {float(np.mean(psnrs)):.3f} over {len(psnrs)} images")
-    os.makedirs("metric_outputs", exist_ok=True)
-    with open(os.path.join("metric_outputs", os.path.basename(os.path.normpath(a.model_path)) + ".txt"), "w") as f:
-        f.write(f"PSNR: {float(np.mean(psnrs)):.4f}\n")
+    print(f"SSIM: {float(np.mean(ssims)):.4f}")
+    os.makedirs(a.metric_output, exist_ok=True)
+    with open(os.path.join(a.metric_output, os.path.basename(os.path.normpath(a.model_path)) + ".txt"), "w") as f:
+        f.write(f"PSNR: {float(np.mean(psnrs)):.4f}\nSSIM: {float(np.mean(ssims)):.4f}\n")
 
 
 if __name__ == "__main__":
