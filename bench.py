@@ -246,7 +246,11 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     Bt, h, w = 16, 32, 64
     steps = steps or a.steps
     model = (model or build_model(device, "single")).train()
-    model.model.diffusion_model.recompute_in_backward = bool(getattr(a, "recompute", False))
+    bf16 = getattr(a, "dtype", "f16") == "bf16"
+    unet = model.model.diffusion_model
+    prev_dtype = unet.compute_dtype
+    unet.compute_dtype = torch.bfloat16 if bf16 else torch.float16      # re-packs the weights on the next forward
+    unet.recompute_in_backward = bool(getattr(a, "recompute", False))
     for p in model.parameters():
         p.requires_grad_(False)
     g0 = torch.Generator(device=device).manual_seed(99)            # parameters: the SAME initial tokens on every rank
@@ -259,7 +263,8 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     # dynamic loss scale like the reference's fp16 AMP (Lightning precision=16 -> GradScaler, train_inpainting.py:52,127):
     # a non-finite scaled gradient skips the step and halves the scale, 200 clean steps double it.  The hipGraph variant
     # keeps the scale fixed (the decision needs the host).
-    scaler = {"scale": 2.0 ** 14, "good": 0, "skipped": 0}
+    # bf16 (BASELINE configs[4]) has fp32's exponent range: no loss scale.
+    scaler = {"scale": 1.0 if bf16 else 2.0 ** 14, "good": 0, "skipped": 0}
 
     t_buf = torch.zeros(Bt, device=device, dtype=torch.long)
     noise_buf = torch.zeros(Bt, 4, h, w, device=device)
@@ -281,7 +286,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
         tokens.grad /= scaler["scale"]
         opt.step()
         scaler["good"] += 1
-        if scaler["good"] % 200 == 0:
+        if scaler["good"] % 200 == 0 and not bf16:
             scaler["scale"] *= 2.0
         return loss
 
@@ -335,21 +340,23 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
     model.eval()
     with torch.no_grad():      # forward alone, same shapes (eager, like the training forward)
-        unet = model.model.diffusion_model
         unet.use_hip_graph = False
         xin = torch.cat([x_start, c_concat], 1)
         tt_ = torch.full((Bt,), 501, device=device, dtype=torch.long)
-        unet(xin, tt_, base_ctx.half())
+        unet(xin, tt_, base_ctx.to(unet.compute_dtype))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
-            unet(xin, tt_, base_ctx.half())
+            unet(xin, tt_, base_ctx.to(unet.compute_dtype))
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / 3 * 1e3
+    unet.compute_dtype = prev_dtype
     return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "configs[4]-like: canvas 256x512 (latent 32x64), per-GPU batch 16, fp16 + loss scale 2^14, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f16", "data": "synthetic",
+            "config": {"workload": "configs[4]: canvas 256x512 (latent 32x64), per-GPU batch 16, "
+                                   + ("bf16 (no loss scale), " if bf16 else "fp16 + dynamic loss scale, ") +
+                                   
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
             "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb,
@@ -442,6 +449,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"],
+                    help="train workload: 16-bit type of activations / packed weights (configs[4] names bf16; the metric "
+                         "workloads are fp16 like the reference's autocast)")
     ap.add_argument("--train-graph", action="store_true", help="train workload: capture the whole step into one hipGraph")
     ap.add_argument("--recompute", action="store_true", help="train workload: recompute blocks in the backward (use_checkpoint)")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
@@ -570,6 +580,14 @@ def main():
                 tr = train_bench(a, rank, world, device, model=model, steps=3)
                 return {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
             side("training_256x512_b16", train)
+
+            def train_bf16():
+                a.dtype = "bf16"
+                try:
+                    return train()
+                finally:
+                    a.dtype = "f16"
+            side("training_256x512_b16_bf16", train_bf16)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline()

@@ -26,7 +26,12 @@ extern "C" {
 #define LR_E_UNSUPPORTED (-3)
 
 typedef void* lr_stream_t; /* hipStream_t */
-typedef uint16_t lr_half;  /* IEEE binary16 bits */
+typedef uint16_t lr_half;  /* 16-bit activation / weight element: IEEE binary16 bits, or bfloat16 bits in the *_bf16 entry points */
+/* 16-bit compute type.  Every kernel exists for both: fp16 is what the reference's autocast inference and its fp16 AMP training
+ * use (train_inpainting.py:52,127); bf16 is BASELINE configs[4].  Entry points named lr_<op>_bf16 have the signature of
+ * lr_<op> (lr_<op>_f16) and read / write bfloat16 (declared at the end of this header); lr_gemm_args carries a `dtype` field. */
+#define LR_DTYPE_F16 0
+#define LR_DTYPE_BF16 1
 
 /* ABI version; bump on any signature change. */
 int lr_abi_version(void);
@@ -128,6 +133,7 @@ typedef struct lr_gemm_args {
    * (openaimodel.py:254-274) comes out of the producer's epilogue; lr_groupnorm_finalize turns the blocks of one sample
    * (H*W must be a multiple of R) into per-group sums.  Fixed order, no atomics.  Not with split-K or GEGLU. */
   float* gn_stats_out;
+  int32_t dtype;            /* LR_DTYPE_F16 | LR_DTYPE_BF16: type of p1, p2, wt, rowvec, resid, out (geglu == 2 is fp16 only) */
 } lr_gemm_args;
 /* rows per block of gn_stats_out (a function of the tile that will be used) */
 int lr_gemm_gn_rows(const lr_gemm_args* args);
@@ -222,6 +228,48 @@ int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, int s, int 
 int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
 /* nearest-2x upsample: y[n][h][w][:] = sum of the four fine pixels of x [N][2H][2W][C]. */
 int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
+
+/* ---- bfloat16 twins: same signatures and semantics as the fp16 entry points above, every lr_half is bfloat16 bits -------- */
+int lr_groupnorm_stats_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
+    lr_stream_t s);
+int lr_groupnorm_apply_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float*
+    partials, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
+int lr_groupnorm_apply_n_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float*
+    partials, int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
+int lr_layernorm_bf16(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C,
+    lr_stream_t s);
+int lr_layernorm_bwd_bf16(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M, int
+    C, lr_stream_t s);
+int lr_groupnorm_bwd_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
+    const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials,
+    lr_half* dx1, lr_half* dx2, lr_stream_t s);
+int lr_nchw_f32_to_nhwc_bf16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N, int H, int
+    W, lr_stream_t s);
+int lr_nhwc_f16_to_nchw_bf16(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W,
+    lr_stream_t s);
+int lr_timestep_embedding_bf16(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s);
+int lr_linear_small_m_bf16(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo, int
+    M, int N, int K, int act_in, int act_out, lr_stream_t s);
+int lr_mv_gather_bf16(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st);
+int lr_mv_scatter_bf16(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st);
+int lr_ddim_cfg_step_bf16(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev, float*
+    pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,
+    lr_stream_t s);
+int lr_geglu_fwd_bf16(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s);
+int lr_geglu_bwd_bf16(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s);
+int lr_sumpool2x2_bf16(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
+int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st);
+int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
+int lr_attention_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int
+    ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+int lr_attention_causal_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half*
+    o, int ldo, int B, int heads, int N, float scale, lr_stream_t s);
+int lr_attention_lse_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
+    int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+int lr_attention_vt_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt, lr_half*
+    o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
+int lr_transpose_v_bf16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s);
+int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s);
 
 #ifdef __cplusplus
 }

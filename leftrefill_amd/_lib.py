@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -36,6 +36,7 @@ class GemmArgs(ctypes.Structure):
         ("ln_colsum", c_void_p),
         ("stats_out", c_void_p),
         ("gn_stats_out", c_void_p),
+        ("dtype", ctypes.c_int32),
     ]
 
 
@@ -91,7 +92,32 @@ SIGNATURES = {
                          c_float, c_float, c_void_p],
 }
 
+# bfloat16 twins (include/leftrefill_hip.h, last section): same argument lists as the fp16 entry points
+BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n", "lr_layernorm", "lr_layernorm_bwd",
+              "lr_groupnorm_bwd", "lr_nchw_f32_to_nhwc_f16", "lr_nhwc_f16_to_nchw", "lr_timestep_embedding", "lr_linear_small_m",
+              "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
+              "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
+              "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16"]
+
+
+def twin(name):
+    """fp16 entry point -> its bfloat16 twin."""
+    return (name[:-4] if name.endswith("_f16") else name) + "_bf16"
+
+
+for _n in BF16_TWINS:
+    SIGNATURES[twin(_n)] = SIGNATURES[_n]
+
 _lib = None
+
+
+def fn(lib, name, dtype):
+    """The entry point `name` for 16-bit element type `dtype` (torch.float16 | torch.bfloat16)."""
+    import torch
+    if dtype == torch.bfloat16:
+        return getattr(lib, twin(name))
+    assert dtype == torch.float16, dtype
+    return getattr(lib, name)
 
 
 def load():

@@ -29,8 +29,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <typename T>
 struct AttnParams {
-  const f16* q; const f16* k; const f16* v; f16* o;
+  const T* q; const T* k; const T* v; T* o;
   int ldq, ldk, ldv, ldo, heads, Nq, Nkv, nqt, nblocks;
   float c;  // scale * log2(e)
   float* lse;  // optional [B][heads][Nq]: log2-domain log-sum-exp m*c + log2(l) (saved for the backward), or NULL
@@ -40,8 +41,8 @@ struct AttnParams {
 // the V tile then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment
 // is ONE ds_read_b128.
 // CAUSAL = true: key j is visible to query i only if j <= i (the text tower's attn_mask); every tile takes the masked path.
-template <bool VT, bool CAUSAL = false>
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams P) {
+template <typename T, bool VT, bool CAUSAL = false>
+__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams<T> P) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KB * 128 + 2 * 64 * VT_PITCH];
   char* Ksm = smem;
   char* Vsm = smem + 2 * ATT_KB * 128;
@@ -57,23 +58,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   const int bh = bid / P.nqt;
   const int h = bh % P.heads, b = bh / P.heads;
 
-  const f16* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
-  const f16* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
-  const f16* vp = VT ? P.v + ((size_t)b * P.heads + h) * 64 * P.ldv : P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
-  f16* op = P.o + (size_t)b * P.Nq * P.ldo + h * 64;
-  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
+  const T* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
+  const T* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
+  const T* vp = VT ? P.v + ((size_t)b * P.heads + h) * 64 * P.ldv : P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
+  T* op = P.o + (size_t)b * P.Nq * P.ldo + h * 64;
+  const T* zero = reinterpret_cast<const T*>(lr_zero_page);
 
   const int ql = lane & 31, hi = lane >> 5;
   // each wave owns 64 queries as two 32-query blocks that share every K / V fragment read from LDS
   int qrow[2];
-  f16x8 qf[2][4];   // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
+  vec8<T> qf[2][4];   // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     qrow[qb] = qt * ATT_QB + w * 64 + qb * 32 + ql;
     const int qc = min(qrow[qb], P.Nq - 1);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
-      qf[qb][s4] = *reinterpret_cast<const f16x8*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
+      qf[qb][s4] = *reinterpret_cast<const vec8<T>*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
   }
 
   const int ntiles = (P.Nkv + ATT_KB - 1) / ATT_KB;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       const int row = rbase + (lane >> 3);
       const int key = tile * ATT_KB + row;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const f16* g = key < P.Nkv ? kp + (size_t)key * P.ldk + chunk * 8 : zero;
+      const T* g = key < P.Nkv ? kp + (size_t)key * P.ldk + chunk * 8 : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ks + rbase * 128), 16, 0, 0);
     }
   };
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       const int rbase = (i * 4 + w) * 8;
       const int row = rbase + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const f16* g = vp + (size_t)row * P.ldv + tile * ATT_KB + chunk * 8;
+      const T* g = vp + (size_t)row * P.ldv + tile * ATT_KB + chunk * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Vs + rbase * 128), 16, 0, 0);
     }
   };
@@ -169,13 +170,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       for (int kb = 0; kb < 2; ++kb) {
         const int row = kb * 32 + ql;
         const int kc = s4 * 2 + hi;
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+        const vec8<T> kf = *reinterpret_cast<const vec8<T>*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][kb], 0, 0, 0);
+          sacc[qb][kb] = lr_mfma32(kf, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][kb]);
       }
 
-    f16x8 pf[2][2][2];
+    vec8<T> pf[2][2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
           const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
           ps2 += pv;
-          pf[qb][kb][r >> 3][r & 7] = (f16)pv[0];
-          pf[qb][kb][r >> 3][(r & 7) + 1] = (f16)pv[1];
+          pf[qb][kb][r >> 3][r & 7] = (T)pv[0];
+          pf[qb][kb][r >> 3][(r & 7) + 1] = (T)pv[1];
         }
       l_run[qb] += ps2[0] + ps2[1];
     }
@@ -239,20 +240,20 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int drow = db * 32 + ql;
-          f16x8 vf;
+          vec8<T> vf;
           if constexpr (VT) {
             const int vc = kb * 4 + tt * 2 + hi;     // 16-byte chunk = this lane's 8 k-slots, contiguous after the permute
-            vf = *reinterpret_cast<const f16x8*>(Vs + drow * 128 + ((vc ^ ((drow >> 1) & 7)) << 4));
+            vf = *reinterpret_cast<const vec8<T>*>(Vs + drow * 128 + ((vc ^ ((drow >> 1) & 7)) << 4));
           } else {
             const int key0 = kb * 32 + 16 * tt + 4 * hi;
-            const f16x4 va = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + key0 * 2);
-            const f16x4 vb = *reinterpret_cast<const f16x4*>(Vs + drow * VT_PITCH + (key0 + 8) * 2);
+            const vec4<T> va = *reinterpret_cast<const vec4<T>*>(Vs + drow * VT_PITCH + key0 * 2);
+            const vec4<T> vb = *reinterpret_cast<const vec4<T>*>(Vs + drow * VT_PITCH + (key0 + 8) * 2);
             vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
             vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
           }
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb)
-            oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][tt], oacc[qb][db], 0, 0, 0);
+            oacc[qb][db] = lr_mfma32(vf, pf[qb][kb][tt], oacc[qb][db]);
         }
     if constexpr (!VT) {
       if (more) write_v(cur ^ 1, nv0, nv1);
@@ -280,15 +281,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f16x4 ov;
+          vec4<T> ov;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ov[i] = (f16)(oacc[qb][db][g * 4 + i] * inv);
-          *reinterpret_cast<f16x4*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * g + 4 * hi) = ov;
+          for (int i = 0; i < 4; ++i) ov[i] = (T)(oacc[qb][db][g * 4 + i] * inv);
+          *reinterpret_cast<vec4<T>*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * g + 4 * hi) = ov;
         }
     }
   }
 }
 
+template <typename T>
 static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                             int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt,
                             float* lse = nullptr) {
@@ -296,51 +298,55 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
   if (vt && (ldv % ATT_KB || ldv < Nkv)) return LR_E_ALIGN;
-  AttnParams P;
-  P.q = (const f16*)q; P.k = (const f16*)k; P.v = (const f16*)v; P.o = (f16*)o;
+  AttnParams<T> P;
+  P.q = (const T*)q; P.k = (const T*)k; P.v = (const T*)v; P.o = (T*)o;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.heads = heads; P.Nq = Nq; P.Nkv = Nkv;
   P.nqt = (Nq + ATT_QB - 1) / ATT_QB;
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = lse;
-  if (vt) hipLaunchKernelGGL(attention_kernel<true>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
-  else hipLaunchKernelGGL(attention_kernel<false>, dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  if (vt) hipLaunchKernelGGL((attention_kernel<T, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  else hipLaunchKernelGGL((attention_kernel<T, false>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }
 
-extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+template <typename T>
+static int lr_attention_t(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                 lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
-  return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false);
+  return launch_attention<T>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false);
 }
 
-extern "C" int lr_attention_causal_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+template <typename T>
+static int lr_attention_causal_t(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                        lr_half* o, int ldo, int B, int heads, int N, float scale, lr_stream_t s) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || N <= 0) return LR_E_ARG;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
-  AttnParams P;
-  P.q = (const f16*)q; P.k = (const f16*)k; P.v = (const f16*)v; P.o = (f16*)o;
+  AttnParams<T> P;
+  P.q = (const T*)q; P.k = (const T*)k; P.v = (const T*)v; P.o = (T*)o;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.heads = heads; P.Nq = N; P.Nkv = N;
   P.nqt = (N + ATT_QB - 1) / ATT_QB;
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = nullptr;
-  hipLaunchKernelGGL((attention_kernel<false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  hipLaunchKernelGGL((attention_kernel<T, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }
 
-extern "C" int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
+template <typename T>
+static int lr_attention_lse_t(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                     lr_half* o, int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale,
                                     lr_stream_t s) {
   if (!lse) return LR_E_ARG;
-  return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false, lse);
+  return launch_attention<T>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s, false, lse);
 }
 
-extern "C" int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt,
+template <typename T>
+static int lr_attention_vt_t(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt,
                                    lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) {
-  return launch_attention(q, ldq, k, ldk, vt, ld_vt, o, ldo, B, heads, Nq, Nkv, scale, s, true);
+  return launch_attention<T>(q, ldq, k, ldk, vt, ld_vt, o, ldo, B, heads, Nq, Nkv, scale, s, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -349,12 +355,13 @@ extern "C" int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, 
 // P^T (the S^T accumulator's key order, see attention_kernel) become one contiguous 16-byte piece.
 // grid = (key tiles, heads, B), block = 256.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict__ v, int ldv, f16* __restrict__ vt, int ld_vt,
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ v, int ldv, T* __restrict__ vt, int ld_vt,
                                                           int heads, int Nkv) {
-  __shared__ f16 tile[64][72];     // [key][d], 144-byte pitch
+  __shared__ T tile[64][72];     // [key][d], 144-byte pitch
   const int t = threadIdx.x;
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const f16* src = v + (size_t)b * Nkv * ldv + h * 64;
+  const T* src = v + (size_t)b * Nkv * ldv + h * 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int key = i * 32 + (t >> 3), j = t & 7;
@@ -365,22 +372,35 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict_
   }
   __syncthreads();
   const int d = t >> 2, g = t & 3;      // output row d, 16-key group g
-  f16 r[16];
+  T r[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int ko = (i & 3) + ((i >> 2) == 0 ? 0 : (i >> 2) == 1 ? 8 : (i >> 2) == 2 ? 4 : 12);
     r[i] = tile[g * 16 + ko][d];
   }
-  f16* dst = vt + (((size_t)b * heads + h) * 64 + d) * ld_vt + kt * 64 + g * 16;
+  T* dst = vt + (((size_t)b * heads + h) * 64 + d) * ld_vt + kt * 64 + g * 16;
   *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&r[0]);
   *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&r[8]);
 }
 
-extern "C" int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv,
+template <typename T>
+static int lr_transpose_v_t(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv,
                                   lr_stream_t s) {
   if (!v || !vt || B <= 0 || heads <= 0 || Nkv <= 0) return LR_E_ARG;
   if (ldv % 8 || ld_vt % ATT_KB || ld_vt < Nkv || (((uintptr_t)v | (uintptr_t)vt) & 15)) return LR_E_ALIGN;
   dim3 grid(ld_vt / ATT_KB, heads, B);
-  hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)s, (const f16*)v, ldv, (f16*)vt, ld_vt, heads, Nkv);
+  hipLaunchKernelGGL(transpose_v_kernel<T>, grid, dim3(256), 0, (hipStream_t)s, (const T*)v, ldv, (T*)vt, ld_vt, heads, Nkv);
   return lr_launch_status();
 }
+
+// ---- C ABI: every entry point in its fp16 and bf16 form -------------------------------------------------------------
+extern "C" int lr_attention_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_t<f16>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_attention_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_t<bf16>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_attention_causal_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, int B, int heads, int N, float scale, lr_stream_t s) { return lr_attention_causal_t<f16>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, N, scale, s); }
+extern "C" int lr_attention_causal_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, int B, int heads, int N, float scale, lr_stream_t s) { return lr_attention_causal_t<bf16>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, N, scale, s); }
+extern "C" int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_lse_t<f16>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_attention_lse_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_lse_t<bf16>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt, lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_vt_t<f16>(q, ldq, k, ldk, vt, ld_vt, o, ldo, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_attention_vt_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* vt, int ld_vt, lr_half* o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s) { return lr_attention_vt_t<bf16>(q, ldq, k, ldk, vt, ld_vt, o, ldo, B, heads, Nq, Nkv, scale, s); }
+extern "C" int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s) { return lr_transpose_v_t<f16>(v, ldv, vt, ld_vt, B, heads, Nkv, s); }
+extern "C" int lr_transpose_v_bf16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s) { return lr_transpose_v_t<bf16>(v, ldv, vt, ld_vt, B, heads, Nkv, s); }

@@ -24,31 +24,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <typename T>
 struct AttnBwdParams {
-  const f16* q; const f16* k; const f16* v; const f16* o; const f16* dout;
-  const f16* qt; const f16* kt; const f16* dot;   // pre-transposed [B][heads*64][ld_*]
+  const T* q; const T* k; const T* v; const T* o; const T* dout;
+  const T* qt; const T* kt; const T* dot;   // pre-transposed [B][heads*64][ld_*]
   const float* lse; float* dsum;                   // [B][heads][Nq]
-  f16* dq; f16* dk; f16* dv;
+  T* dq; T* dk; T* dv;
   int ldq, ldk, ldv, ldo, lddo, ld_qt, ld_kt, lddq, lddk, lddv, heads, Nq, Nkv, nblocks, ntile_blocks;
   float c, scale;
 };
 
 // D[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one thread per (q, head)
-__global__ void attn_bwd_prep_kernel(const AttnBwdParams P, int B) {
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const AttnBwdParams<T> P, int B) {
   const long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long total = (long long)B * P.heads * P.Nq;
   if (id >= total) return;
   const int q = (int)(id % P.Nq);
   const int h = (int)((id / P.Nq) % P.heads);
   const int b = (int)(id / ((long long)P.Nq * P.heads));
-  const f16* op = P.o + ((size_t)b * P.Nq + q) * P.ldo + h * 64;
-  const f16* gp = P.dout + ((size_t)b * P.Nq + q) * P.lddo + h * 64;
+  const T* op = P.o + ((size_t)b * P.Nq + q) * P.ldo + h * 64;
+  const T* gp = P.dout + ((size_t)b * P.Nq + q) * P.lddo + h * 64;
   float acc = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float a[8], g[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(op + j * 8), a);
-    lr_unpack8(*reinterpret_cast<const uint4*>(gp + j * 8), g);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(op + j * 8), a);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(gp + j * 8), g);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc = fmaf(a[i], g[i], acc);
   }
@@ -56,19 +58,21 @@ __global__ void attn_bwd_prep_kernel(const AttnBwdParams P, int B) {
 }
 
 // 64 rows x 128 B tile -> LDS by DMA with the forward's swizzle; rows >= nrows read the zero page
-__device__ __forceinline__ void ab_stage_rows(char* dst, const f16* base, int ld, int row0, int nrows, int w, int lane,
-                                              const f16* zero) {
+template <typename T>
+__device__ __forceinline__ void ab_stage_rows(char* dst, const T* base, int ld, int row0, int nrows, int w, int lane,
+                                              const T* zero) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rbase = (i * 4 + w) * 8;
     const int row = rbase + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const f16* g = row0 + row < nrows ? base + (size_t)(row0 + row) * ld + chunk * 8 : zero;
+    const T* g = row0 + row < nrows ? base + (size_t)(row0 + row) * ld + chunk * 8 : zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + rbase * 128), 16, 0, 0);
   }
 }
 // 64 rows (d) x 128 B (one 64-column tile) of a pre-transposed operand; always in bounds (ld padded to whole tiles)
-__device__ __forceinline__ void ab_stage_t(char* dst, const f16* base, int ld, int col0, int w, int lane) {
+template <typename T>
+__device__ __forceinline__ void ab_stage_t(char* dst, const T* base, int ld, int col0, int w, int lane) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rbase = (i * 4 + w) * 8;
@@ -77,14 +81,16 @@ __device__ __forceinline__ void ab_stage_t(char* dst, const f16* base, int ld, i
     __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * ld + col0 + chunk * 8), (lptr_t)(dst + rbase * 128), 16, 0, 0);
   }
 }
-__device__ __forceinline__ f16x8 ab_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const f16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+template <typename T>
+__device__ __forceinline__ vec8<T> ab_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const vec8<T>*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // dQ: one query per lane (ql), the wave's 32 queries against every key tile.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdParams P) {
+template <typename T>
+__global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdParams<T> P) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * AB_TILE * 128];   // {K, V, K^T} x 2 buffers
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -92,18 +98,18 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
   const int bh = blockIdx.x / P.ntile_blocks;
   const int h = bh % P.heads, b = bh / P.heads;
   const int ql = lane & 31, hi = lane >> 5;
-  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
+  const T* zero = reinterpret_cast<const T*>(lr_zero_page);
 
-  const f16* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
-  const f16* vp = P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
-  const f16* ktp = P.kt + ((size_t)b * P.heads + h) * 64 * P.ld_kt;
+  const T* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
+  const T* vp = P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
+  const T* ktp = P.kt + ((size_t)b * P.heads + h) * 64 * P.ld_kt;
   const int qrow = qblk * 128 + w * 32 + ql;
   const int qc = min(qrow, P.Nq - 1);
-  f16x8 qf[4], gf[4];      // Q^T / dO^T B-operands: lane holds row qc, columns s4*16 + hi*8 .. +8
+  vec8<T> qf[4], gf[4];      // Q^T / dO^T B-operands: lane holds row qc, columns s4*16 + hi*8 .. +8
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
-    qf[s4] = *reinterpret_cast<const f16x8*>(P.q + ((size_t)b * P.Nq + qc) * P.ldq + h * 64 + s4 * 16 + hi * 8);
-    gf[s4] = *reinterpret_cast<const f16x8*>(P.dout + ((size_t)b * P.Nq + qc) * P.lddo + h * 64 + s4 * 16 + hi * 8);
+    qf[s4] = *reinterpret_cast<const vec8<T>*>(P.q + ((size_t)b * P.Nq + qc) * P.ldq + h * 64 + s4 * 16 + hi * 8);
+    gf[s4] = *reinterpret_cast<const vec8<T>*>(P.dout + ((size_t)b * P.Nq + qc) * P.lddo + h * 64 + s4 * 16 + hi * 8);
   }
   const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + qc;
   const float lse = P.lse[sidx], dsum = P.dsum[sidx];
@@ -138,10 +144,10 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int row = kb * 32 + ql;
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Ks, row, s4 * 2 + hi), qf[s4], s4 == 0 ? zero16 : sacc[kb], 0, 0, 0);
-        pacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Vs, row, s4 * 2 + hi), gf[s4], s4 == 0 ? zero16 : pacc[kb], 0, 0, 0);
+        sacc[kb] = lr_mfma32(ab_frag<T>(Ks, row, s4 * 2 + hi), qf[s4], s4 == 0 ? zero16 : sacc[kb]);
+        pacc[kb] = lr_mfma32(ab_frag<T>(Vs, row, s4 * 2 + hi), gf[s4], s4 == 0 ? zero16 : pacc[kb]);
       }
-    f16x8 dsf[2][2];
+    vec8<T> dsf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
           const int key = tile * AB_TILE + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (key >= P.Nkv) p = 0.f;
         }
-        dsf[kb][r >> 3][r & 7] = (f16)(p * (pacc[kb][r] - dsum));
+        dsf[kb][r >> 3][r & 7] = (T)(p * (pacc[kb][r] - dsum));
       }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Kt, db * 32 + ql, kb * 4 + tt * 2 + hi), dsf[kb][tt], dq[db], 0, 0, 0);
+          dq[db] = lr_mfma32(ab_frag<T>(Kt, db * 32 + ql, kb * 4 + tt * 2 + hi), dsf[kb][tt], dq[db]);
     __syncthreads();
   };
   const int nfull = P.Nkv / AB_TILE;
@@ -167,15 +173,15 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
   if (nfull < ntiles) process(nfull, std::true_type{});
 
   if (qrow < P.Nq) {
-    f16* dst = P.dq + ((size_t)b * P.Nq + qrow) * P.lddq + h * 64;
+    T* dst = P.dq + ((size_t)b * P.Nq + qrow) * P.lddq + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f16x4 ov;
+        vec4<T> ov;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = (f16)(dq[db][g * 4 + i] * P.scale);
-        *reinterpret_cast<f16x4*>(dst + db * 32 + 8 * g + 4 * hi) = ov;
+        for (int i = 0; i < 4; ++i) ov[i] = (T)(dq[db][g * 4 + i] * P.scale);
+        *reinterpret_cast<vec4<T>*>(dst + db * 32 + 8 * g + 4 * hi) = ov;
       }
   }
 }
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
 // ---------------------------------------------------------------------------------------------------------------------
 // dK, dV: one key per lane (ql), the wave's 32 keys against every query tile.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdParams P) {
+template <typename T>
+__global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdParams<T> P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // {Q, dO, Q^T, dO^T} x 2 buffers (64 KB) + lse, D (1 KB)
   float (*s_lse)[AB_TILE] = reinterpret_cast<float (*)[AB_TILE]>(smem + 2 * 4 * AB_TILE * 128);
   float (*s_dsum)[AB_TILE] = s_lse + 2;
@@ -193,21 +200,21 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
   const int bh = blockIdx.x / P.ntile_blocks;
   const int h = bh % P.heads, b = bh / P.heads;
   const int ql = lane & 31, hi = lane >> 5;
-  const f16* zero = reinterpret_cast<const f16*>(lr_zero_page);
+  const T* zero = reinterpret_cast<const T*>(lr_zero_page);
 
-  const f16* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
-  const f16* gp = P.dout + (size_t)b * P.Nq * P.lddo + h * 64;
-  const f16* qtp = P.qt + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
-  const f16* gtp = P.dot + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
+  const T* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
+  const T* gp = P.dout + (size_t)b * P.Nq * P.lddo + h * 64;
+  const T* qtp = P.qt + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
+  const T* gtp = P.dot + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
   const float* lsep = P.lse + ((size_t)b * P.heads + h) * P.Nq;
   const float* dsp = P.dsum + ((size_t)b * P.heads + h) * P.Nq;
   const int krow = kblk * 128 + w * 32 + ql;
   const int kc = min(krow, P.Nkv - 1);
-  f16x8 kf[4], vf[4];      // K^T / V^T B-operands: lane holds row kc, columns s4*16 + hi*8 .. +8
+  vec8<T> kf[4], vf[4];      // K^T / V^T B-operands: lane holds row kc, columns s4*16 + hi*8 .. +8
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
-    kf[s4] = *reinterpret_cast<const f16x8*>(P.k + ((size_t)b * P.Nkv + kc) * P.ldk + h * 64 + s4 * 16 + hi * 8);
-    vf[s4] = *reinterpret_cast<const f16x8*>(P.v + ((size_t)b * P.Nkv + kc) * P.ldv + h * 64 + s4 * 16 + hi * 8);
+    kf[s4] = *reinterpret_cast<const vec8<T>*>(P.k + ((size_t)b * P.Nkv + kc) * P.ldk + h * 64 + s4 * 16 + hi * 8);
+    vf[s4] = *reinterpret_cast<const vec8<T>*>(P.v + ((size_t)b * P.Nkv + kc) * P.ldv + h * 64 + s4 * 16 + hi * 8);
   }
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -246,11 +253,11 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int row = qb * 32 + ql;
-        sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Qs, row, s4 * 2 + hi), kf[s4], s4 == 0 ? zero16 : sacc[qb], 0, 0, 0);
-        pacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Gs, row, s4 * 2 + hi), vf[s4], s4 == 0 ? zero16 : pacc[qb], 0, 0, 0);
+        sacc[qb] = lr_mfma32(ab_frag<T>(Qs, row, s4 * 2 + hi), kf[s4], s4 == 0 ? zero16 : sacc[qb]);
+        pacc[qb] = lr_mfma32(ab_frag<T>(Gs, row, s4 * 2 + hi), vf[s4], s4 == 0 ? zero16 : pacc[qb]);
       }
     // accumulator reg r of block qb is query qb*32 + (r&3) + 8*(r>>2) + 4*hi: its lse / D come from LDS, 4 at a time
-    f16x8 pf[2][2], dsf[2][2];
+    vec8<T> pf[2][2], dsf[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -261,8 +268,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
         for (int i = 0; i < 4; ++i) {
           const int r = g * 4 + i;
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][r], P.c, -l4[i]));
-          pf[qb][r >> 3][r & 7] = (f16)p;
-          dsf[qb][r >> 3][r & 7] = (f16)(p * (pacc[qb][r] - d4[i]));
+          pf[qb][r >> 3][r & 7] = (T)p;
+          dsf[qb][r >> 3][r & 7] = (T)(p * (pacc[qb][r] - d4[i]));
         }
       }
     // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -273,29 +280,30 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int chunk = qb * 4 + tt * 2 + hi;
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Gt, db * 32 + ql, chunk), pf[qb][tt], dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_frag(Qt, db * 32 + ql, chunk), dsf[qb][tt], dk[db], 0, 0, 0);
+          dv[db] = lr_mfma32(ab_frag<T>(Gt, db * 32 + ql, chunk), pf[qb][tt], dv[db]);
+          dk[db] = lr_mfma32(ab_frag<T>(Qt, db * 32 + ql, chunk), dsf[qb][tt], dk[db]);
         }
     __syncthreads();
   }
 
   if (krow < P.Nkv) {
-    f16* dkp = P.dk + ((size_t)b * P.Nkv + krow) * P.lddk + h * 64;
-    f16* dvp = P.dv + ((size_t)b * P.Nkv + krow) * P.lddv + h * 64;
+    T* dkp = P.dk + ((size_t)b * P.Nkv + krow) * P.lddk + h * 64;
+    T* dvp = P.dv + ((size_t)b * P.Nkv + krow) * P.lddv + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f16x4 a, c2;
+        vec4<T> a, c2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = (f16)(dk[db][g * 4 + i] * P.scale); c2[i] = (f16)dv[db][g * 4 + i]; }
-        *reinterpret_cast<f16x4*>(dkp + db * 32 + 8 * g + 4 * hi) = a;
-        *reinterpret_cast<f16x4*>(dvp + db * 32 + 8 * g + 4 * hi) = c2;
+        for (int i = 0; i < 4; ++i) { a[i] = (T)(dk[db][g * 4 + i] * P.scale); c2[i] = (T)dv[db][g * 4 + i]; }
+        *reinterpret_cast<vec4<T>*>(dkp + db * 32 + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<vec4<T>*>(dvp + db * 32 + 8 * g + 4 * hi) = c2;
       }
   }
 }
 
-extern "C" int lr_attention_bwd_f16(const lr_attn_bwd_args* a, lr_stream_t s) {
+template <typename T>
+static int lr_attention_bwd_t(const lr_attn_bwd_args* a, lr_stream_t s) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->qt || !a->kt || !a->dot || !a->dsum || !a->dq ||
       !a->dk || !a->dv)
     return LR_E_ARG;
@@ -305,11 +313,11 @@ extern "C" int lr_attention_bwd_f16(const lr_attn_bwd_args* a, lr_stream_t s) {
   if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o | (uintptr_t)a->dout | (uintptr_t)a->qt |
        (uintptr_t)a->kt | (uintptr_t)a->dot) & 15)
     return LR_E_ALIGN;
-  AttnBwdParams P;
-  P.q = (const f16*)a->q; P.k = (const f16*)a->k; P.v = (const f16*)a->v; P.o = (const f16*)a->o;
-  P.dout = (const f16*)a->dout; P.qt = (const f16*)a->qt; P.kt = (const f16*)a->kt; P.dot = (const f16*)a->dot;
+  AttnBwdParams<T> P;
+  P.q = (const T*)a->q; P.k = (const T*)a->k; P.v = (const T*)a->v; P.o = (const T*)a->o;
+  P.dout = (const T*)a->dout; P.qt = (const T*)a->qt; P.kt = (const T*)a->kt; P.dot = (const T*)a->dot;
   P.lse = a->lse; P.dsum = a->dsum;
-  P.dq = (f16*)a->dq; P.dk = (f16*)a->dk; P.dv = (f16*)a->dv;
+  P.dq = (T*)a->dq; P.dk = (T*)a->dk; P.dv = (T*)a->dv;
   P.ldq = a->ldq; P.ldk = a->ldk; P.ldv = a->ldv; P.ldo = a->ldo; P.lddo = a->lddo; P.ld_qt = a->ld_qt; P.ld_kt = a->ld_kt;
   P.lddq = a->lddq; P.lddk = a->lddk; P.lddv = a->lddv;
   P.heads = a->heads; P.Nq = a->Nq; P.Nkv = a->Nkv;
@@ -317,20 +325,24 @@ extern "C" int lr_attention_bwd_f16(const lr_attn_bwd_args* a, lr_stream_t s) {
   P.c = a->scale * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)s;
   const long long total = (long long)a->B * a->heads * a->Nq;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, a->B);
+  hipLaunchKernelGGL(attn_bwd_prep_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, a->B);
   int rc = lr_launch_status();
   if (rc) return rc;
   P.ntile_blocks = (a->Nq + 127) / 128;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), 0, st, P);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), 0, st, P);
   rc = lr_launch_status();
   if (rc) return rc;
   P.ntile_blocks = (a->Nkv + 127) / 128;
   const int dkv_smem = 2 * 4 * AB_TILE * 128 + 4 * AB_TILE * (int)sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), dkv_smem, st, P);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), dkv_smem, st, P);
   return lr_launch_status();
 }
+
+// ---- C ABI: every entry point in its fp16 and bf16 form -------------------------------------------------------------
+extern "C" int lr_attention_bwd_f16(const lr_attn_bwd_args* a, lr_stream_t s) { return lr_attention_bwd_t<f16>(a, s); }
+extern "C" int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s) { return lr_attention_bwd_t<bf16>(a, s); }

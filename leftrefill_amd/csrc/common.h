@@ -9,6 +9,10 @@
 #define LR_WAVE 64
 
 typedef _Float16 f16;
+typedef __bf16 bf16;          // the second 16-bit activation / weight type (LR_DTYPE_BF16): same layouts, same kernels
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
@@ -74,18 +78,33 @@ __device__ __forceinline__ float lr_wave_max(float v) {
   return v;
 }
 
-// 16-byte vector of 8 halves <-> floats
+// 16-byte vector of 8 halves (fp16 or bf16) <-> floats
+template <typename T = f16>
 __device__ __forceinline__ void lr_unpack8(const uint4& u, float* f) {
-  const f16x8 h = __builtin_bit_cast(f16x8, u);
+  const vec8<T> h = __builtin_bit_cast(vec8<T>, u);
 #pragma unroll
   for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
 }
+template <typename T = f16>
 __device__ __forceinline__ uint4 lr_pack8(const float* f) {
-  f16x8 h;
+  vec8<T> h;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
+  for (int i = 0; i < 8; ++i) h[i] = (T)f[i];
   return __builtin_bit_cast(uint4, h);
 }
+
+// matrix-core products on either 16-bit type (fp32 accumulate)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ f32x4_t lr_mfma16(vec8<f16> a, vec8<f16> b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t lr_mfma16(vec8<bf16> a, vec8<bf16> b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16_t lr_mfma32(vec8<f16> a, vec8<f16> b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16_t lr_mfma32(vec8<bf16> a, vec8<bf16> b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+#else   // host pass of hipcc: kernel bodies are parsed but never run; the matrix-core builtins only exist for the device
+template <typename V> __device__ f32x4_t lr_mfma16(V, V, f32x4_t c) { return c; }
+template <typename V> __device__ f32x16_t lr_mfma32(V, V, f32x16_t c) { return c; }
+#endif
 
 // Buffer descriptor from provably wave-uniform pieces (readfirstlane), otherwise hipcc wraps every buffer op in a
 // waterfall loop (guide T20).  The descriptor type only exists in the device pass of hipcc, hence the guard (the host

@@ -8,8 +8,9 @@
 // channel plane are coalesced across the 64 lanes of a wave (consecutive pixels), the 16-byte writes land in the
 // pixel's row.  Cpad is a multiple of 8.
 // ---------------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
-                                    f16* __restrict__ y, int Cpad, int HW, long long total) {
+                                    T* __restrict__ y, int Cpad, int HW, long long total) {
   const int nOct = Cpad >> 3;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -27,12 +28,12 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x1, int C1, const 
       else if (c < C1 + C2) v = x2[((size_t)n * C2 + (c - C1)) * HW + p];
       f[i] = v;
     }
-    *reinterpret_cast<uint4*>(y + ((size_t)n * HW + p) * Cpad + o * 8) = lr_pack8(f);
+    *reinterpret_cast<uint4*>(y + ((size_t)n * HW + p) * Cpad + o * 8) = lr_pack8<T>(f);
   }
 }
 
-template <typename OutT>
-__global__ void nhwc_to_nchw_kernel(const f16* __restrict__ y, int Cstride, int C, OutT* __restrict__ out, int HW,
+template <typename OutT, typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ y, int Cstride, int C, OutT* __restrict__ out, int HW,
                                     long long total) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -48,16 +49,17 @@ __global__ void nhwc_to_nchw_kernel(const f16* __restrict__ y, int Cstride, int 
 // timestep_embedding (util.py:154-174): out[n][0:half] = cos(t * f_j), out[n][half:] = sin(t * f_j),
 // f_j = exp(-ln(10000) * j / half), all in fp32 with the exact libm-class functions (t up to 981 rad: no fast-math).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int N, int dim, f16* __restrict__ out) {
+template <typename T>
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int N, int dim, T* __restrict__ out) {
   const int half = dim >> 1;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * half) return;
   const int n = idx / half, j = idx % half;
   const float freq = expf(-logf(10000.0f) * (float)j / (float)half);
   const float a = (float)t[n] * freq;
-  out[(size_t)n * dim + j] = (f16)cosf(a);
-  out[(size_t)n * dim + half + j] = (f16)sinf(a);
-  if ((dim & 1) && j == 0) out[(size_t)n * dim + dim - 1] = (f16)0.f;
+  out[(size_t)n * dim + j] = (T)cosf(a);
+  out[(size_t)n * dim + half + j] = (T)sinf(a);
+  if ((dim & 1) && j == 0) out[(size_t)n * dim + dim - 1] = (T)0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -65,12 +67,12 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int N, 
 // each wave owns output columns n, lanes split K in 16-byte pieces (coalesced 1 KiB per wave load), the (tiny)
 // activation matrix is staged once per block in LDS with act_in applied.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MMAX>
-__global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const f16* __restrict__ w,
-                                      const float* __restrict__ bias, f16* __restrict__ out, int ldo, int M, int N,
+template <int MMAX, typename T>
+__global__ void linear_small_m_kernel(const T* __restrict__ a, int lda, const T* __restrict__ w,
+                                      const float* __restrict__ bias, T* __restrict__ out, int ldo, int M, int N,
                                       int K, int act_in, int act_out, int cols_per_wave) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  f16* s_a = reinterpret_cast<f16*>(smem_raw);  // [MMAX][K]
+  T* s_a = reinterpret_cast<T*>(smem_raw);  // [MMAX][K]
   const int t = threadIdx.x;
   for (int idx = t; idx < MMAX * K; idx += blockDim.x) {
     const int m = idx / K, k = idx % K;
@@ -79,7 +81,7 @@ __global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const 
       v = (float)a[(size_t)m * lda + k];
       if (act_in) v = lr_silu(v);
     }
-    s_a[idx] = (f16)v;
+    s_a[idx] = (T)v;
   }
   __syncthreads();
   const int lane = t & 63, wave = t >> 6;
@@ -91,11 +93,11 @@ __global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const 
     for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
     for (int k = lane * 8; k < K; k += 64 * 8) {
       float wf[8];
-      lr_unpack8(*reinterpret_cast<const uint4*>(w + (size_t)n * K + k), wf);
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(w + (size_t)n * K + k), wf);
 #pragma unroll
       for (int m = 0; m < MMAX; ++m) {
         float af[8];
-        lr_unpack8(*reinterpret_cast<const uint4*>(s_a + m * K + k), af);
+        lr_unpack8<T>(*reinterpret_cast<const uint4*>(s_a + m * K + k), af);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[m] = fmaf(af[i], wf[i], acc[m]);
       }
@@ -108,7 +110,7 @@ __global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const 
       for (int m = 0; m < MMAX; ++m) if (m == lane) v = acc[m];
       if (bias) v += bias[n];
       if (act_out) v = lr_silu(v);
-      out[(size_t)lane * ldo + n] = (f16)v;
+      out[(size_t)lane * ldo + n] = (T)v;
     }
   }
 }
@@ -118,7 +120,7 @@ __global__ void linear_small_m_kernel(const f16* __restrict__ a, int lda, const 
 // canvases x [b*v][s rows][2s cols][C]; sequence seq [b][(v+1)][s][s][C] = [target(from canvas 0), ref_0..ref_{v-1}].
 // ---------------------------------------------------------------------------------------------------------------
 // SUM = true is the backward of mv_scatter: the target slot collects the right halves of ALL canvases (fp32 sum).
-template <bool SUM>
+template <bool SUM, typename T>
 __global__ void mv_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ seq, int b, int v, int s, int C8,
                                  long long total) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -135,11 +137,11 @@ __global__ void mv_gather_kernel(const uint4* __restrict__ x, uint4* __restrict_
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int cv = 0; cv < v; ++cv) {
         float f[8];
-        lr_unpack8(x[((((size_t)bi * v + cv) * s + row) * (2 * s) + scol) * C8 + c], f);
+        lr_unpack8<T>(x[((((size_t)bi * v + cv) * s + row) * (2 * s) + scol) * C8 + c], f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += f[i];
       }
-      seq[idx] = lr_pack8(acc);
+      seq[idx] = lr_pack8<T>(acc);
     } else {
       seq[idx] = x[((((size_t)bi * v + canvas) * s + row) * (2 * s) + scol) * C8 + c];
     }
@@ -168,7 +170,7 @@ __global__ void mv_scatter_kernel(const uint4* __restrict__ seq, uint4* __restri
 // ---------------------------------------------------------------------------------------------------------------
 // CFG combine + DDIM update (ddim.py:343-381), fp32 state, 4 elements per thread.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename EpsT>
+template <typename EpsT, typename T>
 __global__ void ddim_cfg_step_kernel(const float* __restrict__ x, const EpsT* __restrict__ eps,
                                      const float* __restrict__ noise, float* __restrict__ x_prev,
                                      float* __restrict__ pred_x0, long long numel, float scale, float sqrt_at,
@@ -180,9 +182,9 @@ __global__ void ddim_cfg_step_kernel(const float* __restrict__ x, const EpsT* __
     float e;
     if (sizeof(EpsT) == 2) {
       // the reference's CFG combine runs in fp16 (model output dtype under autocast, ddim.py:343)
-      const f16 d = (f16)(ec - eu);
-      const f16 sd = (f16)(scale * (float)d);
-      e = (float)(f16)(eu + (float)sd);
+      const T d = (T)(ec - eu);
+      const T sd = (T)(scale * (float)d);
+      e = (float)(T)(eu + (float)sd);
     } else {
       e = eu + scale * (ec - eu);
     }
@@ -202,41 +204,45 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 12; }
+extern "C" int lr_abi_version(void) { return 13; }
 
-extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
+template <typename T>
+static int lr_nchw_f32_to_nhwc_t(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,
                                        int H, int W, lr_stream_t s) {
   if (!x1 || !y || N <= 0 || H <= 0 || W <= 0 || C1 <= 0) return LR_E_ARG;
   if (!x2) C2 = 0;
   if (Cpad % 8 || Cpad < C1 + C2) return LR_E_ALIGN;
   const long long total = (long long)N * (Cpad / 8) * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, x1, C1, x2, C2,
-                     (f16*)y, Cpad, H * W, total);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, x1, C1, x2, C2,
+                     (T*)y, Cpad, H * W, total);
   return lr_launch_status();
 }
 
-extern "C" int lr_nhwc_f16_to_nchw(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W,
+template <typename T>
+static int lr_nhwc_f16_to_nchw_t(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W,
                                    lr_stream_t s) {
   if (!y || !out || N <= 0 || C <= 0 || C > Cstride) return LR_E_ARG;
   const long long total = (long long)N * C * H * W;
   if (out_is_f32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const f16*)y, Cstride, C, (float*)out, H * W, total);
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const T*)y, Cstride, C, (float*)out, H * W, total);
   else
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const f16*)y, Cstride, C, (f16*)out, H * W, total);
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const T*)y, Cstride, C, (T*)out, H * W, total);
   return lr_launch_status();
 }
 
-extern "C" int lr_timestep_embedding(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s) {
+template <typename T>
+static int lr_timestep_embedding_t(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s) {
   if (!t || !out || N <= 0 || dim < 2) return LR_E_ARG;
   const int total = N * (dim / 2);
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)s, t, N, dim,
-                     (f16*)out);
+  hipLaunchKernelGGL(timestep_embedding_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)s, t, N, dim,
+                     (T*)out);
   return lr_launch_status();
 }
 
-extern "C" int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo,
+template <typename T>
+static int lr_linear_small_m_t(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo,
                                  int M, int N, int K, int act_in, int act_out, lr_stream_t s) {
   if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) return LR_E_ARG;
   if (M > 16) return LR_E_UNSUPPORTED;
@@ -245,27 +251,29 @@ extern "C" int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, co
   dim3 grid((N + cpw * waves - 1) / (cpw * waves)), block(64 * waves);
   hipStream_t st = (hipStream_t)s;
   if (M <= 4)
-    hipLaunchKernelGGL(linear_small_m_kernel<4>, grid, block, 4 * K * sizeof(f16), st, (const f16*)a, lda,
-                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+    hipLaunchKernelGGL((linear_small_m_kernel<4, T>), grid, block, 4 * K * sizeof(T), st, (const T*)a, lda,
+                       (const T*)w, bias, (T*)out, ldo, M, N, K, act_in, act_out, cpw);
   else if (M <= 8)
-    hipLaunchKernelGGL(linear_small_m_kernel<8>, grid, block, 8 * K * sizeof(f16), st, (const f16*)a, lda,
-                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+    hipLaunchKernelGGL((linear_small_m_kernel<8, T>), grid, block, 8 * K * sizeof(T), st, (const T*)a, lda,
+                       (const T*)w, bias, (T*)out, ldo, M, N, K, act_in, act_out, cpw);
   else
-    hipLaunchKernelGGL(linear_small_m_kernel<16>, grid, block, 16 * K * sizeof(f16), st, (const f16*)a, lda,
-                       (const f16*)w, bias, (f16*)out, ldo, M, N, K, act_in, act_out, cpw);
+    hipLaunchKernelGGL((linear_small_m_kernel<16, T>), grid, block, 16 * K * sizeof(T), st, (const T*)a, lda,
+                       (const T*)w, bias, (T*)out, ldo, M, N, K, act_in, act_out, cpw);
   return lr_launch_status();
 }
 
-extern "C" int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st) {
+template <typename T>
+static int lr_mv_gather_t(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st) {
   if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * (v + 1) * s * s * (C / 8);
-  hipLaunchKernelGGL(mv_gather_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)x,
+  hipLaunchKernelGGL((mv_gather_kernel<false, T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)x,
                      (uint4*)seq, b, v, s, C / 8, total);
   return lr_launch_status();
 }
 
-extern "C" int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st) {
+template <typename T>
+static int lr_mv_scatter_t(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st) {
   if (!x || !seq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * v * s * 2 * s * (C / 8);
@@ -274,7 +282,8 @@ extern "C" int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s
   return lr_launch_status();
 }
 
-extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev,
+template <typename T>
+static int lr_ddim_cfg_step_t(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev,
                                 float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t,
                                 float sqrt_one_minus_at, lr_stream_t s) {
   if (!x || !eps || !x_prev || !pred_x0 || numel <= 0) return LR_E_ARG;
@@ -284,11 +293,11 @@ extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32,
   const float dir_coef = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
   dim3 grid(grid_for(numel, 256)), block(256);
   if (eps_is_f32)
-    hipLaunchKernelGGL(ddim_cfg_step_kernel<float>, grid, block, 0, (hipStream_t)s, x, (const float*)eps, noise, x_prev,
+    hipLaunchKernelGGL((ddim_cfg_step_kernel<float, T>), grid, block, 0, (hipStream_t)s, x, (const float*)eps, noise, x_prev,
                        pred_x0, (long long)numel, cfg_scale, sqrt_at, sqrt_one_minus_at, sqrt_aprev, dir_coef,
                        sigma_t);
   else
-    hipLaunchKernelGGL(ddim_cfg_step_kernel<f16>, grid, block, 0, (hipStream_t)s, x, (const f16*)eps, noise, x_prev,
+    hipLaunchKernelGGL((ddim_cfg_step_kernel<T, T>), grid, block, 0, (hipStream_t)s, x, (const T*)eps, noise, x_prev,
                        pred_x0, (long long)numel, cfg_scale, sqrt_at, sqrt_one_minus_at, sqrt_aprev, dir_coef,
                        sigma_t);
   return lr_launch_status();
@@ -301,7 +310,8 @@ extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32,
 // GEGLU backward.  pre [M][2H]: the projection (+bias) in the packed layout of lr_gemm_conv_f16 (16-column groups
 // [u16 | g16 | u16 | g16 ...]); dy [M][H];  dpre (same layout as pre): du = dy * gelu(g), dg = dy * u * gelu'(g),
 // gelu'(g) = Phi(g) + g * phi(g)  (erf form, attention.py:56-58).  One thread per 8 output columns.
-__global__ void geglu_bwd_kernel(const f16* __restrict__ pre, const f16* __restrict__ dy, f16* __restrict__ dpre, long long total,
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dpre, long long total,
                                  int H) {
   const int cpr = H >> 3;      // 8-column chunks per row of dy
   for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
@@ -309,9 +319,9 @@ __global__ void geglu_bwd_kernel(const f16* __restrict__ pre, const f16* __restr
     const int c = (int)(id - m * cpr) * 8;            // first output column of this chunk
     const int pc = (c >> 4) * 32 + (c & 15);          // packed column of u; g sits 16 columns later
     float u[8], g[8], d[8], du[8], dg[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
-    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
-    lr_unpack8(*reinterpret_cast<const uint4*>(dy + m * H + c), d);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(dy + m * H + c), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float cdf = 0.5f * (1.0f + lr_erf(g[i] * 0.70710678118654752f));
@@ -319,52 +329,56 @@ __global__ void geglu_bwd_kernel(const f16* __restrict__ pre, const f16* __restr
       du[i] = d[i] * g[i] * cdf;
       dg[i] = d[i] * u[i] * fmaf(g[i], pdf, cdf);
     }
-    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc) = lr_pack8(du);
-    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc + 16) = lr_pack8(dg);
+    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc) = lr_pack8<T>(du);
+    *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc + 16) = lr_pack8<T>(dg);
   }
 }
 
 // GEGLU forward from the stored projection (training keeps `pre` for the backward instead of recomputing the GEMM):
 // out[m][c] = u * gelu_erf(g), same packed layout of pre as above.
-__global__ void geglu_fwd_kernel(const f16* __restrict__ pre, f16* __restrict__ out, long long total, int H) {
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out, long long total, int H) {
   const int cpr = H >> 3;
   for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
     const long long m = id / cpr;
     const int c = (int)(id - m * cpr) * 8;
     const int pc = (c >> 4) * 32 + (c & 15);
     float u[8], g[8], o[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
-    lr_unpack8(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = u[i] * lr_gelu_erf(g[i]);
-    *reinterpret_cast<uint4*>(out + m * H + c) = lr_pack8(o);
+    *reinterpret_cast<uint4*>(out + m * H + c) = lr_pack8<T>(o);
   }
 }
 
-extern "C" int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s) {
+template <typename T>
+static int lr_geglu_fwd_t(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s) {
   if (!pre || !out || M <= 0 || H <= 0) return LR_E_ARG;
   if (H % 16) return LR_E_ALIGN;
   const long long total = (long long)M * (H / 8);
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)pre, (f16*)out, total, H);
+  hipLaunchKernelGGL(geglu_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const T*)pre, (T*)out, total, H);
   return lr_launch_status();
 }
 
-extern "C" int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) {
+template <typename T>
+static int lr_geglu_bwd_t(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) {
   if (!pre || !dy || !dpre || M <= 0 || H <= 0) return LR_E_ARG;
   if (H % 16) return LR_E_ALIGN;
   const long long total = (long long)M * (H / 8);
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)pre, (const f16*)dy,
-                     (f16*)dpre, total, H);
+  hipLaunchKernelGGL(geglu_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const T*)pre, (const T*)dy,
+                     (T*)dpre, total, H);
   return lr_launch_status();
 }
 
 // Backward of the nearest-2x upsample in front of a conv (Upsample.forward, openaimodel.py:115): the four fine pixels
 // of a coarse pixel add up.  x [N][2H][2W][C] -> y [N][H][W][C].
-__global__ void sumpool2x2_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long total, int H, int W, int C) {
+template <typename T>
+__global__ void sumpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, long long total, int H, int W, int C) {
   const int cpr = C >> 3;
   for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(id % cpr) * 8;
@@ -373,34 +387,36 @@ __global__ void sumpool2x2_kernel(const f16* __restrict__ x, f16* __restrict__ y
     pix /= W;
     const int yh = (int)(pix % H);
     const long long n = pix / H;
-    const f16* src = x + ((n * 2 * H + 2 * yh) * 2 * W + 2 * xw) * (long long)C + c;
+    const T* src = x + ((n * 2 * H + 2 * yh) * 2 * W + 2 * xw) * (long long)C + c;
     float a[8], acc[8];
-    lr_unpack8(*reinterpret_cast<const uint4*>(src), acc);
-    lr_unpack8(*reinterpret_cast<const uint4*>(src + C), a);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(src), acc);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(src + C), a);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += a[i];
-    lr_unpack8(*reinterpret_cast<const uint4*>(src + 2LL * W * C), a);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(src + 2LL * W * C), a);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += a[i];
-    lr_unpack8(*reinterpret_cast<const uint4*>(src + 2LL * W * C + C), a);
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(src + 2LL * W * C + C), a);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += a[i];
-    *reinterpret_cast<uint4*>(y + ((n * H + yh) * W + xw) * (long long)C + c) = lr_pack8(acc);
+    *reinterpret_cast<uint4*>(y + ((n * H + yh) * W + xw) * (long long)C + c) = lr_pack8<T>(acc);
   }
 }
 
-extern "C" int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s) {
+template <typename T>
+static int lr_sumpool2x2_t(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)N * H * W * (C / 8);
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const f16*)x, (f16*)y, total, H, W, C);
+  hipLaunchKernelGGL(sumpool2x2_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, total, H, W, C);
   return lr_launch_status();
 }
 
 // Backward of the multi-view re-arrangement (same shapes as lr_mv_gather / lr_mv_scatter, roles of x and seq swapped)
-extern "C" int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) {
+template <typename T>
+static int lr_mv_gather_bwd_t(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) {
   if (!dx || !dseq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * v * s * 2 * s * (C / 8);
@@ -409,11 +425,38 @@ extern "C" int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, 
   return lr_launch_status();
 }
 
-extern "C" int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) {
+template <typename T>
+static int lr_mv_scatter_bwd_t(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) {
   if (!dx || !dseq || b <= 0 || v <= 0 || s <= 0) return LR_E_ARG;
   if (C % 8) return LR_E_ALIGN;
   const long long total = (long long)b * (v + 1) * s * s * (C / 8);
-  hipLaunchKernelGGL(mv_gather_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)dx,
+  hipLaunchKernelGGL((mv_gather_kernel<true, T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)st, (const uint4*)dx,
                      (uint4*)dseq, b, v, s, C / 8, total);
   return lr_launch_status();
 }
+
+// ---- C ABI: every entry point in its fp16 and bf16 form -------------------------------------------------------------
+extern "C" int lr_nchw_f32_to_nhwc_f16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N, int H, int W, lr_stream_t s) { return lr_nchw_f32_to_nhwc_t<f16>(x1, C1, x2, C2, y, Cpad, N, H, W, s); }
+extern "C" int lr_nchw_f32_to_nhwc_bf16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N, int H, int W, lr_stream_t s) { return lr_nchw_f32_to_nhwc_t<bf16>(x1, C1, x2, C2, y, Cpad, N, H, W, s); }
+extern "C" int lr_nhwc_f16_to_nchw(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W, lr_stream_t s) { return lr_nhwc_f16_to_nchw_t<f16>(y, Cstride, C, out, out_is_f32, N, H, W, s); }
+extern "C" int lr_nhwc_f16_to_nchw_bf16(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W, lr_stream_t s) { return lr_nhwc_f16_to_nchw_t<bf16>(y, Cstride, C, out, out_is_f32, N, H, W, s); }
+extern "C" int lr_timestep_embedding(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s) { return lr_timestep_embedding_t<f16>(t, N, dim, out, s); }
+extern "C" int lr_timestep_embedding_bf16(const int64_t* t, int N, int dim, lr_half* out, lr_stream_t s) { return lr_timestep_embedding_t<bf16>(t, N, dim, out, s); }
+extern "C" int lr_linear_small_m(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo, int M, int N, int K, int act_in, int act_out, lr_stream_t s) { return lr_linear_small_m_t<f16>(a, lda, w, bias, out, ldo, M, N, K, act_in, act_out, s); }
+extern "C" int lr_linear_small_m_bf16(const lr_half* a, int lda, const lr_half* w, const float* bias, lr_half* out, int ldo, int M, int N, int K, int act_in, int act_out, lr_stream_t s) { return lr_linear_small_m_t<bf16>(a, lda, w, bias, out, ldo, M, N, K, act_in, act_out, s); }
+extern "C" int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_gather_t<f16>(x, seq, b, v, s, C, st); }
+extern "C" int lr_mv_gather_bf16(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_gather_t<bf16>(x, seq, b, v, s, C, st); }
+extern "C" int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_t<f16>(seq, x, b, v, s, C, st); }
+extern "C" int lr_mv_scatter_bf16(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_t<bf16>(seq, x, b, v, s, C, st); }
+extern "C" int lr_ddim_cfg_step(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev, float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, lr_stream_t s) { return lr_ddim_cfg_step_t<f16>(x, eps, eps_is_f32, noise, x_prev, pred_x0, numel, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, s); }
+extern "C" int lr_ddim_cfg_step_bf16(const float* x, const void* eps, int eps_is_f32, const float* noise, float* x_prev, float* pred_x0, int64_t numel, float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, lr_stream_t s) { return lr_ddim_cfg_step_t<bf16>(x, eps, eps_is_f32, noise, x_prev, pred_x0, numel, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, s); }
+extern "C" int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s) { return lr_geglu_fwd_t<f16>(pre, out, M, H, s); }
+extern "C" int lr_geglu_fwd_bf16(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s) { return lr_geglu_fwd_t<bf16>(pre, out, M, H, s); }
+extern "C" int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) { return lr_geglu_bwd_t<f16>(pre, dy, dpre, M, H, s); }
+extern "C" int lr_geglu_bwd_bf16(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s) { return lr_geglu_bwd_t<bf16>(pre, dy, dpre, M, H, s); }
+extern "C" int lr_sumpool2x2(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s) { return lr_sumpool2x2_t<f16>(x, y, N, H, W, C, s); }
+extern "C" int lr_sumpool2x2_bf16(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s) { return lr_sumpool2x2_t<bf16>(x, y, N, H, W, C, s); }
+extern "C" int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_gather_bwd_t<f16>(dseq, dx, b, v, s, C, st); }
+extern "C" int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_gather_bwd_t<bf16>(dseq, dx, b, v, s, C, st); }
+extern "C" int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_bwd_t<f16>(dx, dseq, b, v, s, C, st); }
+extern "C" int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_bwd_t<bf16>(dx, dseq, b, v, s, C, st); }

@@ -36,6 +36,7 @@ struct GemmParams {
   // per-channel (sum, sumsq) of this GEMM's fp16 output over each wave's rows: gs_out[row block][N][2], row block =
   // m / (rows per wave tile); feeds the GroupNorm of the consumer (lr_groupnorm_finalize) instead of a statistics pass
   float* gs_out;
+  int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
 #endif
@@ -119,7 +120,7 @@ __device__ __forceinline__ constexpr int weight_tile(const int wn, const int j) 
   return GEGLU ? 2 * emit_tile<TN / 2, WNW>(wn, j >> 1) + (j & 1) : emit_tile<TN, WNW>(wn, j);
 }
 
-template <int TM, int TN, int MODE, int PAR_LD, int WNW>
+template <int TM, int TN, int MODE, int PAR_LD, int WNW, typename T>
 __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)[TN][TM], const int m_w0, const int n0,
                                                const int wn, const int lane, const float* rs, const float* par,
                                                const int part) {
@@ -262,22 +263,22 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     }
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     float e[8];
-    lr_unpack8(__builtin_bit_cast(uint4, rvec), e);
+    lr_unpack8<T>(__builtin_bit_cast(uint4, rvec), e);
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] += e[q];
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = lr_gelu_erf(v[q]);
     }
-    lr_unpack8(__builtin_bit_cast(uint4, rres), e);
+    lr_unpack8<T>(__builtin_bit_cast(uint4, rres), e);
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] += e[q];
-    const uint4 pk = lr_pack8(v);
+    const uint4 pk = lr_pack8<T>(v);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rsO,
                                            ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, 0);
     if (gstat) {
       float f[8];
-      lr_unpack8(pk, f);
+      lr_unpack8<T>(pk, f);
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const float x = ok ? f[q] : 0.f; g1(q) += x; g2(q) = fmaf(x, x, g2(q)); }
       if (u < NUJ) { if (u % TM == TM - 1) flush_group(n, false); }
@@ -285,7 +286,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     }
     if (P.st_out) {
       float f[8], t1 = 0.f, t2 = 0.f;
-      lr_unpack8(pk, f);
+      lr_unpack8<T>(pk, f);
 #pragma unroll
       for (int q = 0; q < 8; ++q) { t1 += f[q]; t2 = fmaf(f[q], f[q], t2); }
       if (!ok) { t1 = 0.f; t2 = 0.f; }
@@ -362,7 +363,7 @@ __device__ __forceinline__ void ln_rows_to_lds(const GemmParams& P, float* rs, c
 }
 
 // 2nd launch-bounds argument = waves per SIMD the register allocation must leave room for (= resident blocks per CU here)
-template <int BN, int MODE>
+template <int BN, int MODE, typename T>
 __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) void gemm_conv_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = 4;            // 16-row MFMA tiles per wave along M (64 rows)
@@ -481,23 +482,23 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
     const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8 xf[TM], wf[TN];
+      vec8<T> xf[TM], wf[TN];
       const int kc = ks * 4 + fq;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * 64 + i * 16 + fr;
-        xf[i] = *reinterpret_cast<const f16x8*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+        xf[i] = *reinterpret_cast<const vec8<T>*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = weight_tile<TN, 2, MODE == 1>(wn, j) * 16 + fr;
-        wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+        wf[j] = *reinterpret_cast<const vec8<T>*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
     }
     __syncthreads();  // all reads of buf[cur] done; all LDS-DMA into buf[cur^1] landed (vmcnt(0) precedes the barrier)
     cur ^= 1;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
     ln_rows_to_lds(P, rs, m0, BM, t);
     __syncthreads();
   }
-  epilogue_units<TM, TN, MODE, PAR_LD, 2>(P, acc, m0 + wm * 64, n0, wn, lane, rs + 2 * (wm * 64), par, tile_n * 2 + wn);
+  epilogue_units<TM, TN, MODE, PAR_LD, 2, T>(P, acc, m0 + wm * 64, n0, wn, lane, rs + 2 * (wm * 64), par, tile_n * 2 + wn);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -534,7 +535,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //                            L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
 //   <256, 2, 2>            : wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
 //   <320, 4, 2>            : wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
-template <int BN, int WMW, int NSTAGE, int MODE>
+template <int BN, int WMW, int NSTAGE, int MODE, typename T>
 __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WNW = 8 / WMW;
@@ -654,27 +655,27 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   // eight waves do not all hit the LDS port at once.  One barrier per K-step, placed between the two halves: at that
   // point every wave has finished reading stage kt (-> its buffer is refilled with stage kt+3) and stage kt+1 has landed.
   const int fr = lane & 15, fq = lane >> 4;
-  auto read_frags = [&](f16x8 (&xf)[TM], f16x8 (&wf)[TN], int buf, int ks) {
+  auto read_frags = [&](vec8<T> (&xf)[TM], vec8<T> (&wf)[TN], int buf, int ks) {
     const char* As = smem + buf * STAGE;
     const char* Bs = As + A_BYTES;
     const int kc = ks * 4 + fq;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * (TM * 16) + i * 16 + fr;
-      xf[i] = *reinterpret_cast<const f16x8*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      xf[i] = *reinterpret_cast<const vec8<T>*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = weight_tile<TN, WNW, MODE == 1>(wn, j) * 16 + fr;
-      wf[j] = *reinterpret_cast<const f16x8*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      wf[j] = *reinterpret_cast<const vec8<T>*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     }
   };
-  auto mma = [&](const f16x8 (&xf)[TM], const f16x8 (&wf)[TN]) {
+  auto mma = [&](const vec8<T> (&xf)[TM], const vec8<T> (&wf)[TN]) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
   };
   // wait until all of this wave's LDS-DMA except the newest `inflight` stages has landed
   auto wait_stages = [&](int inflight) {
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   for (int sidx = 0; sidx < NSTAGE; ++sidx)
     if (sidx < nsteps) stage(sidx, k_begin + sidx);
   LR_STAMP(1);
-  f16x8 xa[TM], wa[TN];
+  vec8<T> xa[TM], wa[TN];
   if (nsteps > 0) {
     wait_stages(nsteps > NSTAGE - 1 ? NSTAGE - 1 : nsteps - 1);
     __builtin_amdgcn_s_barrier();
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   LR_STAMP(2);
   int cur = 0;
   if constexpr (DB) {
-    f16x8 xb[TM], wb[TN];
+    vec8<T> xb[TM], wb[TN];
     for (int it = 0; it < nsteps; ++it) {
       const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
       // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
     __syncthreads();
   }
   LR_STAMP(4);
-  epilogue_units<TM, TN, MODE, PAR_LD, WNW>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
+  epilogue_units<TM, TN, MODE, PAR_LD, WNW, T>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
                                             tile_n * WNW + wn);
   LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
@@ -761,8 +762,8 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BN, int WMW, int NSTAGE, int MODE>
-static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
+template <int BN, int WMW, int NSTAGE, int MODE, typename T>
+static int launch_gemm256_t(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
   const int ntm = (P.M + BM2 - 1) / BM2;
@@ -773,15 +774,16 @@ static int launch_gemm256(const GemmParams& P0, hipStream_t st) {
   const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE, MODE>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE, MODE, T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE, MODE>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE, MODE, T>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
 // Fixed-order reduction of the split-K partials + the fused epilogue (deterministic: no atomics).
+template <typename T>
 __global__ void splitk_reduce_kernel(const GemmParams P) {
   const int cpr = P.N >> 3;
   const long long total = (long long)P.M * cpr;
@@ -802,7 +804,7 @@ __global__ void splitk_reduce_kernel(const GemmParams P) {
     }
     if (P.rowvec) {
       float e[8];
-      lr_unpack8(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += e[i];
     }
@@ -812,16 +814,16 @@ __global__ void splitk_reduce_kernel(const GemmParams P) {
     }
     if (P.resid) {
       float e[8];
-      lr_unpack8(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += e[i];
     }
-    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8(v);
+    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8<T>(v);
   }
 }
 
-template <int BN, int MODE>
-static int launch_gemm(const GemmParams& P0, hipStream_t st) {
+template <int BN, int MODE, typename T>
+static int launch_gemm_t(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
   const int ntm = (P.M + BM - 1) / BM;
@@ -832,19 +834,32 @@ static int launch_gemm(const GemmParams& P0, hipStream_t st) {
   const size_t smem = 2 * (size_t)(BM + BN) * 128 + BM * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN, MODE, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_conv_kernel<BN, MODE>), dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv_kernel<BN, MODE, T>), dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
   return lr_launch_status();
+}
+
+// dtype dispatch (fp16 | bf16; the erf-GELU mode of the text tower is fp16 only)
+template <int BN, int WMW, int NSTAGE, int MODE>
+static int launch_gemm256(const GemmParams& P, hipStream_t st) {
+  if constexpr (MODE != 2) { if (P.bf16) return launch_gemm256_t<BN, WMW, NSTAGE, MODE, bf16>(P, st); }
+  return launch_gemm256_t<BN, WMW, NSTAGE, MODE, f16>(P, st);
+}
+template <int BN, int MODE>
+static int launch_gemm(const GemmParams& P, hipStream_t st) {
+  if constexpr (MODE != 2) { if (P.bf16) return launch_gemm_t<BN, MODE, bf16>(P, st); }
+  return launch_gemm_t<BN, MODE, f16>(P, st);
 }
 
 static int launch_reduce(const GemmParams& P, hipStream_t st) {
   long long chunks = (long long)P.M * (P.N >> 3);
   int grid = (int)((chunks + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P);
+  if (P.bf16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<f16>, dim3(grid), dim3(256), 0, st, P);
   return lr_launch_status();
 }
 
@@ -991,6 +1006,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
 #ifdef LR_GEMM_TRACE
   P.trace = g_trace;
 #endif
+  if (a->dtype != LR_DTYPE_F16 && a->dtype != LR_DTYPE_BF16) return LR_E_ARG;
+  P.bf16 = a->dtype == LR_DTYPE_BF16;
+  if (P.bf16 && P.gelu) return LR_E_UNSUPPORTED;
   P.gs_out = a->gn_stats_out;
   if (P.gs_out && (splits > 1 || P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
   P.st_out = a->stats_out;

@@ -12,7 +12,8 @@
 // combines them per group in a FIXED order through LDS (no atomics => bitwise reproducible reruns) and writes
 // partials[n][chunk][32][2].
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, int HW,
                                 float* __restrict__ partials, int nOct, int R, int nchunks) {
   extern __shared__ float s_part[];  // [R][C][2]
   const int C = C1 + C2;
@@ -23,13 +24,13 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
   const int per = (HW + nchunks - 1) / nchunks;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   const int c0 = o * 8;
-  const f16* src;
+  const T* src;
   int cs, coff;
   if (c0 < C1) { src = x1; cs = C1; coff = c0; } else { src = x2; cs = C2; coff = c0 - C1; }
   float sm[8], sq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { sm[i] = 0.f; sq[i] = 0.f; }
-  const f16* base = src + ((size_t)n * HW) * cs + coff;
+  const T* base = src + ((size_t)n * HW) * cs + coff;
   int p = p0 + r;
   // four pixels in flight per thread
   for (; p + 3 * R < p1; p += 4 * R) {
@@ -39,7 +40,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float f[8];
-      lr_unpack8(u[k], f);
+      lr_unpack8<T>(u[k], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { sm[i] += f[i]; sq[i] = fmaf(f[i], f[i], sq[i]); }
     }
@@ -47,7 +48,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
   for (; p < p1; p += R) {
     const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)p * cs);
     float f[8];
-    lr_unpack8(u0, f);
+    lr_unpack8<T>(u0, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sm[i] += f[i]; sq[i] = fmaf(f[i], f[i], sq[i]); }
   }
@@ -74,9 +75,10 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* _
 // per-element index division).  Each block first finalises mean/rstd of its sample from the LR_GN_CHUNKS partials
 // (fp64, fixed order => deterministic).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, int HW,
                                 const float* __restrict__ partials, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, int silu, f16* __restrict__ y,
+                                const float* __restrict__ beta, float eps, int silu, T* __restrict__ y,
                                 int pix_per_block, int nOct, int R, int nchunks) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = C1 + C2;
@@ -87,11 +89,11 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* _
   const int c0 = o * 8;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
-  const f16* src;
+  const T* src;
   int cs;
   if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; cs = C1; }
   else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
-  f16* dst = y + ((size_t)n * HW) * C + c0;
+  T* dst = y + ((size_t)n * HW) * C + c0;
 
   // request the first pixels before the statistics prologue (their latency hides under it)
   int p = p0 + r;
@@ -131,13 +133,13 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* _
   }
   auto emit = [&](int pp, const uint4& v) {
     float f[8];
-    lr_unpack8(v, f);
+    lr_unpack8<T>(v, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float z = fmaf(f[i], a[i], b[i]);
       f[i] = silu ? z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)) : z;
     }
-    *reinterpret_cast<uint4*>(dst + (size_t)pp * C) = lr_pack8(f);
+    *reinterpret_cast<uint4*>(dst + (size_t)pp * C) = lr_pack8<T>(f);
   };
   if (r >= R) return;   // spare threads when blockDim was rounded up (never with nOct * R sizing)
   bool have = first;
@@ -164,9 +166,9 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* _
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (C <= 2048), two-pass mean / variance like ATen.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NV>  // 16-byte vectors per lane
-__global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, f16* __restrict__ y, int M, int C) {
+template <int NV, typename T>  // 16-byte vectors per lane
+__global__ void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, T* __restrict__ y, int M, int C) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -178,7 +180,7 @@ __global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restr
     const int o = lane + j * 64;
     if (o < nOct) {
       const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)row * C + o * 8);
-      lr_unpack8(u, v[j]);
+      lr_unpack8<T>(u, v[j]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum += v[j][i];
     } else {
@@ -210,7 +212,7 @@ __global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restr
       float f[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] = fmaf((v[j][i] - mean) * rstd, g[i], b[i]);
-      *reinterpret_cast<uint4*>(y + (size_t)row * C + o * 8) = lr_pack8(f);
+      *reinterpret_cast<uint4*>(y + (size_t)row * C + o * 8) = lr_pack8<T>(f);
     }
   }
 }
@@ -224,13 +226,13 @@ __global__ void layernorm_kernel(const f16* __restrict__ x, const float* __restr
 // through the GEMM kernel):  p[m][:] = softmax(scale * s[m][:]) in fp32, one 256-thread block per row, the row stays
 // in registers (NV 16-byte vectors per thread).  In place is allowed.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NV>
-__global__ void softmax_rows_kernel(const f16* __restrict__ s, f16* __restrict__ p, int N, float scale) {
+template <int NV, typename T>
+__global__ void softmax_rows_kernel(const T* __restrict__ s, T* __restrict__ p, int N, float scale) {
   __shared__ float red[8];
   const size_t row = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const f16* src = s + row * (size_t)N;
-  f16* dst = p + row * (size_t)N;
+  const T* src = s + row * (size_t)N;
+  T* dst = p + row * (size_t)N;
   float f[NV][8];
   float mx = -INFINITY;
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ void softmax_rows_kernel(const f16* __restrict__ s, f16* __restrict__
     const int c = (v * 256 + t) * 8;
     if (c < N) {
       const uint4 u = *reinterpret_cast<const uint4*>(src + c);
-      lr_unpack8(u, f[v]);
+      lr_unpack8<T>(u, f[v]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { f[v][i] *= scale; mx = fmaxf(mx, f[v][i]); }
     }
@@ -266,7 +268,7 @@ __global__ void softmax_rows_kernel(const f16* __restrict__ s, f16* __restrict__
     if (c < N) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[v][i] *= inv;
-      *reinterpret_cast<uint4*>(dst + c) = lr_pack8(f[v]);
+      *reinterpret_cast<uint4*>(dst + c) = lr_pack8<T>(f[v]);
     }
   }
 }
@@ -288,7 +290,8 @@ static int gn_nchunks(int N, int HW, int C) {
   return c;
 }
 
-extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
+template <typename T>
+static int lr_groupnorm_stats_t(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials,
                                   lr_stream_t s) {
   if (!x1 || !partials || N <= 0 || HW <= 0) return LR_E_ARG;
   if (!x2) C2 = 0;
@@ -301,8 +304,8 @@ extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, 
   if (threads > 1024) return LR_E_UNSUPPORTED;
   const int nchunks = gn_nchunks(N, HW, C);
   dim3 grid(nchunks, N);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)R * C * 2 * sizeof(float), (hipStream_t)s,
-                     (const f16*)x1, C1, (const f16*)x2, C2, HW, partials, nOct, R, nchunks);
+  hipLaunchKernelGGL(gn_stats_kernel<T>, grid, dim3(threads), (size_t)R * C * 2 * sizeof(float), (hipStream_t)s,
+                     (const T*)x1, C1, (const T*)x2, C2, HW, partials, nOct, R, nchunks);
   return lr_launch_status();
 }
 
@@ -356,23 +359,27 @@ extern "C" int lr_groupnorm_finalize(const float* p1, int C1, int R1, const floa
   return lr_launch_status();
 }
 
+template <typename T>
 static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                                 int nchunks_in, const float* gamma, const float* beta, float eps, int silu, lr_half* y,
                                 lr_stream_t s);
 
-extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
+template <typename T>
+static int lr_groupnorm_apply_t(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
                                   const float* partials, const float* gamma, const float* beta, float eps, int silu,
                                   lr_half* y, lr_stream_t s) {
-  return groupnorm_apply_impl(x1, C1, x2, C2, N, HW, partials, 0, gamma, beta, eps, silu, y, s);
+  return groupnorm_apply_impl<T>(x1, C1, x2, C2, N, HW, partials, 0, gamma, beta, eps, silu, y, s);
 }
 
-extern "C" int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
+template <typename T>
+static int lr_groupnorm_apply_n_t(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW,
                                     const float* partials, int nchunks, const float* gamma, const float* beta, float eps,
                                     int silu, lr_half* y, lr_stream_t s) {
   if (nchunks <= 0) return LR_E_ARG;
-  return groupnorm_apply_impl(x1, C1, x2, C2, N, HW, partials, nchunks, gamma, beta, eps, silu, y, s);
+  return groupnorm_apply_impl<T>(x1, C1, x2, C2, N, HW, partials, nchunks, gamma, beta, eps, silu, y, s);
 }
 
+template <typename T>
 static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                                 int nchunks_in, const float* gamma, const float* beta, float eps, int silu, lr_half* y,
                                 lr_stream_t s) {
@@ -398,12 +405,13 @@ static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, in
   ppb = ((ppb + 4 * R - 1) / (4 * R)) * (4 * R);   // whole 4-deep load batches per thread (no serial tail)
   dim3 grid((HW + ppb - 1) / ppb, N);
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
-  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, (hipStream_t)s, (const f16*)x1, C1, (const f16*)x2, C2,
-                     HW, partials, gamma, beta, eps, silu, (f16*)y, ppb, nOct, R, nchunks_in > 0 ? nchunks_in : gn_nchunks(N, HW, C));
+  hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(threads), 0, (hipStream_t)s, (const T*)x1, C1, (const T*)x2, C2,
+                     HW, partials, gamma, beta, eps, silu, (T*)y, ppb, nOct, R, nchunks_in > 0 ? nchunks_in : gn_nchunks(N, HW, C));
   return lr_launch_status();
 }
 
-extern "C" int lr_layernorm(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C,
+template <typename T>
+static int lr_layernorm_t(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C,
                             lr_stream_t s) {
   if (!x || !gamma || !beta || !y || M <= 0) return LR_E_ARG;
   if (C % 8 || C > 2048) return LR_E_ALIGN;
@@ -411,10 +419,10 @@ extern "C" int lr_layernorm(const lr_half* x, const float* gamma, const float* b
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)s;
   switch (nv) {
-    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
-    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
-    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
-    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, (const f16*)x, gamma, beta, eps, (f16*)y, M, C); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<1, T>), grid, block, 0, st, (const T*)x, gamma, beta, eps, (T*)y, M, C); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<2, T>), grid, block, 0, st, (const T*)x, gamma, beta, eps, (T*)y, M, C); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<3, T>), grid, block, 0, st, (const T*)x, gamma, beta, eps, (T*)y, M, C); break;
+    default: hipLaunchKernelGGL((layernorm_kernel<4, T>), grid, block, 0, st, (const T*)x, gamma, beta, eps, (T*)y, M, C); break;
   }
   return lr_launch_status();
 }
@@ -426,10 +434,10 @@ extern "C" int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, f
   const int nv = (N + 2047) / 2048;
   dim3 grid(M), block(256);
   hipStream_t hs = (hipStream_t)st;
-  if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
-  else if (nv <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
-  else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
-  else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  if (nv <= 1) hipLaunchKernelGGL((softmax_rows_kernel<1, f16>), grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else if (nv <= 2) hipLaunchKernelGGL((softmax_rows_kernel<2, f16>), grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else if (nv <= 4) hipLaunchKernelGGL((softmax_rows_kernel<4, f16>), grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
+  else hipLaunchKernelGGL((softmax_rows_kernel<8, f16>), grid, block, 0, hs, (const f16*)s, (f16*)p, N, scale);
   return lr_launch_status();
 }
 
@@ -438,9 +446,9 @@ extern "C" int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, f
 // =====================================================================================================================
 
 // ---- LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  One wave per row.
-template <int NV>
-__global__ void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, const float* __restrict__ gamma,
-                                     float eps, f16* __restrict__ dx, int M, int C) {
+template <int NV, typename T>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                     float eps, T* __restrict__ dx, int M, int C) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -451,8 +459,8 @@ __global__ void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __res
   for (int j = 0; j < NV; ++j) {
     const int o = lane + j * 64;
     if (o < nOct) {
-      lr_unpack8(*reinterpret_cast<const uint4*>(x + (size_t)row * C + o * 8), v[j]);
-      lr_unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)row * C + o * 8), g[j]);
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(x + (size_t)row * C + o * 8), v[j]);
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(dy + (size_t)row * C + o * 8), g[j]);
       const float4 g0 = *reinterpret_cast<const float4*>(gamma + o * 8);
       const float4 g1 = *reinterpret_cast<const float4*>(gamma + o * 8 + 4);
       const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -496,12 +504,13 @@ __global__ void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __res
       float f[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] = rstd * (g[j][i] - s1 - v[j][i] * s2);
-      *reinterpret_cast<uint4*>(dx + (size_t)row * C + o * 8) = lr_pack8(f);
+      *reinterpret_cast<uint4*>(dx + (size_t)row * C + o * 8) = lr_pack8<T>(f);
     }
   }
 }
 
-extern "C" int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M,
+template <typename T>
+static int lr_layernorm_bwd_t(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M,
                                 int C, lr_stream_t s) {
   if (!x || !dy || !gamma || !dx || M <= 0) return LR_E_ARG;
   if (C % 8 || C > 2048) return LR_E_ALIGN;
@@ -509,10 +518,10 @@ extern "C" int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)s;
   switch (nv) {
-    case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
-    case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
-    case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
-    default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, (const f16*)x, (const f16*)dy, gamma, eps, (f16*)dx, M, C); break;
+    case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
+    case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
+    case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
+    default: hipLaunchKernelGGL((layernorm_bwd_kernel<4, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
   }
   return lr_launch_status();
 }
@@ -548,8 +557,9 @@ __device__ __forceinline__ float gn_act_grad(float z, int silu) {
   return sg * fmaf(z, 1.0f - sg, 1.0f);
 }
 
-__global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
-                                    const f16* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ gamma,
+template <typename T>
+__global__ void gn_bwd_stats_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, int HW,
+                                    const T* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float eps, int silu, float* __restrict__ out, int nOct,
                                     int R, int nchunks) {
   extern __shared__ float s_part[];  // [R][C][2]
@@ -562,10 +572,10 @@ __global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f1
   const int c0 = o * 8;
   gn_finalize_stats(fwd, n, nchunks, HW, Cg, eps, s_mean, s_rstd);
   __syncthreads();
-  const f16* src;
+  const T* src;
   int cs;
   if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; cs = C1; } else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
-  const f16* gsrc = dy + ((size_t)n * HW) * C + c0;
+  const T* gsrc = dy + ((size_t)n * HW) * C + c0;
   float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -575,8 +585,8 @@ __global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f1
   }
   auto accum = [&](const uint4& ux, const uint4& ug) {
     float xv[8], gv[8];
-    lr_unpack8(ux, xv);
-    lr_unpack8(ug, gv);
+    lr_unpack8<T>(ux, xv);
+    lr_unpack8<T>(ug, gv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float xh = (xv[i] - mu[i]) * rs[i];
@@ -615,10 +625,11 @@ __global__ void gn_bwd_stats_kernel(const f16* __restrict__ x1, int C1, const f1
   }
 }
 
-__global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2, int HW,
-                                    const f16* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ bwd,
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, int HW,
+                                    const T* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ bwd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int silu,
-                                    f16* __restrict__ dx1, f16* __restrict__ dx2, int pix_per_block, int nOct, int R,
+                                    T* __restrict__ dx1, T* __restrict__ dx2, int pix_per_block, int nOct, int R,
                                     int nchunks) {
   __shared__ float s_mean[32], s_rstd[32], s_c1[32], s_c2[32];
   const int C = C1 + C2, Cg = C / 32;
@@ -643,12 +654,12 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
   }
   __syncthreads();
   if (r >= R) return;
-  const f16* src;
-  f16* dst;
+  const T* src;
+  T* dst;
   int cs;
   if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; dst = dx1 + ((size_t)n * HW) * C1 + c0; cs = C1; }
   else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); dst = dx2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
-  const f16* gsrc = dy + ((size_t)n * HW) * C + c0;
+  const T* gsrc = dy + ((size_t)n * HW) * C + c0;
   float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -658,8 +669,8 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
   }
   auto emit = [&](int pp, const uint4& ux, const uint4& ug) {
     float xv[8], gv[8], f[8];
-    lr_unpack8(ux, xv);
-    lr_unpack8(ug, gv);
+    lr_unpack8<T>(ux, xv);
+    lr_unpack8<T>(ug, gv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float xh = (xv[i] - mu[i]) * rs[i];
@@ -667,7 +678,7 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
       const float g = gv[i] * gn_act_grad(z, silu) * ga[i];
       f[i] = rs[i] * (g - k1[i] - xh * k2[i]);
     }
-    *reinterpret_cast<uint4*>(dst + (size_t)pp * cs) = lr_pack8(f);
+    *reinterpret_cast<uint4*>(dst + (size_t)pp * cs) = lr_pack8<T>(f);
   };
   int p = p0 + r;
   for (; p + 3 * R < p1; p += 4 * R) {
@@ -684,7 +695,8 @@ __global__ void gn_bwd_apply_kernel(const f16* __restrict__ x1, int C1, const f1
     emit(p, *reinterpret_cast<const uint4*>(src + (size_t)p * cs), *reinterpret_cast<const uint4*>(gsrc + (size_t)p * C));
 }
 
-extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
+template <typename T>
+static int lr_groupnorm_bwd_t(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
                                 const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu,
                                 float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) {
   if (!x1 || !dy || !fwd_partials || !bwd_partials || !gamma || !beta || !dx1 || N <= 0 || HW <= 0) return LR_E_ARG;
@@ -699,8 +711,8 @@ extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, in
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
   const int nchunks = gn_nchunks(N, HW, C);
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunks, N), dim3(threads), (size_t)R * C * 2 * sizeof(float), st,
-                     (const f16*)x1, C1, (const f16*)x2, C2, HW, (const f16*)dy, fwd_partials, gamma, beta, eps, silu,
+  hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(nchunks, N), dim3(threads), (size_t)R * C * 2 * sizeof(float), st,
+                     (const T*)x1, C1, (const T*)x2, C2, HW, (const T*)dy, fwd_partials, gamma, beta, eps, silu,
                      bwd_partials, nOct, R, nchunks);
   int rc = lr_launch_status();
   if (rc) return rc;
@@ -709,8 +721,22 @@ extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, in
   int ppb = (int)(((long long)N * HW + blocks - 1) / blocks);
   if (ppb < 16) ppb = 16;
   if (ppb > HW) ppb = HW;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, st, (const f16*)x1, C1,
-                     (const f16*)x2, C2, HW, (const f16*)dy, fwd_partials, bwd_partials, gamma, beta, eps, silu, (f16*)dx1,
-                     (f16*)dx2, ppb, nOct, R, nchunks);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, st, (const T*)x1, C1,
+                     (const T*)x2, C2, HW, (const T*)dy, fwd_partials, bwd_partials, gamma, beta, eps, silu, (T*)dx1,
+                     (T*)dx2, ppb, nOct, R, nchunks);
   return lr_launch_status();
 }
+
+// ---- C ABI: every entry point in its fp16 and bf16 form -------------------------------------------------------------
+extern "C" int lr_groupnorm_stats(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials, lr_stream_t s) { return lr_groupnorm_stats_t<f16>(x1, C1, x2, C2, N, HW, partials, s); }
+extern "C" int lr_groupnorm_stats_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, float* partials, lr_stream_t s) { return lr_groupnorm_stats_t<bf16>(x1, C1, x2, C2, N, HW, partials, s); }
+extern "C" int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s) { return lr_groupnorm_apply_t<f16>(x1, C1, x2, C2, N, HW, partials, gamma, beta, eps, silu, y, s); }
+extern "C" int lr_groupnorm_apply_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s) { return lr_groupnorm_apply_t<bf16>(x1, C1, x2, C2, N, HW, partials, gamma, beta, eps, silu, y, s); }
+extern "C" int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials, int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s) { return lr_groupnorm_apply_n_t<f16>(x1, C1, x2, C2, N, HW, partials, nchunks, gamma, beta, eps, silu, y, s); }
+extern "C" int lr_groupnorm_apply_n_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials, int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s) { return lr_groupnorm_apply_n_t<bf16>(x1, C1, x2, C2, N, HW, partials, nchunks, gamma, beta, eps, silu, y, s); }
+extern "C" int lr_layernorm(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C, lr_stream_t s) { return lr_layernorm_t<f16>(x, gamma, beta, eps, y, M, C, s); }
+extern "C" int lr_layernorm_bf16(const lr_half* x, const float* gamma, const float* beta, float eps, lr_half* y, int M, int C, lr_stream_t s) { return lr_layernorm_t<bf16>(x, gamma, beta, eps, y, M, C, s); }
+extern "C" int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M, int C, lr_stream_t s) { return lr_layernorm_bwd_t<f16>(x, dy, gamma, eps, dx, M, C, s); }
+extern "C" int lr_layernorm_bwd_bf16(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M, int C, lr_stream_t s) { return lr_layernorm_bwd_t<bf16>(x, dy, gamma, eps, dx, M, C, s); }
+extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW, const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<f16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s); }
+extern "C" int lr_groupnorm_bwd_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW, const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<bf16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s); }

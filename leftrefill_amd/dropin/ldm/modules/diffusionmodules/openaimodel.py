@@ -131,7 +131,7 @@ class ResBlock(TimestepBlock):
 
     def forward(self, x, emb):
         pr = self._packed()
-        e = ops.linear_small_m(emb.to(torch.float16).contiguous(), pr.emb.w, pr.emb.b, act_in=True)
+        e = ops.linear_small_m(emb.to(pr.emb.w.dtype).contiguous(), pr.emb.w, pr.emb.b, act_in=True)
         out = self._fwd(engine.act_from_nchw(x), e)
         return engine.act_to_nchw(out, self.out_channels).to(x.dtype)
 
@@ -179,6 +179,8 @@ class UNetModel(nn.Module):
         self.num_classes = num_classes
         self.use_checkpoint = use_checkpoint
         self.dtype = th.float16 if use_fp16 else th.float32
+        # 16-bit type of the HIP path's activations / packed weights: float16 (reference autocast, appendix B) or bfloat16
+        self.compute_dtype = th.float16
         self.num_heads = num_heads
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
@@ -249,7 +251,7 @@ class UNetModel(nn.Module):
     MAX_GRAPHS = 8        # captured step graphs kept per model (least recently used shape is dropped beyond that)
 
     def _sig(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.compute_dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -274,6 +276,10 @@ class UNetModel(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs on the HIP device only: call .to('cuda') first (no CPU fallback)")
+        with engine.compute(self.compute_dtype):
+            return self._pack(sig)
+
+    def _pack(self, sig):
         E = engine
         plan = {"sig": sig}
         plan["t0"] = E.PackedLinear(self.time_embed[0])
@@ -349,7 +355,7 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         L = context.shape[1]
         ctx = context.reshape(N * L, context.shape[2])
-        t_emb = ops.timestep_embedding(timesteps, self.model_channels)
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels, self.compute_dtype)
         e = ops.linear_small_m(t_emb, P["t0"].w, P["t0"].b, act_out=True)
         emb = ops.linear_small_m(e, P["t2"].w, P["t2"].b)
         emb_all = ops.linear_small_m(emb, P["emb_w"], P["emb_b"], act_in=True)   # [N, sum Cout]
@@ -397,7 +403,7 @@ class UNetModel(nn.Module):
             if taps is not None:
                 taps[name] = E.act_to_nchw(a, dtype=torch.float32)
 
-        act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"]), N, H, W)
+        act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"], dtype=self.compute_dtype), N, H, W)
         hs = []
         for i, steps in enumerate(P["input"]):
             act = run(steps, act)
@@ -411,7 +417,7 @@ class UNetModel(nn.Module):
             tap(f"out{i}", act)
         act = E.gn(act, P["out_norm"], True)
         act = E.conv(act, P["out_conv"])
-        return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels, torch.float16)
+        return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """eps = UNet(x, t, context).  Returns fp16 (the reference's output dtype under autocast, appendix B)."""
@@ -422,12 +428,12 @@ class UNetModel(nn.Module):
         ctx_src = context
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the noisy latent is not produced (p_losses feeds x_noisy without grad)")
-        context = context.to(torch.float16).contiguous()
+        context = context.to(self.compute_dtype).contiguous()
         if not self.use_hip_graph or (torch.is_grad_enabled() and context.requires_grad):
             # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
             # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
-        key = (tuple(x.shape), tuple(context.shape), x.device.index)
+        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype)
         g = self._graphs.pop(key, None)
         if g is None:
             g = _StepGraph(self, x, timesteps, context)

@@ -22,6 +22,30 @@ import torch
 from . import packing
 from . import train_ops as ops     # == leftrefill_amd.ops unless autograd is recording and an input requires grad
 
+# 16-bit storage / MFMA operand type of activations and packed weights: float16 (the reference's autocast type, every
+# inference config) or bfloat16 (BASELINE configs[4]).  Accumulation, statistics and the softmax stay fp32 in both.
+_COMPUTE = [torch.float16]
+
+
+def compute_dtype():
+    return _COMPUTE[0]
+
+
+class compute:
+    """`with engine.compute(torch.bfloat16): ...` -- packing and activation conversions inside use that 16-bit type."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"compute dtype must be float16 or bfloat16, got {dtype}")
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _COMPUTE[0]
+        _COMPUTE[0] = self.dtype
+
+    def __exit__(self, *exc):
+        _COMPUTE[0] = self.prev
+
 
 @dataclass
 class Act:
@@ -56,7 +80,7 @@ class PackedConv:
         w = conv.weight.detach()
         self.cout = w.shape[0]
         self.taps = w.shape[2] * w.shape[3]
-        self.w = packing.pack_conv(w, cin_pad=cin_pad)
+        self.w = packing.pack_conv(w, cin_pad=cin_pad, dtype=compute_dtype())
         self.b = packing.pack_bias(conv.bias.detach(), self.w.shape[0]) if conv.bias is not None else None
         self.stride = conv.stride[0]
 
@@ -71,12 +95,12 @@ class PackedLinear:
         w = weight.detach()
         if w.dim() == 4:  # 1x1 conv used as a linear (use_linear_in_transformer=False)
             w = w.reshape(w.shape[0], w.shape[1])
-        self.w = packing.pack_linear(w)
+        self.w = packing.pack_linear(w, compute_dtype())
         self.b = f32(bias) if bias is not None else None
         self.wf = None
         if norm is not None:
             self.wf, self.bf, self.cs = packing.fold_layernorm(w, None if bias is None else bias.detach(),
-                                                               norm.weight.detach(), norm.bias.detach())
+                                                               norm.weight.detach(), norm.bias.detach(), compute_dtype())
             self.eps = float(norm.eps)
 
 
@@ -126,10 +150,10 @@ class PackedTBlock:
         self.attn2 = PackedAttn(blk.attn2, False, blk.norm2)
         self.n1, self.n2, self.n3 = PackedNorm(blk.norm1), PackedNorm(blk.norm2), PackedNorm(blk.norm3)
         proj = blk.ff.net[0].proj
-        self.geglu_w, self.geglu_b = packing.pack_geglu(proj.weight.detach(), proj.bias.detach())
+        self.geglu_w, self.geglu_b = packing.pack_geglu(proj.weight.detach(), proj.bias.detach(), compute_dtype())
         # LayerNorm(norm3)-folded copy of the GEGLU projection (rows in the same interleaved order)
         wf, bf, cs = packing.fold_layernorm(proj.weight.detach(), proj.bias.detach(), blk.norm3.weight.detach(),
-                                            blk.norm3.bias.detach())
+                                            blk.norm3.bias.detach(), compute_dtype())
         perm = packing.geglu_perm(proj.weight.shape[0] // 2, proj.weight.device)
         self.geglu_wf, self.geglu_bf, self.geglu_cs = wf[perm].contiguous(), bf[perm].contiguous(), cs[perm].contiguous()
         self.ff2 = PackedLinear(blk.ff.net[2])
@@ -340,14 +364,14 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):
 def to_tokens(x):
     """[B, L, C] any float dtype -> ([B*L, C] fp16 contiguous, B, L)"""
     B, L, C = x.shape
-    return x.reshape(B * L, C).to(torch.float16).contiguous(), B, L
+    return x.reshape(B * L, C).to(compute_dtype()).contiguous(), B, L
 
 
 def act_from_nchw(x, cpad=None):
     N, C, H, W = x.shape
-    return Act(ops.nchw_to_nhwc(x, cpad=cpad), N, H, W)
+    return Act(ops.nchw_to_nhwc(x, cpad=cpad, dtype=compute_dtype()), N, H, W)
 
 
-def act_to_nchw(act: Act, C=None, dtype=torch.float16):
+def act_to_nchw(act: Act, C=None, dtype=None):
     tok = act.materialize()
     return ops.nhwc_to_nchw(tok, act.N, act.H, act.W, C or tok.shape[1], dtype)

@@ -52,28 +52,37 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+HALF_TYPES = (torch.float16, torch.bfloat16)
+
+
 def _chk16(t, name):
-    assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous(), f"{name}: need contiguous cuda fp16"
+    assert t.is_cuda and t.dtype in HALF_TYPES and t.is_contiguous(), f"{name}: need contiguous cuda fp16 / bf16"
 
 
-def nchw_to_nhwc(x1, x2=None, cpad=None):
-    """[N,C1,H,W] fp32 (+ optional [N,C2,H,W]) -> [N*H*W, cpad] fp16."""
+def _fn(lib, name, dtype):
+    return _lib.fn(lib, name, dtype)
+
+
+def nchw_to_nhwc(x1, x2=None, cpad=None, dtype=torch.float16):
+    """[N,C1,H,W] fp32 (+ optional [N,C2,H,W]) -> [N*H*W, cpad] fp16 (or bf16)."""
     lib = _lib.load()
     N, C1, H, W = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]
     cpad = cpad or ((C1 + C2 + 7) // 8) * 8
     x1 = x1.float().contiguous()
     x2 = None if x2 is None else x2.float().contiguous()
-    y = torch.empty(N * H * W, cpad, device=x1.device, dtype=torch.float16)
-    _lib.check(lib.lr_nchw_f32_to_nhwc_f16(_p(x1), C1, _p(x2), C2, _p(y), cpad, N, H, W, _stream()), "nchw_to_nhwc")
+    y = torch.empty(N * H * W, cpad, device=x1.device, dtype=dtype)
+    _lib.check(_fn(lib, "lr_nchw_f32_to_nhwc_f16", dtype)(_p(x1), C1, _p(x2), C2, _p(y), cpad, N, H, W, _stream()), "nchw_to_nhwc")
     return y
 
 
-def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
+def nhwc_to_nchw(y, N, H, W, C, out_dtype=None):
+    """[N*H*W, >=C] -> [N,C,H,W] in out_dtype: float32, or the 16-bit type of y (default)."""
     lib = _lib.load()
     _chk16(y, "y")
+    out_dtype = y.dtype if out_dtype is None or out_dtype in HALF_TYPES else out_dtype
     out = torch.empty(N, C, H, W, device=y.device, dtype=out_dtype)
-    _lib.check(lib.lr_nhwc_f16_to_nchw(_p(y), y.shape[-1], C, _p(out), int(out_dtype == torch.float32), N, H, W,
+    _lib.check(_fn(lib, "lr_nhwc_f16_to_nchw", y.dtype)(_p(y), y.shape[-1], C, _p(out), int(out_dtype == torch.float32), N, H, W,
                                        _stream()), "nhwc_to_nchw")
     return out
 
@@ -89,10 +98,10 @@ def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None):
         C2 = x2.shape[-1]
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C1 + C2
     partials = torch.empty(N * GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
-    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=x1.dtype)
     st = _stream()
-    _lib.check(lib.lr_groupnorm_stats(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
-    _lib.check(lib.lr_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
+    _lib.check(_fn(lib, "lr_groupnorm_stats", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
+    _lib.check(_fn(lib, "lr_groupnorm_apply", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
                                       int(bool(silu)), _p(y), st), "groupnorm_apply")
     return y
 
@@ -112,10 +121,10 @@ def group_norm_fused(x1, N, HW, gamma, beta, eps, silu, gs1, x2=None, gs2=None):
         assert p2.shape == (N * HW // r2, C2, 2) and HW % r2 == 0
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C1 + C2
     partials = torch.empty(N * 64, device=x1.device, dtype=torch.float32)
-    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+    y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=x1.dtype)
     st = _stream()
     _lib.check(lib.lr_groupnorm_finalize(_p(p1), C1, r1, _p(p2), C2, r2, N, HW, _p(partials), st), "groupnorm_finalize")
-    _lib.check(lib.lr_groupnorm_apply_n(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), 1, _p(gamma), _p(beta), float(eps),
+    _lib.check(_fn(lib, "lr_groupnorm_apply_n", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), 1, _p(gamma), _p(beta), float(eps),
                                         int(bool(silu)), _p(y), st), "groupnorm_apply_n")
     return y
 
@@ -125,15 +134,15 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     _chk16(x, "x")
     M, C = x.shape
     y = torch.empty_like(x)
-    _lib.check(lib.lr_layernorm(_p(x), _p(gamma), _p(beta), float(eps), _p(y), M, C, _stream()), "layernorm")
+    _lib.check(_fn(lib, "lr_layernorm", x.dtype)(_p(x), _p(gamma), _p(beta), float(eps), _p(y), M, C, _stream()), "layernorm")
     return y
 
 
-def timestep_embedding(t, dim):
+def timestep_embedding(t, dim, dtype=torch.float16):
     lib = _lib.load()
     t = t.to(torch.int64).contiguous()
-    out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float16)
-    _lib.check(lib.lr_timestep_embedding(_p(t), t.shape[0], dim, _p(out), _stream()), "timestep_embedding")
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=dtype)
+    _lib.check(_fn(lib, "lr_timestep_embedding", dtype)(_p(t), t.shape[0], dim, _p(out), _stream()), "timestep_embedding")
     return out
 
 
@@ -144,11 +153,11 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
     _chk16(w, "w")
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty(M, N, device=a.device, dtype=torch.float16)
+    out = torch.empty(M, N, device=a.device, dtype=a.dtype)
     st = _stream()
     for m0 in range(0, M, 16):   # the kernel keeps <= 16 rows in LDS; larger batches go in row chunks
         mc = min(16, M - m0)
-        _lib.check(lib.lr_linear_small_m(a[m0:].data_ptr(), K, _p(w), _p(bias), out[m0:].data_ptr(), N, mc, N, K,
+        _lib.check(_fn(lib, "lr_linear_small_m", a.dtype)(a[m0:].data_ptr(), K, _p(w), _p(bias), out[m0:].data_ptr(), N, mc, N, K,
                                          int(act_in), int(act_out), st), "linear_small_m")
     return out
 
@@ -179,7 +188,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     M = B * H * W
     n_out = Nw // 2 if geglu else Nw
     if out is None:
-        out = torch.empty(M, n_out, device=x1.device, dtype=torch.float16)
+        out = torch.empty(M, n_out, device=x1.device, dtype=x1.dtype)
     a = GemmArgs()
     a.p1, a.C1, a.p2, a.C2 = _p(x1), C1, _p(x2), C2
     a.B, a.H, a.W, a.Hs, a.Ws = B, H, W, Hs, Ws
@@ -191,7 +200,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.rowvec, a.ld_rowvec = _p(rowvec), (rowvec.stride(0) if rowvec is not None else 0)
     a.resid, a.ld_resid = _p(resid), (resid.stride(0) if resid is not None else 0)
     if resid is not None:
-        assert resid.shape[0] == M and resid.dtype == torch.float16
+        assert resid.shape[0] == M and resid.dtype == x1.dtype
     a.out, a.ld_out = _p(out), out.stride(0)
     assert not (geglu and gelu)
     a.geglu = 2 if gelu else int(geglu)      # 1: fused GEGLU, 2: plain erf-GELU epilogue
@@ -200,6 +209,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.splits = splits
     a.workspace, a.workspace_bytes = 0, 0
     a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
+    assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
+    a.dtype = int(x1.dtype == torch.bfloat16)      # LR_DTYPE_F16 | LR_DTYPE_BF16
     if ln is not None:
         st_in, eps, colsum = ln
         assert st_in.dtype == torch.float32 and st_in.is_contiguous() and st_in.shape[0] == M and st_in.shape[2] == 2
@@ -314,11 +325,11 @@ VT_MIN_KEYS = int(os.environ.get("LEFTREFILL_VT_MIN_KEYS", "1024"))   # pre-tran
 def transpose_v(v, B, heads, Nkv, out=None):
     """v [B*Nkv, >=heads*64] (row stride ldv) -> V^T [B, heads*64, pad64(Nkv)] in the attention kernel's key order."""
     lib = _lib.load()
-    assert v.is_cuda and v.dtype == torch.float16 and v.stride(1) == 1
+    assert v.is_cuda and v.dtype in HALF_TYPES and v.stride(1) == 1
     ld = ((Nkv + 63) // 64) * 64
-    vt = torch.empty(B, heads * 64, ld, device=v.device, dtype=torch.float16) if out is None else out
+    vt = torch.empty(B, heads * 64, ld, device=v.device, dtype=v.dtype) if out is None else out
     assert vt.shape == (B, heads * 64, ld) and vt.is_contiguous()
-    _lib.check(lib.lr_transpose_v_f16(_p(v), v.stride(0), _p(vt), ld, B, heads, Nkv, _stream()), "transpose_v")
+    _lib.check(_fn(lib, "lr_transpose_v_f16", v.dtype)(_p(v), v.stride(0), _p(vt), ld, B, heads, Nkv, _stream()), "transpose_v")
     return vt
 
 
@@ -329,16 +340,16 @@ def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     the pre-transposed-V kernel (vt: optional cached result of transpose_v, e.g. for a fixed context)."""
     lib = _lib.load()
     for t_ in (q, k, v):
-        assert t_.is_cuda and t_.dtype == torch.float16 and t_.stride(1) == 1
+        assert t_.is_cuda and t_.dtype == q.dtype and q.dtype in HALF_TYPES and t_.stride(1) == 1
     if out is None:
-        out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+        out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=q.dtype)
     if vt is None and Nkv >= VT_MIN_KEYS:
         vt = transpose_v(v, B, heads, Nkv)
     if vt is not None:
-        _lib.check(lib.lr_attention_vt_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),
+        _lib.check(_fn(lib, "lr_attention_vt_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),
                                            out.stride(0), B, heads, Nq, Nkv, float(scale), _stream()), "attention_vt")
         return out
-    _lib.check(lib.lr_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+    _lib.check(_fn(lib, "lr_attention_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                     B, heads, Nq, Nkv, float(scale), _stream()), "attention")
     return out
 
@@ -347,9 +358,9 @@ def attention_causal(q, k, v, B, heads, N, scale):
     """Causal self-attention (query i sees keys <= i), q/k/v [B*N, >=heads*64] strided column slices; the text tower."""
     lib = _lib.load()
     for t_ in (q, k, v):
-        assert t_.is_cuda and t_.dtype == torch.float16 and t_.stride(1) == 1
-    out = torch.empty(B * N, heads * 64, device=q.device, dtype=torch.float16)
-    _lib.check(lib.lr_attention_causal_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+        assert t_.is_cuda and t_.dtype == q.dtype and q.dtype in HALF_TYPES and t_.stride(1) == 1
+    out = torch.empty(B * N, heads * 64, device=q.device, dtype=q.dtype)
+    _lib.check(_fn(lib, "lr_attention_causal_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                            B, heads, N, float(scale), _stream()), "attention_causal")
     return out
 
@@ -382,8 +393,8 @@ def mv_gather(x, b, v, s):
     lib = _lib.load()
     _chk16(x, "x")
     C = x.shape[-1]
-    seq = torch.empty(b * (v + 1) * s * s, C, device=x.device, dtype=torch.float16)
-    _lib.check(lib.lr_mv_gather(_p(x), _p(seq), b, v, s, C, _stream()), "mv_gather")
+    seq = torch.empty(b * (v + 1) * s * s, C, device=x.device, dtype=x.dtype)
+    _lib.check(_fn(lib, "lr_mv_gather", x.dtype)(_p(x), _p(seq), b, v, s, C, _stream()), "mv_gather")
     return seq
 
 
@@ -391,8 +402,8 @@ def mv_scatter(seq, b, v, s):
     lib = _lib.load()
     _chk16(seq, "seq")
     C = seq.shape[-1]
-    x = torch.empty(b * v * s * 2 * s, C, device=seq.device, dtype=torch.float16)
-    _lib.check(lib.lr_mv_scatter(_p(seq), _p(x), b, v, s, C, _stream()), "mv_scatter")
+    x = torch.empty(b * v * s * 2 * s, C, device=seq.device, dtype=seq.dtype)
+    _lib.check(_fn(lib, "lr_mv_scatter", seq.dtype)(_p(seq), _p(x), b, v, s, C, _stream()), "mv_scatter")
     return x
 
 
@@ -400,12 +411,12 @@ def ddim_cfg_step(x, eps, noise, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus
     """x [B,...] fp32; eps [2B,...] fp16|fp32 (uncond first); returns (x_prev, pred_x0) fp32."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
-    assert eps.numel() == 2 * x.numel() and eps.dtype in (torch.float16, torch.float32)
+    assert eps.numel() == 2 * x.numel() and eps.dtype in (torch.float16, torch.bfloat16, torch.float32)
     if noise is not None:
         noise = noise.float().contiguous()
     x_prev = torch.empty_like(x)
     pred = torch.empty_like(x)
-    _lib.check(lib.lr_ddim_cfg_step(_p(x), _p(eps), int(eps.dtype == torch.float32), _p(noise), _p(x_prev), _p(pred),
+    _lib.check(_fn(lib, "lr_ddim_cfg_step", torch.bfloat16 if eps.dtype == torch.bfloat16 else torch.float16)(_p(x), _p(eps), int(eps.dtype == torch.float32), _p(noise), _p(x_prev), _p(pred),
                                     x.numel(), float(cfg_scale), float(a_t), float(a_prev), float(sigma_t),
                                     float(sqrt_one_minus_at), _stream()), "ddim_cfg_step")
     return x_prev, pred

@@ -11,12 +11,12 @@ def pad_to(n, m):
     return ((n + m - 1) // m) * m
 
 
-def pack_conv(w, cin_pad=None, cout_pad=None):
+def pack_conv(w, cin_pad=None, cout_pad=None, dtype=torch.float16):
     cout, cin, kh, kw = w.shape
     cin_pad = cin_pad or pad_to(cin, 64)
     cout_pad = cout_pad or pad_to(cout, 64)
-    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
-    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin).to(torch.float16)
+    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=dtype, device=w.device)
+    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin).to(dtype)
     return out.reshape(cout_pad, kh * kw * cin_pad).contiguous()
 
 
@@ -27,8 +27,8 @@ def pack_bias(b, n_pad=None):
     return out
 
 
-def pack_linear(w):
-    return w.to(torch.float16).contiguous()
+def pack_linear(w, dtype=torch.float16):
+    return w.to(dtype).contiguous()
 
 
 def geglu_perm(n_half, device=None):
@@ -42,18 +42,18 @@ def geglu_perm(n_half, device=None):
     return perm
 
 
-def pack_geglu(w, b):
+def pack_geglu(w, b, dtype=torch.float16):
     n_half = w.shape[0] // 2
     perm = geglu_perm(n_half, w.device)
-    return w[perm].to(torch.float16).contiguous(), b[perm].float().contiguous()
+    return w[perm].to(dtype).contiguous(), b[perm].float().contiguous()
 
 
-def fold_layernorm(w, b, gamma, beta):
+def fold_layernorm(w, b, gamma, beta, dtype=torch.float16):
     """Linear(LayerNorm(x)) as ONE GEMM on the raw x (lr_gemm_args.ln_stats):
-        y = rstd * (x @ Wf^T - mean * cs) + bf,   Wf = W * gamma (fp16),  cs[n] = sum_k Wf[n][k],  bf = W @ beta + b.
-    cs is taken from the fp16-ROUNDED Wf so that it cancels exactly what the matrix cores accumulate."""
+        y = rstd * (x @ Wf^T - mean * cs) + bf,   Wf = W * gamma (fp16 / bf16),  cs[n] = sum_k Wf[n][k],  bf = W @ beta + b.
+    cs is taken from the ROUNDED Wf so that it cancels exactly what the matrix cores accumulate."""
     w32 = w.float()
-    wf = (w32 * gamma.float()[None, :]).to(torch.float16).contiguous()
+    wf = (w32 * gamma.float()[None, :]).to(dtype).contiguous()
     cs = wf.float().sum(dim=1).contiguous()
     bf = (w32 * beta.float()[None, :]).sum(dim=1)     # not `@`: packing may run inside a caller's autocast region (fp16 matmul)
     if b is not None:

@@ -111,8 +111,8 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
 def geglu_fwd(pre):
     lib = _lib.load()
     M, H2 = pre.shape
-    out = torch.empty(M, H2 // 2, device=pre.device, dtype=torch.float16)
-    _lib.check(lib.lr_geglu_fwd(_p(pre), _p(out), M, H2 // 2, _stream()), "geglu_fwd")
+    out = torch.empty(M, H2 // 2, device=pre.device, dtype=pre.dtype)
+    _lib.check(_lib.fn(lib, "lr_geglu_fwd", pre.dtype)(_p(pre), _p(out), M, H2 // 2, _stream()), "geglu_fwd")
     return out
 
 
@@ -121,7 +121,7 @@ def geglu_bwd(pre, dy):
     M, H = dy.shape
     assert pre.shape == (M, 2 * H) and pre.is_contiguous() and dy.is_contiguous()
     dpre = torch.empty_like(pre)
-    _lib.check(lib.lr_geglu_bwd(_p(pre), _p(dy), _p(dpre), M, H, _stream()), "geglu_bwd")
+    _lib.check(_lib.fn(lib, "lr_geglu_bwd", pre.dtype)(_p(pre), _p(dy), _p(dpre), M, H, _stream()), "geglu_bwd")
     return dpre
 
 
@@ -130,8 +130,8 @@ def sumpool2x2(x, N, H, W):
     lib = _lib.load()
     C = x.shape[-1]
     assert x.shape[0] == N * 4 * H * W and x.is_contiguous()
-    y = torch.empty(N * H * W, C, device=x.device, dtype=torch.float16)
-    _lib.check(lib.lr_sumpool2x2(_p(x), _p(y), N, H, W, C, _stream()), "sumpool2x2")
+    y = torch.empty(N * H * W, C, device=x.device, dtype=x.dtype)
+    _lib.check(_lib.fn(lib, "lr_sumpool2x2", x.dtype)(_p(x), _p(y), N, H, W, C, _stream()), "sumpool2x2")
     return y
 
 
@@ -142,10 +142,10 @@ class _GroupNorm(torch.autograd.Function):
         C1 = x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
         partials = torch.empty(N * ops.GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
-        y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=torch.float16)
+        y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=x1.dtype)
         st = _stream()
-        _lib.check(lib.lr_groupnorm_stats(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
-        _lib.check(lib.lr_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
+        _lib.check(_lib.fn(lib, "lr_groupnorm_stats", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
+        _lib.check(_lib.fn(lib, "lr_groupnorm_apply", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
                                           int(bool(silu)), _p(y), st), "groupnorm_apply")
         ctx.save_for_backward(x1, x2, gamma, beta, partials)
         ctx.meta = (N, HW, float(eps), int(bool(silu)))
@@ -162,7 +162,7 @@ class _GroupNorm(torch.autograd.Function):
         scratch = torch.empty_like(partials)
         dx1 = torch.empty_like(x1)
         dx2 = None if x2 is None else torch.empty_like(x2)
-        _lib.check(lib.lr_groupnorm_bwd(_p(x1), C1, _p(x2), C2, _p(dy), N, HW, _p(partials), _p(gamma), _p(beta), eps, silu,
+        _lib.check(_lib.fn(lib, "lr_groupnorm_bwd", x1.dtype)(_p(x1), C1, _p(x2), C2, _p(dy), N, HW, _p(partials), _p(gamma), _p(beta), eps, silu,
                                         _p(scratch), _p(dx1), _p(dx2), _stream()), "groupnorm_bwd")
         return dx1, dx2, None, None, None, None, None, None
 
@@ -188,7 +188,7 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         M, C = x.shape
-        _lib.check(lib.lr_layernorm_bwd(_p(x), _p(dy), _p(gamma), ctx.eps, _p(dx), M, C, _stream()), "layernorm_bwd")
+        _lib.check(_lib.fn(lib, "lr_layernorm_bwd", x.dtype)(_p(x), _p(dy), _p(gamma), ctx.eps, _p(dx), M, C, _stream()), "layernorm_bwd")
         return dx, None, None, None
 
 
@@ -209,7 +209,7 @@ class _ToNCHW(torch.autograd.Function):
         return ops.nchw_to_nhwc(dout.float().contiguous(), cpad=ctx.meta[0]), None, None, None, None, None
 
 
-def nhwc_to_nchw(y, N, H, W, C, out_dtype=torch.float16):
+def nhwc_to_nchw(y, N, H, W, C, out_dtype=None):
     if not _needs_grad(y):
         return ops.nhwc_to_nchw(y, N, H, W, C, out_dtype)
     return _ToNCHW.apply(y, N, H, W, C, out_dtype)
@@ -232,14 +232,14 @@ def _attention_backward(q, k, v, out, lse, dout, meta, dq, dk, dv):
     a.ld_qt, a.ld_kt = qt.shape[2], kt.shape[2]
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
-    _lib.check(lib.lr_attention_bwd_f16(a, _stream()), "attention_bwd")
+    _lib.check(_lib.fn(lib, "lr_attention_bwd_f16", q.dtype)(a, _stream()), "attention_bwd")
 
 
 def _attention_forward(q, k, v, B, heads, Nq, Nkv, scale):
     lib = _lib.load()
-    out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=torch.float16)
+    out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=q.dtype)
     lse = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
-    _lib.check(lib.lr_attention_lse_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+    _lib.check(_lib.fn(lib, "lr_attention_lse_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                         _p(lse), B, heads, Nq, Nkv, float(scale), _stream()), "attention_lse")
     return out, lse
 
@@ -257,9 +257,9 @@ class _Attention(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         B, heads, Nq, Nkv, _ = ctx.meta
         C = heads * 64
-        dq = torch.empty(B * Nq, C, device=q.device, dtype=torch.float16)
-        dk = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
-        dv = torch.empty(B * Nkv, C, device=q.device, dtype=torch.float16)
+        dq = torch.empty(B * Nq, C, device=q.device, dtype=q.dtype)
+        dk = torch.empty(B * Nkv, C, device=q.device, dtype=q.dtype)
+        dv = torch.empty(B * Nkv, C, device=q.device, dtype=q.dtype)
         _attention_backward(q, k, v, out, lse, dout, ctx.meta, dq, dk, dv)
         return dq, dk, dv, None, None, None, None, None
 
@@ -336,8 +336,8 @@ class _MvGather(torch.autograd.Function):
         b, v, s = ctx.meta
         dseq = dseq.contiguous()
         C = dseq.shape[-1]
-        dx = torch.empty(b * v * s * 2 * s, C, device=dseq.device, dtype=torch.float16)
-        _lib.check(lib.lr_mv_gather_bwd(_p(dseq), _p(dx), b, v, s, C, _stream()), "mv_gather_bwd")
+        dx = torch.empty(b * v * s * 2 * s, C, device=dseq.device, dtype=dseq.dtype)
+        _lib.check(_lib.fn(lib, "lr_mv_gather_bwd", dseq.dtype)(_p(dseq), _p(dx), b, v, s, C, _stream()), "mv_gather_bwd")
         return dx, None, None, None
 
 
@@ -353,8 +353,8 @@ class _MvScatter(torch.autograd.Function):
         b, v, s = ctx.meta
         dx = dx.contiguous()
         C = dx.shape[-1]
-        dseq = torch.empty(b * (v + 1) * s * s, C, device=dx.device, dtype=torch.float16)
-        _lib.check(lib.lr_mv_scatter_bwd(_p(dx), _p(dseq), b, v, s, C, _stream()), "mv_scatter_bwd")
+        dseq = torch.empty(b * (v + 1) * s * s, C, device=dx.device, dtype=dx.dtype)
+        _lib.check(_lib.fn(lib, "lr_mv_scatter_bwd", dx.dtype)(_p(dx), _p(dseq), b, v, s, C, _stream()), "mv_scatter_bwd")
         return dseq, None, None, None
 
 
