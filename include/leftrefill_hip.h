@@ -134,10 +134,13 @@ typedef struct lr_gemm_args {
    * (H*W must be a multiple of R) into per-group sums.  Fixed order, no atomics.  Not with split-K or GEGLU. */
   float* gn_stats_out;
   int32_t dtype;            /* LR_DTYPE_F16 | LR_DTYPE_BF16: type of p1, p2, wt, rowvec, resid, out (geglu == 2 is fp16 only) */
+  int32_t stages;           /* depth of the LDS ring: 0 = the tile's default (tile_m 128: 2; 256 x {128,160}: 3; 256 x {256,320}: 2);
+                             * 4 with tile_m 128, tile_n 128 | 160 selects the 4-stage one-block-per-CU instance (small-M levels);
+                             * any other non-default value: LR_E_UNSUPPORTED */
 } lr_gemm_args;
 /* rows per block of gn_stats_out (a function of the tile that will be used) */
 int lr_gemm_gn_rows(const lr_gemm_args* args);
-/* plan[0..2] = (tile_m, tile_n, splits) the call would use: explicit requests as given, zeros resolved by the static
+/* plan[0..3] = (tile_m, tile_n, splits, stages) the call would use: explicit requests as given, zeros resolved by the static
  * heuristics (a pure function of the shape -- never of timing; the Python front end ships its tuned choices as a table). */
 int lr_gemm_plan(const lr_gemm_args* args, int32_t* plan);
 /* number of per-row partials this call writes to stats_out (a function of N and the tile that will be used) */

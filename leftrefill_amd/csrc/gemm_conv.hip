@@ -17,6 +17,7 @@
 //   consecutive output channels of ONE output row: the fp32 tile goes to LDS with 16-byte writes, and the epilogue
 //   (bias, per-sample time-embedding row, residual, GEGLU gate) streams it out as whole fp16 lines.
 #include "common.h"
+#include <type_traits>
 
 #define BK 64
 #define GEMM_THREADS 256
@@ -524,29 +525,37 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
 // The gather addresses are kept per row as a base pointer + validity bit and only recomputed when the tap or the
 // concat source changes (every C/64 K-steps); inside a tap the K-step offset is a scalar add.
 // =====================================================================================================================
-#define BM2 256
-#define GEMM2_THREADS 512
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// WMW = waves along M (the other 8 / WMW along N); NSTAGE = depth of the LDS-DMA ring.  Instances:
-//   <128, 4, 3>, <160, 4, 3>: wave tile 64 x BN/2, 3-stage ring (loads two K-steps ahead)
-//   <320, 2, 2>            : wave tile 128 x 80 (40 accumulator tiles): 28 % fewer LDS bytes per MFMA and 31 % less
-//                            L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
-//   <256, 2, 2>            : wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
-//   <320, 4, 2>            : wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
-template <int BN, int WMW, int NSTAGE, int MODE, typename T>
-__global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmParams P) {
+// BM2 x BN tile, NW waves of which WMW along M (the other NW / WMW along N); NSTAGE = depth of the LDS-DMA ring.
+// Instances <BM2, NW, BN, WMW, NSTAGE>:
+//   <256, 8, 128, 4, 3>, <256, 8, 160, 4, 3>: wave tile 64 x BN/2, 3-stage ring (loads two K-steps ahead)
+//   <256, 8, 320, 2, 2>: wave tile 128 x 80 (40 accumulator tiles): 28 % fewer LDS bytes per MFMA and 31 % less
+//                        L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
+//   <256, 8, 256, 2, 2>: wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
+//   <256, 8, 320, 4, 2>: wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
+//   <128, 4, 128, 2, 4>, <128, 4, 160, 2, 4>: the small-M levels (M = 4096 / 1024 rows: 128 x 160 tiles of
+//                        4096 x 1280 are exactly 256 blocks).  Wave tile 64 x BN/2 as above, but the block's K-step is
+//                        only 2.6 MFLOP, so the loads run THREE K-steps ahead (4-stage ring, 147 KB): with the 2-stage
+//                        ring of gemm_conv_kernel every K-step of these shapes waits out a full L2/HBM latency
+//                        (measured 32 us for 13.4 GFLOP whatever the tile).
+template <int BM2, int NW, int BN, int WMW, int NSTAGE, int MODE, typename T>
+__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int WNW = 8 / WMW;
+  constexpr int WNW = NW / WMW;
   constexpr int TM = BM2 / WMW / 16;    // 16-row MFMA tiles per wave along M
   constexpr int TN = BN / WNW / 16;     // 16-col MFMA tiles per wave along N
   constexpr bool DB = TM * TN <= 20;    // double-buffer the fragments in registers when the accumulators leave room
   constexpr int A_BYTES = BM2 * 128;
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NB_FULL = BN / 64;      // B staging instructions issued by every wave
-  constexpr bool B_TAIL = (BN % 64) != 0;  // one more instruction for waves 0..3 (rows 128..159 when BN = 160)
+  constexpr int NA = BM2 / (NW * 8);    // A staging instructions per wave (8 rows of 128 B each)
+  constexpr int NB_FULL = BN / (NW * 8);   // B staging instructions issued by every wave
+  constexpr bool B_TAIL = (BN % (NW * 8)) != 0;  // one more instruction for the first waves (rows 128..159 when BN = 160, NW = 8)
+  constexpr int TAIL_WAVES = (BN % (NW * 8)) / 8;
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  static_assert((NSTAGE - 1) * (NA + NB_FULL + 1) <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
@@ -564,11 +573,11 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   const int m0 = tile_m * BM2, n0 = tile_n * BN;
 
   const int HW = P.H * P.W;
-  int rb[4], ry[4], rx[4];
+  int rb[NA], ry[NA], rx[NA];
   const int slot = lane & 7;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 8 + w) * 8 + (lane >> 3);
+  for (int i = 0; i < NA; ++i) {
+    const int row = (i * NW + w) * 8 + (lane >> 3);
     const int m = m0 + row;
     if (m < P.M) {
       const int b = m / HW, rem = m - b * HW;
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   unsigned wvo[NB_FULL + 1];
 #pragma unroll
   for (int i = 0; i < NB_FULL + 1; ++i) {
-    const int row = (i * 8 + w) * 8 + (lane >> 3);
+    const int row = (i * NW + w) * 8 + (lane >> 3);
     const int n = n0 + row;
     const int chunk = slot ^ ((row >> 1) & 7);
     wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
@@ -608,11 +617,27 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
 
   // gather state: per-row byte offset of the current (tap, source) segment, recomputed only when the tap or the concat
   // source changes
-  unsigned avo[4] = {OOB, OOB, OOB, OOB};
+  unsigned avo[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) avo[i] = OOB;
   int seg_tap = -1, seg_src = -1;
-  auto stage = [&](int buf, int kt) {
-    char* As = smem + buf * STAGE;
-    char* Bs = As + A_BYTES;
+  // A K-step's staging is split in two: stage_prepare (wave-uniform control flow: new gather offsets when the tap or
+  // the concat source changes; the descriptor / scalar offsets of the step) and stage_issue (a straight line of
+  // NA + NB_FULL `buffer_load ... lds`), so that the main loop can spread the issue over the MFMAs of a half K-step:
+  // an LDS-DMA instruction costs its wave ~60 cycles of issue among MFMAs but 100-185 in a back-to-back burst next to
+  // the ds_reads (MI355X_MICROARCH.md, "LDS-DMA piece issue cost").
+  const __amdgpu_buffer_rsrc_t rsA1 = uniform_rsrc((const void*)P.p1, a1_bytes);
+  const __amdgpu_buffer_rsrc_t rsA2 = uniform_rsrc(P.p2 ? (const void*)P.p2 : (const void*)P.p1, a2_bytes);
+  // a stage past the end of this block's K range is issued all the same, through zero-length descriptors (every lane
+  // out of range: no memory traffic, zeros into an LDS buffer nobody reads any more) -- the number of LDS-DMA
+  // instructions in flight is then the same in every iteration and all vmcnt waits are constants
+  const __amdgpu_buffer_rsrc_t rsNull = uniform_rsrc((const void*)P.wt, 0);
+  __amdgpu_buffer_rsrc_t rsA = rsA1, rsB = rsW;
+  unsigned coff = 0, koff = 0;
+  auto stage_prepare = [&](int buf, int kt) {
+    if (kt >= nk) {
+      rsA = rsNull; rsB = rsNull;
+    } else {
     const int tap = kt / cpt, cc = kt - tap * cpt;
     const int srcsel = cc < cpt1 ? 0 : 1;
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform
@@ -621,8 +646,8 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
       if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
       const int cs = srcsel ? P.C2 : P.C1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (i * 8 + w) * 8 + (lane >> 3);
+      for (int i = 0; i < NA; ++i) {
+        const int row = (i * NW + w) * 8 + (lane >> 3);
         const int iy = ry[i] + dy, ix = rx[i] + dx;
         const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && !(((iy | ix) & 1) & P.zins);
         const int sy = iy >> P.up, sx = ix >> P.up;
@@ -630,19 +655,26 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
         avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
       }
     }
-    const unsigned coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
-    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(srcsel ? (const void*)P.p2 : (const void*)P.p1,
-                                                    srcsel ? a2_bytes : a1_bytes);
+    coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
+    rsA = srcsel ? rsA2 : rsA1;
+    rsB = rsW;
+    koff = (unsigned)(kt * 128);
+    }
+    if (B_TAIL && w < TAIL_WAVES)     // the odd weight rows (first waves only): issued here, ahead of the step's other loads
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * STAGE + A_BYTES + ((NB_FULL * NW + w) * 8) * 128), 16,
+                                               wvo[NB_FULL], koff, 0, 0);
+  };
+  auto stage_issue = [&](int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * 8 + w) * 8) * 128), 16, avo[i], coff, 0, 0);
-    const unsigned koff = (unsigned)(kt * 128);
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * NW + w) * 8) * 128), 16, avo[i], coff, 0, 0);
 #pragma unroll
     for (int i = 0; i < NB_FULL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * 8 + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
-    if (B_TAIL && w < 4)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((NB_FULL * 8 + w) * 8) * 128), 16, wvo[NB_FULL], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + ((i * NW + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
   };
+  auto stage = [&](int buf, int kt) { stage_prepare(buf, kt); stage_issue(buf); };
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -677,18 +709,14 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
       for (int i = 0; i < TM; ++i)
         acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
   };
-  // wait until all of this wave's LDS-DMA except the newest `inflight` stages has landed
-  auto wait_stages = [&](int inflight) {
-    if (B_TAIL && w < 4) {
-      if (inflight >= 2) wait_vmcnt<2 * (4 + NB_FULL + 1)>();
-      else if (inflight == 1) wait_vmcnt<4 + NB_FULL + 1>();
-      else wait_vmcnt<0>();
-    } else {
-      if (inflight >= 2) wait_vmcnt<2 * (4 + NB_FULL)>();
-      else if (inflight == 1) wait_vmcnt<4 + NB_FULL>();
-      else wait_vmcnt<0>();
-    }
+  // wait until all of this wave's LDS-DMA except the newest INFLIGHT stages has landed
+  auto wait_stages = [&](auto inflight) {
+    constexpr int F = decltype(inflight)::value;
+    constexpr int L0 = NA + NB_FULL, L1 = L0 + 1;   // LDS-DMA instructions per stage of a wave without / with the tail
+    if (B_TAIL && w < TAIL_WAVES) wait_vmcnt<F * L1>();
+    else wait_vmcnt<F * L0>();
   };
+  using std::integral_constant;
 
   const int nsteps = nk - k_begin;
   LR_STAMP(0);
@@ -696,53 +724,82 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
   float* rs = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
   float* par = rs + 2 * BM2;
   stage_params<BN, PAR_LD>(P, par, n0, w, lane);
+  // DB: the whole ring is filled up front and K-step `it` refills its own buffer (stage it + NSTAGE) from the middle of
+  // the step on; !DB: NSTAGE - 1 stages up front, stage it + NSTAGE - 1 goes out during the first half of K-step `it`
+  // (its buffer was released by the barrier that ended step it - 1).
+  constexpr int NPRO = DB ? NSTAGE : NSTAGE - 1;
 #pragma unroll
-  for (int sidx = 0; sidx < NSTAGE; ++sidx)
-    if (sidx < nsteps) stage(sidx, k_begin + sidx);
+  for (int sidx = 0; sidx < NPRO; ++sidx) stage(sidx, k_begin + sidx);
   LR_STAMP(1);
   vec8<T> xa[TM], wa[TN];
+  if constexpr (!DB) stage_prepare(NSTAGE - 1, k_begin + NSTAGE - 1);
   if (nsteps > 0) {
-    wait_stages(nsteps > NSTAGE - 1 ? NSTAGE - 1 : nsteps - 1);
+    wait_stages(integral_constant<int, NPRO - 1>{});
     __builtin_amdgcn_s_barrier();
     if constexpr (DB) read_frags(xa, wa, 0, 0);
   }
   LR_STAMP(2);
   int cur = 0;
+  // MFMAs of one half K-step with the prepared stage's LDS-DMA instructions spread between them
+  constexpr int NDMA = NA + NB_FULL;
+  constexpr int MFMA_PER = (TM * TN) / NDMA > 0 ? (TM * TN) / NDMA : 1;
+  auto mma_issue = [&](const vec8<T> (&xf)[TM], const vec8<T> (&wf)[TN], int buf) {
+    stage_issue(buf);
+    mma(xf, wf);
+#pragma unroll
+    for (int g = 0; g < NDMA; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x8, MFMA_PER, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    }
+  };
   if constexpr (DB) {
     vec8<T> xb[TM], wb[TN];
-    for (int it = 0; it < nsteps; ++it) {
+    for (int it = 0; it + 1 < nsteps; ++it) {
       const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
       // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]
       read_frags(xb, wb, cur, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(xa, wa);
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 1 < nsteps) {
-        wait_stages(nsteps - it - 2 < NSTAGE - 2 ? nsteps - it - 2 : NSTAGE - 2);   // stage it+1 landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage `it` are in registers
-        __builtin_amdgcn_s_barrier();
-        if (it + NSTAGE < nsteps) stage(cur, k_begin + it + NSTAGE);  // refill the buffer every wave has finished with
-        read_frags(xa, wa, nxt, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mma(xb, wb);
+      wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage `it` are in registers
+      __builtin_amdgcn_s_barrier();
+      stage_prepare(cur, k_begin + it + NSTAGE);           // refill the buffer every wave has finished with ...
+      read_frags(xa, wa, nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_issue(xb, wb, cur);                              // ... between the MFMAs of the second half
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
+    if (nsteps > 0) {
+      read_frags(xb, wb, cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xb, wb);
+    }
   } else {
-    for (int it = 0; it < nsteps; ++it) {
+    int pbuf = NSTAGE - 1;      // buffer of the prepared, not yet issued stage
+    for (int it = 0; it + 1 < nsteps; ++it) {
       const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
+      read_frags(xa, wa, cur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_issue(xa, wa, pbuf);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(xa, wa, cur, 1);
+      mma(xa, wa);
+      wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage_prepare(cur, k_begin + it + NSTAGE);
+      pbuf = cur;
+      cur = nxt;
+    }
+    if (nsteps > 0) {
       read_frags(xa, wa, cur, 0);
       mma(xa, wa);
       read_frags(xa, wa, cur, 1);
       mma(xa, wa);
-      if (it + 1 < nsteps) {
-        wait_stages(nsteps - it - 2 < NSTAGE - 2 ? nsteps - it - 2 : NSTAGE - 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (it + NSTAGE < nsteps) stage(cur, k_begin + it + NSTAGE);
-      }
-      cur = nxt;
     }
   }
   // ---- epilogue straight from the accumulators (see epilogue_units)
@@ -762,8 +819,8 @@ __global__ __launch_bounds__(GEMM2_THREADS) void gemm_conv256_kernel(const GemmP
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BN, int WMW, int NSTAGE, int MODE, typename T>
-static int launch_gemm256_t(const GemmParams& P0, hipStream_t st) {
+template <int BM2, int NW, int BN, int WMW, int NSTAGE, int MODE, typename T>
+static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
   P.ntiles_n = (P.N + BN - 1) / BN;
   const int ntm = (P.M + BM2 - 1) / BM2;
@@ -774,11 +831,11 @@ static int launch_gemm256_t(const GemmParams& P0, hipStream_t st) {
   const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv256_kernel<BN, WMW, NSTAGE, MODE, T>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_conv256_kernel<BN, WMW, NSTAGE, MODE, T>), dim3(P.nblocks, P.splits), dim3(GEMM2_THREADS), smem, st, P);
+  hipLaunchKernelGGL((gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(P.nblocks, P.splits), dim3(NW * 64), smem, st, P);
   return lr_launch_status();
 }
 
@@ -843,11 +900,13 @@ static int launch_gemm_t(const GemmParams& P0, hipStream_t st) {
 }
 
 // dtype dispatch (fp16 | bf16; the erf-GELU mode of the text tower is fp16 only)
-template <int BN, int WMW, int NSTAGE, int MODE>
-static int launch_gemm256(const GemmParams& P, hipStream_t st) {
-  if constexpr (MODE != 2) { if (P.bf16) return launch_gemm256_t<BN, WMW, NSTAGE, MODE, bf16>(P, st); }
-  return launch_gemm256_t<BN, WMW, NSTAGE, MODE, f16>(P, st);
+template <int BM2, int NW, int BN, int WMW, int NSTAGE, int MODE>
+static int launch_pipe(const GemmParams& P, hipStream_t st) {
+  if constexpr (MODE != 2) { if (P.bf16) return launch_pipe_t<BM2, NW, BN, WMW, NSTAGE, MODE, bf16>(P, st); }
+  return launch_pipe_t<BM2, NW, BN, WMW, NSTAGE, MODE, f16>(P, st);
 }
+template <int BN, int WMW, int NSTAGE, int MODE>
+static int launch_gemm256(const GemmParams& P, hipStream_t st) { return launch_pipe<256, 8, BN, WMW, NSTAGE, MODE>(P, st); }
 template <int BN, int MODE>
 static int launch_gemm(const GemmParams& P, hipStream_t st) {
   if constexpr (MODE != 2) { if (P.bf16) return launch_gemm_t<BN, MODE, bf16>(P, st); }
@@ -881,16 +940,23 @@ static void choose_tile(int M, int N, int geglu, int* tm, int* tn) {
   }
 }
 
-static int choose_splits(int M, int N, int K, int tm, int tn, int geglu) {
+static int choose_splits(int M, int N, int K, int tm, int tn, int geglu, int stages) {
   if (geglu) return 1;
   const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
   const int nk = K / BK;
-  const int slots = tm == 256 ? 256 : 512;   // resident blocks on the chip
+  const int slots = (tm == 256 || stages == 4) ? 256 : 512;   // resident blocks on the chip
   if (tiles * 10 > slots * 6 || nk < 32) return 1;   // > 60 % of the resident slots filled: do not split
   int s = (slots + tiles / 2) / tiles;               // round to the nearest whole number of waves
   if (s > 8) s = 8;
   if (s > nk / 8) s = nk / 8;
   return s < 1 ? 1 : s;
+}
+
+// ring depth of the instance that serves tile (tm, tn): 128-row tiles come as the 2-stage 4-wave kernel (several blocks
+// per CU cover each other's waits) and, for tn = 128 | 160, as the 4-stage one (one block per CU, loads three K-steps ahead)
+static int choose_stages(int tm, int tn, int stages) {
+  if (tm == 128) return (stages == 4 && (tn == 128 || tn == 160)) ? 4 : 2;
+  return (tn == 128 || tn == 160) ? 3 : 2;
 }
 
 // waves along N of the instance that serves tile (tm, tn): each writes one (sum, sumsq) partial per row
@@ -908,7 +974,8 @@ extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
   plan[0] = tm; plan[1] = tn;
-  plan[2] = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1);
+  plan[2] = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
+  plan[3] = choose_stages(tm, tn, a->stages);
   return 0;
 }
 
@@ -940,7 +1007,7 @@ extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
-  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1);
+  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
   return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
@@ -985,7 +1052,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(P.M, P.N, P.geglu || P.gelu, &tm, &tn);
   int splits = a->splits;
-  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu);
+  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu, a->stages);
   if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
   if (splits > 1) {
     const int64_t need = (int64_t)splits * P.M * P.N * (int64_t)sizeof(float);
@@ -1017,8 +1084,12 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   hipStream_t st = (hipStream_t)s;
   int rc;
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
+  if (a->stages != 0 && a->stages != choose_stages(tm, tn, a->stages)) return LR_E_UNSUPPORTED;
+  const bool deep = tm == 128 && choose_stages(tm, tn, a->stages) == 4;
   if (mode == 0) {
-    if (tm == 128 && tn == 128) rc = launch_gemm<128, 0>(P, st);
+    if (deep && tn == 128) rc = launch_pipe<128, 4, 128, 2, 4, 0>(P, st);
+    else if (deep && tn == 160) rc = launch_pipe<128, 4, 160, 2, 4, 0>(P, st);
+    else if (tm == 128 && tn == 128) rc = launch_gemm<128, 0>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 0>(P, st);
     else if (tm == 128 && tn == 160) rc = launch_gemm<160, 0>(P, st);
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 0>(P, st);
@@ -1027,13 +1098,15 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     else if (tm == 256 && tn == 320) rc = launch_gemm256<320, 2, 2, 0>(P, st);                 // wave tile 128 x 80
     else return LR_E_UNSUPPORTED;
   } else if (mode == 1) {
-    if (tm == 128 && tn == 128) rc = launch_gemm<128, 1>(P, st);
+    if (deep && tn == 128) rc = launch_pipe<128, 4, 128, 2, 4, 1>(P, st);
+    else if (tm == 128 && tn == 128) rc = launch_gemm<128, 1>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 1>(P, st);
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 1>(P, st);
     else if (tm == 256 && tn == 256) rc = launch_gemm256<256, 2, 2, 1>(P, st);
     else if (tm == 256 && tn == 320) rc = launch_gemm256<320, 4, 2, 1>(P, st);                 // wave tile 64 x 160: even TN
     else return LR_E_UNSUPPORTED;
   } else {   // erf-GELU epilogue (text tower MLP): the small-tile instances only
+    if (deep) return LR_E_UNSUPPORTED;
     if (tm == 128 && tn == 128) rc = launch_gemm<128, 2>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 2>(P, st);
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 2>(P, st);

@@ -22,7 +22,9 @@ GN_CHUNKS = 256
 # LEFTREFILL_AUTOTUNE=1 is a developer mode: unknown shapes are timed on first sight and added to the in-memory table
 # (dump it with tile_cache()); it is never on by default.
 AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "0") == "1"
-TILE_CANDIDATES = ((128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320))
+# (tile_m, tile_n, stages): stages 0 = the tile's default LDS ring depth, 4 = the deep one-block-per-CU 128-row instance
+TILE_CANDIDATES = ((128, 64, 0), (128, 128, 0), (128, 160, 0), (128, 128, 4), (128, 160, 4), (256, 128, 0), (256, 160, 0),
+                   (256, 256, 0), (256, 320, 0))
 TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
 _tile_cache = None
 
@@ -163,8 +165,8 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, ln=None, want_stats=False,
-              want_gn_stats=False):
+              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, stages=0, ln=None,
+              want_stats=False, want_gn_stats=False):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
 
     ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
@@ -207,6 +209,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.tile_n = tile_n
     a.tile_m = tile_m
     a.splits = splits
+    a.stages = stages
     a.workspace, a.workspace_bytes = 0, 0
     a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
@@ -224,7 +227,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)
             tile_cache()[key] = best
         if best is not None:
-            a.tile_m, a.tile_n, a.splits = best
+            a.tile_m, a.tile_n, a.splits = best[:3]
+            a.stages = best[3] if len(best) > 3 else 0
     stats = None
     if want_stats:
         if a.splits == 0:
@@ -236,7 +240,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         a.splits = 1
     gstats = None
     if want_gn_stats:
-        plan = (ctypes.c_int32 * 3)()
+        plan = (ctypes.c_int32 * 4)()
         lib.lr_gemm_plan(a, plan)
         rows = lib.lr_gemm_gn_rows(a)
         if plan[2] == 1 and (H * W) % rows == 0:     # whole K in one block; row blocks never straddle two samples
@@ -251,17 +255,17 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
 
 
 def gemm_plan(M, N, K, **kw):
-    """(tile_m, tile_n, splits) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
+    """(tile_m, tile_n, splits, stages) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
     best = tile_cache().get(tile_key(M, N, K, **kw))
     if best is not None:
-        return tuple(best)
+        return tuple(best) if len(best) > 3 else tuple(best) + (0,)
     lib = _lib.load()
     a = GemmArgs()
     a.B, a.H, a.W, a.N, a.taps, a.C1 = 1, 1, M, N, kw.get("taps", 1), K // kw.get("taps", 1)
     a.geglu = int(kw.get("geglu", False))
-    plan = (ctypes.c_int32 * 3)()
+    plan = (ctypes.c_int32 * 4)()
     _lib.check(lib.lr_gemm_plan(a, plan), "gemm_plan")
-    return tuple(plan)
+    return tuple(plan)[:3] + (0,)
 
 
 def _workspace(lib, a, device):
@@ -292,11 +296,11 @@ def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
     """Developer mode: time every (tile, split-K) configuration and return the fastest (tile_m, tile_n, splits)."""
     st = _stream()
     best, best_t = None, float("inf")
-    plan = (ctypes.c_int32 * 3)()
-    for tm, tn in TILE_CANDIDATES:
+    plan = (ctypes.c_int32 * 4)()
+    for tm, tn, stg in TILE_CANDIDATES:
         if geglu and tn == 160:
             continue
-        a.tile_m, a.tile_n, a.splits = tm, tn, 0
+        a.tile_m, a.tile_n, a.splits, a.stages = tm, tn, 0, stg
         lib.lr_gemm_plan(a, plan)
         cands = {1} if no_split else {1, int(plan[2])}
         for sp in sorted(cands):
@@ -314,7 +318,7 @@ def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
             t = _time_launch(lib, a, st, reps, rounds)
             del ws, stats
             if t < best_t:
-                best, best_t = (tm, tn, sp), t
+                best, best_t = (tm, tn, sp, stg), t
     a.stats_out = 0
     return best
 

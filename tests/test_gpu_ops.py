@@ -281,17 +281,23 @@ def test_conv_golden_cases(golden):
         report("golden " + name, from_tok(y, N, H, W), torch.from_numpy(g[name]), rtol=4e-3, atol=4e-3)
 
 
-ALL_TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)]
+# (tile_m, tile_n[, stages]): every GEMM instance; stages 4 = the deep-ring 128-row kernel
+ALL_TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320), (128, 128, 4), (128, 160, 4)]
 
 
-@pytest.mark.parametrize("tm,tn", ALL_TILES)
-def test_gemm_row_stats_and_layernorm_fold(tm, tn):
+def tile_kw(t):
+    return dict(tile_m=t[0], tile_n=t[1], stages=t[2] if len(t) > 2 else 0)
+
+
+@pytest.mark.parametrize("tile", ALL_TILES, ids=lambda t_: "x".join(map(str, t_)))
+def test_gemm_row_stats_and_layernorm_fold(tile):
     """LayerNorm folded into the consumer GEMM (lr_gemm_args.ln_stats): the producer's epilogue writes per-row
     (sum, sumsq) partials of its fp16 output, the consumer normalises inside its own epilogue.  Checked against
     F.linear(F.layer_norm(x)) in fp32 on the same fp16-rounded x (attention.py:271-283 semantics), every tile."""
     from leftrefill_amd import ops, packing
     d = dev()
     for C, N2, M in ((320, 960, 700), (640, 640, 300), (1280, 320, 130)):
+        tm, tn = tile[:2]
         name = f"lnf{C}_{tm}x{tn}"
         a = h16(G.T(name + ".a", (M, C)))
         w0 = h16(torch.from_numpy(weights.fill_like(name + ".w0", (C, C))))
@@ -299,7 +305,7 @@ def test_gemm_row_stats_and_layernorm_fold(tm, tn):
         r0 = h16(G.T(name + ".r0", (M, C)) * 3.0 + 0.7)          # non-zero mean rows
         x_ref = (F.linear(a, w0, b0) + r0).half()                 # what the producer stores
         x, st = ops.gemm_conv(a.half().to(d), w0.half().to(d), B=1, H=1, W=M, taps=1, bias=b0.to(d), resid=r0.half().to(d),
-                              tile_m=tm, tile_n=tn, want_stats=True)
+                              want_stats=True, **tile_kw(tile))
         report(name + " producer", x, x_ref.float())
         xs = x.float()
         s = st.sum(dim=1)
@@ -313,14 +319,16 @@ def test_gemm_row_stats_and_layernorm_fold(tm, tn):
         xc = x.float().cpu()
         ref = F.linear(F.layer_norm(xc, (C,), gam, bet, 1e-5), w1, b1)
         wf, bf, cs = packing.fold_layernorm(w1, b1, gam, bet)
-        y = ops.gemm_conv(x, wf.to(d), B=1, H=1, W=M, taps=1, bias=bf.to(d), ln=(st, 1e-5, cs.to(d)), tile_m=tm, tile_n=tn)
+        y = ops.gemm_conv(x, wf.to(d), B=1, H=1, W=M, taps=1, bias=bf.to(d), ln=(st, 1e-5, cs.to(d)), **tile_kw(tile))
         # two fp16 roundings differ from the reference pipeline (gamma folded into W; no rounded LayerNorm output)
         report(name + " consumer", y, ref, rtol=4e-3, atol=4e-3)
 
 
-@pytest.mark.parametrize("tm,tn", [(128, 64), (128, 128), (256, 128), (256, 256), (256, 320)])
-def test_geglu_layernorm_fold(tm, tn):
+@pytest.mark.parametrize("tile", [(128, 64), (128, 128), (256, 128), (256, 256), (256, 320), (128, 128, 4)],
+                         ids=lambda t_: "x".join(map(str, t_)))
+def test_geglu_layernorm_fold(tile):
     from leftrefill_amd import ops, packing
+    tm, tn = tile[:2]
     d = dev()
     C, M = 320, 520
     name = f"lng_{tm}x{tn}"
@@ -335,25 +343,26 @@ def test_geglu_layernorm_fold(tm, tn):
     wf, bf, cs = packing.fold_layernorm(w, b, gam, bet)
     perm = packing.geglu_perm(4 * C)
     y = ops.gemm_conv(x.half().to(d), wf[perm].contiguous().to(d), B=1, H=1, W=M, taps=1, bias=bf[perm].contiguous().to(d),
-                      geglu=True, ln=(st, 1e-5, cs[perm].contiguous().to(d)), tile_m=tm, tile_n=tn)
+                      geglu=True, ln=(st, 1e-5, cs[perm].contiguous().to(d)), **tile_kw(tile))
     report(name, y, ref, rtol=4e-3, atol=4e-3)
 
 
-@pytest.mark.parametrize("tm,tn", ALL_TILES)
-def test_groupnorm_statistics_from_gemm_epilogue(tm, tn):
+@pytest.mark.parametrize("tile", ALL_TILES, ids=lambda t_: "x".join(map(str, t_)))
+def test_groupnorm_statistics_from_gemm_epilogue(tile):
     """GroupNorm whose statistics come out of the producing GEMMs' epilogues (lr_gemm_args.gn_stats_out +
     lr_groupnorm_finalize) instead of a pass over x: per-channel block sums match the stored tensor, and the normalised
     output matches F.group_norm on the virtual concat of two producers with different block sizes (openaimodel.py:781)."""
     from leftrefill_amd import ops, packing
     d = dev()
     N, H, W = 2, 8, 16                      # HW = 128 rows per sample (the 8 x 16 level)
+    tm, tn = tile[:2]
     name = f"gnf_{tm}x{tn}"
     outs = []
     for k, (Cin, Cout, taps) in enumerate(((320, 320, 9), (128, 640, 1))):
         x = h16(G.T(f"{name}.x{k}", (N, Cin, H, W)) * 1.5 + 0.4)
         w = h16(torch.from_numpy(weights.fill_like(f"{name}.w{k}", (Cout, Cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1))))
         b = torch.from_numpy(weights.fill_like(f"{name}.b{k}", (Cout,))) + 0.3
-        kw = dict(tile_m=tm, tile_n=tn, splits=1) if k == 0 else dict(tile_m=128, tile_n=64, splits=1)
+        kw = dict(splits=1, **tile_kw(tile)) if k == 0 else dict(tile_m=128, tile_n=64, splits=1)
         y, gs = ops.gemm_conv(to_tok(x), packing.pack_conv(w, cin_pad=Cin).to(d), B=N, H=H, W=W, taps=taps,
                               bias=packing.pack_bias(b).to(d), want_gn_stats=True, **kw)
         assert gs is not None
@@ -385,9 +394,9 @@ def test_tile_plan_is_static_and_tiles_agree_bitwise():
     x = h16(G.T("tp.x", (300, 2560))).half().to(d)
     w = h16(torch.from_numpy(weights.fill_like("tp.w", (640, 2560)))).half().to(d)
     for splits in (1, 4):
-        ys = [ops.gemm_conv(x, w, B=1, H=1, W=300, taps=1, tile_m=tm, tile_n=tn, splits=splits) for tm, tn in ALL_TILES]
-        for (tm, tn), y in zip(ALL_TILES[1:], ys[1:]):
-            assert torch.equal(y, ys[0]), f"tile {tm}x{tn} differs bitwise from {ALL_TILES[0]} at splits={splits}"
+        ys = [ops.gemm_conv(x, w, B=1, H=1, W=300, taps=1, splits=splits, **tile_kw(t_)) for t_ in ALL_TILES]
+        for t_, y in zip(ALL_TILES[1:], ys[1:]):
+            assert torch.equal(y, ys[0]), f"tile {t_} differs bitwise from {ALL_TILES[0]} at splits={splits}"
 
 
 def test_geglu_epilogue():
@@ -607,7 +616,8 @@ def test_gemm_conv_randomised_shapes():
     from leftrefill_amd import ops, packing
     rng = random.Random(1234)
     d = dev()
-    tiles = [(0, 0), (128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)]
+    tiles = [(0, 0, 0), (128, 64, 0), (128, 128, 0), (128, 160, 0), (256, 128, 0), (256, 160, 0), (256, 256, 0), (256, 320, 0),
+             (128, 128, 4), (128, 160, 4)]
     n_checked = 0
     for case in range(60):
         taps = rng.choice([1, 9, 9])
@@ -623,7 +633,7 @@ def test_gemm_conv_randomised_shapes():
         elif mode == "up":
             H, W = 2 * rng.randint(1, 6), 2 * rng.randint(1, 7)
             Hs, Ws, up = H // 2, W // 2, 1
-        tm, tn = rng.choice(tiles)
+        tm, tn, stg = rng.choice(tiles)
         splits = rng.choice([0, 0, 1, 2, 3])
         use_bias, use_rv, use_res = rng.random() < 0.8, rng.random() < 0.3, rng.random() < 0.5
         name = f"fz{case}"
@@ -649,7 +659,7 @@ def test_gemm_conv_randomised_shapes():
             y = ops.gemm_conv(to_tok(x[:, :C1]), wp, B=B, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym,
                               x2=to_tok(x[:, C1:]) if C2 else None, bias=b.to(d) if use_bias else None,
                               rowvec=rv.half().to(d) if use_rv else None, resid=to_tok(rs) if use_res else None,
-                              tile_m=tm, tile_n=tn, splits=splits)
+                              tile_m=tm, tile_n=tn, splits=splits, stages=stg)
         except RuntimeError as e:        # an explicit split request that the shape cannot honour is an argument error
             assert splits > 1 and "gemm_conv" in str(e), (case, str(e))
             continue

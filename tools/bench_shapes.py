@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leftrefill_amd import ops  # noqa: E402
 
-TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)]
+TILES = list(ops.TILE_CANDIDATES)     # (tile_m, tile_n, stages)
 # name, M, N, K, taps, flags
 SHAPES = [
     ("l0 KC resid+stats", 65536, 320, 320, 1, dict(resid=1, stats=1)),
@@ -64,8 +64,8 @@ def make_case(M, N, K, taps, fl, dev, nsets):
     cs = w.float().sum(1).contiguous()
     rv = torch.randn(B, N, device=dev).half() if fl.get("rowvec") else None
 
-    def launch(d, tm, tn, sp):
-        return ops.gemm_conv(d["x"], w, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp,
+    def launch(d, tm, tn, sp, stg=0):
+        return ops.gemm_conv(d["x"], w, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp, stages=stg,
                              geglu=bool(fl.get("geglu")), resid=d.get("resid"), rowvec=rv,
                              ln=(d["st"], 1e-5, cs) if fl.get("ln") else None, want_stats=bool(fl.get("stats")))
     return sets, launch
@@ -99,28 +99,28 @@ def main():
             plans = [ops.gemm_plan(M, N, K, taps=taps, geglu=bool(fl.get("geglu")), ln=bool(fl.get("ln")),
                                    stats=bool(fl.get("stats")))]
         else:
-            plans = [(tm, tn, 0) for tm, tn in TILES]
+            plans = [(tm, tn, 0, stg) for tm, tn, stg in TILES]
         res = []
-        for tm, tn, sp in plans:
+        for tm, tn, sp, stg in plans:
             if fl.get("geglu") and tn == 160:
                 continue
             if (fl.get("ln") or fl.get("stats")) and sp == 0:
                 sp = 1
             try:
-                launch(sets[0], tm, tn, sp)
+                launch(sets[0], tm, tn, sp, stg)
                 torch.cuda.synchronize()
             except RuntimeError as e:
-                res.append((tm, tn, None, None, str(e)[:40]))
+                res.append((f'{tm}x{tn}' + ('d' if stg else ''), tn, None, None, str(e)[:40]))
                 continue
-            cold = min(time_seq(lambda i: launch(sets[i % nsets], tm, tn, sp), nsets * 2) for _ in range(2))
-            hot = min(time_seq(lambda i: launch(sets[0], tm, tn, sp), a.reps) for _ in range(2))
-            res.append((tm, tn, cold, hot, ""))
+            cold = min(time_seq(lambda i: launch(sets[i % nsets], tm, tn, sp, stg), nsets * 2) for _ in range(2))
+            hot = min(time_seq(lambda i: launch(sets[0], tm, tn, sp, stg), a.reps) for _ in range(2))
+            res.append((f'{tm}x{tn}' + ('d' if stg else ''), tn, cold, hot, ""))
         fl_ = 2.0 * M * N * K
         ok = [r for r in res if r[2] is not None]
         best = min(ok, key=lambda r: r[2]) if ok else None
-        line = "  ".join(f"{tm}x{tn}:{c:6.1f}/{h:6.1f}" if c is not None else f"{tm}x{tn}:  err" for tm, tn, c, h, _ in res)
+        line = "  ".join(f"{tm}:{c:6.1f}/{h:6.1f}" if c is not None else f"{tm}:  err" for tm, tn, c, h, _ in res)
         if best:
-            print(f"{name:24s} M={M:6d} N={N:5d} K={K:5d} best {best[0]}x{best[1]} {best[2]:7.1f} us cold "
+            print(f"{name:24s} M={M:6d} N={N:5d} K={K:5d} best {best[0]} {best[2]:7.1f} us cold "
                   f"({fl_ / best[2] / 1e6:6.0f} TF)  | {line}", flush=True)
         del sets, launch
         torch.cuda.empty_cache()

@@ -40,22 +40,26 @@ def main():
     lib.lr_gemm_set_trace.argtypes = [ctypes.c_void_p]
     lib.lr_gemm_set_trace.restype = None
     dev = torch.device("cuda:0")
-    only = sys.argv[1:] or ["l0 KC", "l0 qkv", "l0 geglu", "l0 conv3x3 resid"]
+    tiles = [(256, 320, 0), (256, 160, 0), (256, 256, 0)]
+    argv = sys.argv[1:]
+    if argv and argv[0].startswith("--tiles="):      # e.g. --tiles=128x160x4,256x128
+        tiles = [tuple((list(map(int, t_.split("x"))) + [0])[:3]) for t_ in argv.pop(0)[8:].split(",")]
+    only = argv or ["l0 KC", "l0 qkv", "l0 geglu", "l0 conv3x3 resid"]
     for name, M, N, K, taps, fl in bs.SHAPES:
         if not any(o in name for o in only):
             continue
         sets, launch = bs.make_case(M, N, K, taps, fl, dev, 6)
-        for tm, tn in ((256, 320), (256, 160), (256, 256)):
+        for tm, tn, stg in tiles:
             if fl.get("geglu") and tn == 160:
                 continue
             trace = torch.zeros(8192 * 8, device=dev, dtype=torch.int64)
             for i in range(4):
-                launch(sets[i], tm, tn, 1)       # warm
+                launch(sets[i], tm, tn, 1, stg)       # warm
             torch.cuda.synchronize()
             lib.lr_gemm_set_trace(trace.data_ptr())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(sets[4], tm, tn, 1)
+            launch(sets[4], tm, tn, 1, stg)
             e1.record()
             torch.cuda.synchronize()
             lib.lr_gemm_set_trace(None)
@@ -67,7 +71,7 @@ def main():
             span = (tr[:, 6].max() - t0).item()
             start_spread = (tr[:, 0].max() - t0).item()
             end = (tr[:, 6] - t0)
-            print(f"{name:24s} tile {tm}x{tn} blocks {nb:5d} kernel {1e3 * e0.elapsed_time(e1):7.1f} us | cycles: span {span:9.0f} "
+            print(f"{name:24s} tile {tm}x{tn}/{stg} blocks {nb:5d} kernel {1e3 * e0.elapsed_time(e1):7.1f} us | cycles: span {span:9.0f} "
                   f"start-spread {start_spread:8.0f} | issue {ph[0]:7.0f} first-land {ph[1]:7.0f} loop {ph[2]:7.0f} ln {ph[3]:6.0f} "
                   f"epi-issue {ph[4]:7.0f} drain {ph[5]:7.0f} | block end min/mean/max {end.min().item():8.0f} {end.mean().item():8.0f} {end.max().item():8.0f}",
                   flush=True)
