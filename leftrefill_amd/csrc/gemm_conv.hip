@@ -29,6 +29,7 @@ struct GemmParams {
   int ntiles_n, nblocks;
   int splits; float* ws;   // split-K: blockIdx.y = K slice, fp32 partial tiles -> ws[split][M][N]
   int ntiles_m, m_fastest; // tile order inside an XCD's contiguous chunk (see tile_order())
+  unsigned hw_mul, hw_sh, w_mul, w_sh;   // magic numbers of the unsigned divisions by H*W and by W (see lr_udiv)
   // LayerNorm folded into this GEMM (A = raw x, Wt = W * gamma): out = rstd[m] * (acc - mean[m] * ln_cs[n]) + bias'[n];
   // (mean, rstd) of row m come from the producer's per-row partial (sum, sumsq): ln_part[m][ln_parts][2]
   const float* ln_part; const float* ln_cs; int ln_parts; float ln_eps, ln_invc;
@@ -44,7 +45,7 @@ struct GemmParams {
 };
 
 #ifdef LR_GEMM_TRACE
-#define LR_STAMP(k) do { if (P.trace && threadIdx.x == 0) P.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define LR_STAMP(k) do { if (P.trace && threadIdx.x == 0) P.trace[(size_t)(blockIdx.y * P.nblocks + lr_trace_tile) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 static unsigned long long* g_trace = nullptr;
 extern "C" void lr_gemm_set_trace(void* p) { g_trace = (unsigned long long*)p; }
 #else
@@ -363,6 +364,19 @@ __device__ __forceinline__ void ln_rows_to_lds(const GemmParams& P, float* rs, c
   }
 }
 
+// n / d for any 32-bit n with a host-made (mul, sh) pair (Granlund-Montgomery round-up method): 4 VALU ops instead of
+// the ~40-instruction expansion of a runtime integer division
+__device__ __forceinline__ unsigned lr_udiv(unsigned n, unsigned mul, unsigned sh) {
+  const unsigned t = __umulhi(n, mul);
+  return (t + ((n - t) >> (sh ? 1 : 0))) >> (sh ? sh - 1 : 0);
+}
+static void lr_udiv_magic(unsigned d, unsigned* mul, unsigned* sh) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                       // ceil(log2 d)
+  *mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  *sh = l;                                           // d == 1: l = 0, mul = 1 -> t = 0, q = n
+}
+
 // 2nd launch-bounds argument = waves per SIMD the register allocation must leave room for (= resident blocks per CU here)
 template <int BN, int MODE, typename T>
 __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) void gemm_conv_kernel(const GemmParams P) {
@@ -398,8 +412,8 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
     const int row = (i * 4 + w) * 8 + (lane >> 3);
     const int m = m0 + row;
     if (m < P.M) {
-      const int b = m / HW, rem = m - b * HW;
-      const int y = rem / P.W, x = rem - y * P.W;
+      const int b = (int)lr_udiv((unsigned)m, P.hw_mul, P.hw_sh), rem = m - b * HW;
+      const int y = (int)lr_udiv((unsigned)rem, P.w_mul, P.w_sh), x = rem - y * P.W;
       rb[i] = b * P.Hs * P.Ws;
       ry[i] = y * P.stride;
       rx[i] = x * P.stride;
@@ -563,32 +577,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w / WNW, wn = w % WNW;
 
-  int bid = blockIdx.x;
-  {
-    const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tile_m, tile_n;
-  tile_order(P, bid, tile_m, tile_n);
-  const int m0 = tile_m * BM2, n0 = tile_n * BN;
+  // XCD-aware bijective remap: hardware block b lives on XCD b & 7; XCD x owns the contiguous logical tiles
+  // [t_begin, t_begin + t_cnt) (shared A rows / halos stay in its L2).
+  // (A persistent variant -- min(tiles, CUs) blocks walking the tiles and prefetching the next tile's first stages under
+  // the epilogue -- was built and measured in round 2: slower on every shape, e.g. the level-0 GEGLU projection 220 vs
+  // 184 us; the next tile's gather state has to stay live across an epilogue that already sits at the 256-VGPR limit.)
+  const int xcd = blockIdx.x & 7;
+  const int q8 = P.nblocks >> 3, r8 = P.nblocks & 7;
+  const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int tl = blockIdx.x >> 3;       // this block's tile, local to the XCD's range
+  [[maybe_unused]] int lr_trace_tile = 0;
 
   const int HW = P.H * P.W;
-  int rb[NA], ry[NA], rx[NA];
   const int slot = lane & 7;
+  const unsigned OOB = 0x80000000u;
+  int tile_m = 0, tile_n = 0, m0 = 0, n0 = 0;
+  unsigned wvo[NB_FULL + 1];      // weight rows (fixed over K): instr i covers rows (i*NW + w)*8 + lane/8
+  // gather state: per-row byte offset of the current (tap, source) segment, recomputed only when the tap or the concat
+  // source changes
+  unsigned avo[NA];
+  int seg_tap = -1, seg_src = -1;
+  // descriptors of the current A segment and of the weights (zero-length for a stage past the end of K); rebuilt from
+  // the kernel arguments when the segment / tile changes instead of holding 4 SGPRs per operand
+  __amdgpu_buffer_rsrc_t rsA = uniform_rsrc((const void*)P.wt, 0), rsB = rsA;
+  auto setup_tile = [&](int tloc) __attribute__((always_inline)) {
+    tile_order(P, t_begin + tloc, tile_m, tile_n);
+    lr_trace_tile = t_begin + tloc;
+    m0 = tile_m * BM2; n0 = tile_n * BN;
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int row = (i * NW + w) * 8 + (lane >> 3);
-    const int m = m0 + row;
-    if (m < P.M) {
-      const int b = m / HW, rem = m - b * HW;
-      const int y = rem / P.W, x = rem - y * P.W;
-      rb[i] = b * P.Hs * P.Ws;
-      ry[i] = y * P.stride;
-      rx[i] = x * P.stride;
-    } else {
-      rb[i] = 0; ry[i] = -(1 << 20); rx[i] = -(1 << 20);
+    for (int i = 0; i < NA; ++i) avo[i] = OOB;
+#pragma unroll
+    for (int i = 0; i < NB_FULL + 1; ++i) {
+      const int row = (i * NW + w) * 8 + (lane >> 3);
+      const int n = n0 + row;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
     }
-  }
+    seg_tap = -1; seg_src = -1;
+    rsB = uniform_rsrc(P.wt, (size_t)P.N * P.K * 2);
+  };
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
   const int cpt = (P.C1 + P.C2) >> 6;
   const int cpt1 = P.C1 >> 6;
@@ -600,43 +627,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
   // LDS-DMA through buffer descriptors: address = SRD base + per-lane voffset (VGPR, fixed within a tap) + soffset
   // (SGPR, the K-step's channel offset).  A K-step therefore issues its 6-7 `buffer_load_dwordx4 ... lds` with NO
   // per-lane address arithmetic, and padding / tails need no zero page: an out-of-range voffset reads as 0.
-  const unsigned OOB = 0x80000000u;
   const size_t a1_bytes = (size_t)P.Hs * P.Ws * P.C1 * 2 * (P.M / HW);
   const size_t a2_bytes = P.p2 ? (size_t)P.Hs * P.Ws * P.C2 * 2 * (P.M / HW) : 0;
-  const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.wt, (size_t)P.N * P.K * 2);
-
-  // weight rows (fixed over K): instr i covers rows (i*8 + w)*8 + lane/8
-  unsigned wvo[NB_FULL + 1];
-#pragma unroll
-  for (int i = 0; i < NB_FULL + 1; ++i) {
-    const int row = (i * NW + w) * 8 + (lane >> 3);
-    const int n = n0 + row;
-    const int chunk = slot ^ ((row >> 1) & 7);
-    wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
-  }
-
-  // gather state: per-row byte offset of the current (tap, source) segment, recomputed only when the tap or the concat
-  // source changes
-  unsigned avo[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) avo[i] = OOB;
-  int seg_tap = -1, seg_src = -1;
+  setup_tile(tl);
   // A K-step's staging is split in two: stage_prepare (wave-uniform control flow: new gather offsets when the tap or
   // the concat source changes; the descriptor / scalar offsets of the step) and stage_issue (a straight line of
   // NA + NB_FULL `buffer_load ... lds`), so that the main loop can spread the issue over the MFMAs of a half K-step:
   // an LDS-DMA instruction costs its wave ~60 cycles of issue among MFMAs but 100-185 in a back-to-back burst next to
   // the ds_reads (MI355X_MICROARCH.md, "LDS-DMA piece issue cost").
-  const __amdgpu_buffer_rsrc_t rsA1 = uniform_rsrc((const void*)P.p1, a1_bytes);
-  const __amdgpu_buffer_rsrc_t rsA2 = uniform_rsrc(P.p2 ? (const void*)P.p2 : (const void*)P.p1, a2_bytes);
   // a stage past the end of this block's K range is issued all the same, through zero-length descriptors (every lane
   // out of range: no memory traffic, zeros into an LDS buffer nobody reads any more) -- the number of LDS-DMA
   // instructions in flight is then the same in every iteration and all vmcnt waits are constants
-  const __amdgpu_buffer_rsrc_t rsNull = uniform_rsrc((const void*)P.wt, 0);
-  __amdgpu_buffer_rsrc_t rsA = rsA1, rsB = rsW;
   unsigned coff = 0, koff = 0;
-  auto stage_prepare = [&](int buf, int kt) {
-    if (kt >= nk) {
-      rsA = rsNull; rsB = rsNull;
+  auto stage_prepare = [&](int buf, int kt) __attribute__((always_inline)) {
+    if (kt >= nk) {      // (no real stage follows in this tile; setup_tile / the next segment change restore them)
+      rsA = uniform_rsrc((const void*)P.wt, 0); rsB = rsA;
     } else {
     const int tap = kt / cpt, cc = kt - tap * cpt;
     const int srcsel = cc < cpt1 ? 0 : 1;
@@ -645,26 +650,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
       int dy = 0, dx = 0;
       if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
       const int cs = srcsel ? P.C2 : P.C1;
+      rsA = uniform_rsrc(srcsel ? (const void*)P.p2 : (const void*)P.p1, srcsel ? a2_bytes : a1_bytes);
+      // (sample, y, x) of each gathered row are re-derived here (a few dozen VALU ops per tap) rather than kept in 3 * NA
+      // registers for the whole tile: the persistent loop keeps the next tile's gather state live across the epilogue
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int row = (i * NW + w) * 8 + (lane >> 3);
-        const int iy = ry[i] + dy, ix = rx[i] + dx;
-        const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && !(((iy | ix) & 1) & P.zins);
+        const unsigned m = (unsigned)(m0 + row);
+        const unsigned b = lr_udiv(m, P.hw_mul, P.hw_sh), rem = m - b * (unsigned)HW;
+        const unsigned y = lr_udiv(rem, P.w_mul, P.w_sh), x = rem - y * (unsigned)P.W;
+        const int iy = (int)y * P.stride + dy, ix = (int)x * P.stride + dx;
+        const bool ok = (int)m < P.M && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim &&
+                        !(((iy | ix) & 1) & P.zins);
         const int sy = iy >> P.up, sx = ix >> P.up;
         const int chunk = slot ^ ((row >> 1) & 7);
-        avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
+        avo[i] = ok ? (unsigned)(((size_t)((int)b * P.Hs * P.Ws + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
       }
     }
     coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
-    rsA = srcsel ? rsA2 : rsA1;
-    rsB = rsW;
     koff = (unsigned)(kt * 128);
     }
     if (B_TAIL && w < TAIL_WAVES)     // the odd weight rows (first waves only): issued here, ahead of the step's other loads
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * STAGE + A_BYTES + ((NB_FULL * NW + w) * 8) * 128), 16,
                                                wvo[NB_FULL], koff, 0, 0);
   };
-  auto stage_issue = [&](int buf) {
+  auto stage_issue = [&](int buf) __attribute__((always_inline)) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
 #pragma unroll
@@ -674,13 +684,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
     for (int i = 0; i < NB_FULL; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + ((i * NW + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
   };
-  auto stage = [&](int buf, int kt) { stage_prepare(buf, kt); stage_issue(buf); };
+  auto stage = [&](int buf, int kt) __attribute__((always_inline)) { stage_prepare(buf, kt); stage_issue(buf); };
 
   f32x4 acc[TN][TM];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- main loop.  Fragments are double-buffered in registers: while the 20 MFMAs of one half K-step (k = 32) run,
   // the ds_read_b128 of the NEXT half step are already in flight, so the matrix pipe never waits on LDS latency and the
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
         acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
   };
   // wait until all of this wave's LDS-DMA except the newest INFLIGHT stages has landed
-  auto wait_stages = [&](auto inflight) {
+  auto wait_stages = [&](auto inflight) __attribute__((always_inline)) {
     constexpr int F = decltype(inflight)::value;
     constexpr int L0 = NA + NB_FULL, L1 = L0 + 1;   // LDS-DMA instructions per stage of a wave without / with the tail
     if (B_TAIL && w < TAIL_WAVES) wait_vmcnt<F * L1>();
@@ -719,30 +725,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
   using std::integral_constant;
 
   const int nsteps = nk - k_begin;
-  LR_STAMP(0);
   constexpr int PAR_LD = ((BN + 63) / 64) * 64;
   float* rs = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
   float* par = rs + 2 * BM2;
-  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
   // DB: the whole ring is filled up front and K-step `it` refills its own buffer (stage it + NSTAGE) from the middle of
   // the step on; !DB: NSTAGE - 1 stages up front, stage it + NSTAGE - 1 goes out during the first half of K-step `it`
   // (its buffer was released by the barrier that ended step it - 1).
   constexpr int NPRO = DB ? NSTAGE : NSTAGE - 1;
-#pragma unroll
-  for (int sidx = 0; sidx < NPRO; ++sidx) stage(sidx, k_begin + sidx);
-  LR_STAMP(1);
-  vec8<T> xa[TM], wa[TN];
-  if constexpr (!DB) stage_prepare(NSTAGE - 1, k_begin + NSTAGE - 1);
-  if (nsteps > 0) {
-    wait_stages(integral_constant<int, NPRO - 1>{});
-    __builtin_amdgcn_s_barrier();
-    if constexpr (DB) read_frags(xa, wa, 0, 0);
-  }
-  LR_STAMP(2);
-  int cur = 0;
-  // MFMAs of one half K-step with the prepared stage's LDS-DMA instructions spread between them
   constexpr int NDMA = NA + NB_FULL;
   constexpr int MFMA_PER = (TM * TN) / NDMA > 0 ? (TM * TN) / NDMA : 1;
+  // MFMAs of one half K-step with the prepared stage's LDS-DMA instructions spread between them
   auto mma_issue = [&](const vec8<T> (&xf)[TM], const vec8<T> (&wf)[TN], int buf) {
     stage_issue(buf);
     mma(xf, wf);
@@ -752,70 +744,88 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) 
       __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
     }
   };
-  if constexpr (DB) {
-    vec8<T> xb[TM], wb[TN];
-    for (int it = 0; it + 1 < nsteps; ++it) {
-      const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
-      // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]
-      read_frags(xb, wb, cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(xa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage `it` are in registers
-      __builtin_amdgcn_s_barrier();
-      stage_prepare(cur, k_begin + it + NSTAGE);           // refill the buffer every wave has finished with ...
-      read_frags(xa, wa, nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_issue(xb, wb, cur);                              // ... between the MFMAs of the second half
-      __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
+  LR_STAMP(0);
+  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
+#pragma unroll
+  for (int sidx = 0; sidx < NPRO; ++sidx) stage(sidx, k_begin + sidx);
+  if constexpr (!DB) stage_prepare(NSTAGE - 1, k_begin + NSTAGE - 1);
+  LR_STAMP(1);
+  {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    vec8<T> xa[TM], wa[TN];
+    wait_stages(integral_constant<int, NPRO - 1>{});        // stage 0 (and the column parameters) landed
+    __builtin_amdgcn_s_barrier();
+    if constexpr (DB) { if (nsteps > 0) read_frags(xa, wa, 0, 0); }
+    LR_STAMP(2);
+    int cur = 0;
+    if constexpr (DB) {
+      vec8<T> xb[TM], wb[TN];
+      for (int it = 0; it + 1 < nsteps; ++it) {
+        const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
+        // sched_barrier(0) pins the issue order [reads of the next half] -> [MFMAs of the current half]
+        read_frags(xb, wb, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage `it` are in registers
+        __builtin_amdgcn_s_barrier();
+        stage_prepare(cur, k_begin + it + NSTAGE);           // refill the buffer every wave has finished with ...
+        read_frags(xa, wa, nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_issue(xb, wb, cur);                              // ... between the MFMAs of the second half
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+      if (nsteps > 0) {
+        read_frags(xb, wb, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xb, wb);
+      }
+    } else {
+      int pbuf = NSTAGE - 1;      // buffer of the prepared, not yet issued stage
+      for (int it = 0; it + 1 < nsteps; ++it) {
+        const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
+        read_frags(xa, wa, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_issue(xa, wa, pbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(xa, wa, cur, 1);
+        mma(xa, wa);
+        wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_prepare(cur, k_begin + it + NSTAGE);
+        pbuf = cur;
+        cur = nxt;
+      }
+      if (nsteps > 0) {
+        read_frags(xa, wa, cur, 0);
+        mma(xa, wa);
+        read_frags(xa, wa, cur, 1);
+        mma(xa, wa);
+      }
     }
-    if (nsteps > 0) {
-      read_frags(xb, wb, cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(xa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(xb, wb);
+    LR_STAMP(3);
+    // ---- epilogue straight from the accumulators (see epilogue_units)
+    if (P.ln_part) {
+      ln_rows_to_lds(P, rs, m0, BM2, t);
+      __syncthreads();
     }
-  } else {
-    int pbuf = NSTAGE - 1;      // buffer of the prepared, not yet issued stage
-    for (int it = 0; it + 1 < nsteps; ++it) {
-      const int nxt = cur == NSTAGE - 1 ? 0 : cur + 1;
-      read_frags(xa, wa, cur, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_issue(xa, wa, pbuf);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(xa, wa, cur, 1);
-      mma(xa, wa);
-      wait_stages(integral_constant<int, NSTAGE - 2>{});   // stage it+1 landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stage_prepare(cur, k_begin + it + NSTAGE);
-      pbuf = cur;
-      cur = nxt;
-    }
-    if (nsteps > 0) {
-      read_frags(xa, wa, cur, 0);
-      mma(xa, wa);
-      read_frags(xa, wa, cur, 1);
-      mma(xa, wa);
-    }
-  }
-  // ---- epilogue straight from the accumulators (see epilogue_units)
-  LR_STAMP(3);
-  if (P.ln_part) {
-    ln_rows_to_lds(P, rs, m0, BM2, t);
-    __syncthreads();
-  }
-  LR_STAMP(4);
-  epilogue_units<TM, TN, MODE, PAR_LD, WNW, T>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
-                                            tile_n * WNW + wn);
-  LR_STAMP(5);
+    LR_STAMP(4);
+    epilogue_units<TM, TN, MODE, PAR_LD, WNW, T>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
+                                              tile_n * WNW + wn);
+    LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  LR_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LR_STAMP(6);
 #endif
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -835,7 +845,8 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(P.nblocks, P.splits), dim3(NW * 64), smem, st, P);
+  const int gx = P.nblocks;
+  hipLaunchKernelGGL((gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(gx, P.splits), dim3(NW * 64), smem, st, P);
   return lr_launch_status();
 }
 
@@ -1042,6 +1053,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.geglu = a->geglu == 1 ? 1 : 0;
   P.gelu = a->geglu == 2 ? 1 : 0;      // plain erf-GELU of (acc + bias [+ rowvec]), applied before the residual
   P.rows_per_batch = a->H * a->W;
+  lr_udiv_magic((unsigned)(a->H * a->W), &P.hw_mul, &P.hw_sh);
+  lr_udiv_magic((unsigned)a->W, &P.w_mul, &P.w_sh);
   const int N_out = P.geglu ? P.N / 2 : P.N;
   if (P.N % 8 || N_out % 8 || P.ld_out % 8 || (P.resid && P.ld_resid % 8) || (P.rowvec && P.ld_rowvec % 8))
     return LR_E_ALIGN;
