@@ -132,7 +132,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   constexpr int NPJ = TE / 2;
   constexpr int NUJ = TM * NPJ;
   constexpr int NU = NUJ + (TE & 1) * (TM / 2);
-  constexpr int G = TM * TN >= 40 ? 4 : 8;   // residual loads in flight per wave (16 B per lane each)
+  constexpr int G = TM * TN >= 40 ? 4 : 8;   // residual loads in flight per wave (16 B per lane each); 6 / 8 for the 40-tile instances spill and measured 3-5 % slower
   const int fr = lane & 15, fq = lane >> 4;
   const int odd = fq & 1, ch8 = (fq >> 1) * 8;
   const int N_out = GEGLU ? P.N >> 1 : P.N;
@@ -555,7 +555,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //                        ring of gemm_conv_kernel every K-step of these shapes waits out a full L2/HBM latency
 //                        (measured 32 us for 13.4 GFLOP whatever the tile).
 template <int BM2, int NW, int BN, int WMW, int NSTAGE, int MODE, typename T>
-__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const GemmParams P) {
+__global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WNW = NW / WMW;
   constexpr int TM = BM2 / WMW / 16;    // 16-row MFMA tiles per wave along M
@@ -841,12 +841,12 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
   const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   const int gx = P.nblocks;
-  hipLaunchKernelGGL((gemm_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(gx, P.splits), dim3(NW * 64), smem, st, P);
+  hipLaunchKernelGGL((gemm_conv_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(gx, P.splits), dim3(NW * 64), smem, st, P);
   return lr_launch_status();
 }
 

@@ -16,7 +16,8 @@ from collections import defaultdict
 
 
 def family(name):
-    for key in ("gemm_conv256_kernel<320, 2, 2>", "gemm_conv256_kernel<256, 2, 2>", "gemm_conv256_kernel", "gemm_conv_kernel",
+    for key in ("gemm_conv_pipe_kernel<256, 8, 320, 2, 2", "gemm_conv_pipe_kernel<256, 8, 256, 2, 2", "gemm_conv_pipe_kernel",
+                "gemm_conv_kernel",
                 "attention_kernel<true", "attention_kernel<false", "gn_apply", "gn_stats", "layernorm", "splitk_reduce",
                 "transpose_v"):
         if key in name:

@@ -1,4 +1,4 @@
-"""Developer tool: per-phase timeline of gemm_conv256_kernel from in-kernel shader-clock stamps (needs a trace build):
+"""Developer tool: per-phase timeline of gemm_conv_pipe_kernel from in-kernel shader-clock stamps (needs a trace build):
 
     hipcc ... -DLR_GEMM_TRACE (python tools/trace_gemm.py builds its own copy of the library under /tmp)
 
