@@ -130,8 +130,9 @@ typedef struct lr_gemm_args {
   float* stats_out;
   /* gn_stats_out != NULL: per-channel (sum, sumsq) of the fp16-rounded output over each block of R = lr_gemm_gn_rows(args)
    * consecutive rows, [ceil(M / R)][N][2] fp32 -- the statistics pass of the GroupNorm that consumes this tensor
-   * (openaimodel.py:254-274) comes out of the producer's epilogue; lr_groupnorm_finalize turns the blocks of one sample
-   * (H*W must be a multiple of R) into per-group sums.  Fixed order, no atomics.  Not with split-K or GEGLU. */
+   * (openaimodel.py:254-274) comes out of the producer's epilogue (of the reduce kernel, R = 32, when the call splits K);
+   * lr_groupnorm_finalize turns the blocks of one sample (H*W must be a multiple of R) into per-group sums.
+   * Fixed order, no atomics.  Not with GEGLU. */
   float* gn_stats_out;
   int32_t dtype;            /* LR_DTYPE_F16 | LR_DTYPE_BF16: type of p1, p2, wt, rowvec, resid, out (geglu == 2 is fp16 only) */
   int32_t stages;           /* depth of the LDS ring: 0 = the tile's default (tile_m 128: 2; 256 x {128,160}: 3; 256 x {256,320}: 2);

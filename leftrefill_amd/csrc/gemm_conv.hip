@@ -158,7 +158,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   // GroupNorm statistics of the consumer: per-channel sums over the wave's rows.  All units of a column group (the TM
   // units of a tile-column pair, or the TM/2 units of the odd last column) put the SAME eight channels in a lane, so the
   // lane accumulates over them and the group is reduced over the 16 row lanes (4 DPP adds per value) when it completes.
-  const bool gstat = !GEGLU && P.gs_out != nullptr && P.st_out == nullptr;
+  const bool gstat = !GEGLU && fin && P.gs_out != nullptr && P.st_out == nullptr;
   auto row16_sum = [&](float v) -> float {   // sum over the 16 lanes of a DPP row, result in every lane
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
@@ -851,19 +851,42 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
 }
 
 // Fixed-order reduction of the split-K partials + the fused epilogue (deterministic: no atomics).
+// Block = RED_GROUPS channel groups (8 channels = 16 B of output each) x RED_ROWS = 32 output rows, one (row, group) per thread;
+// the partial loads of a thread are independent and issued four splits at a time (the round-1 kernel walked the splits
+// with one dependent load pair per iteration: 11 us for 20-30 MB).  With gs_out the block also emits the per-channel
+// (sum, sumsq) of its 32 rows of the ROUNDED output -- the GroupNorm statistics of the consumer -- so a split-K producer
+// no longer needs the stand-alone statistics pass.
+#define RED_ROWS 32
+#define RED_GROUPS 16     // 8-channel groups per block: 128 channels x 32 rows = 512 threads; 1024 x 1280 outputs -> 320 blocks
 template <typename T>
-__global__ void splitk_reduce_kernel(const GemmParams P) {
-  const int cpr = P.N >> 3;
-  const long long total = (long long)P.M * cpr;
-  for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total;
-       id += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(id / cpr), n = (int)(id - (long long)m * cpr) * 8;
-    float v[8];
+__global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(const GemmParams P) {
+  __shared__ float red[RED_ROWS][RED_GROUPS][17];     // 17: conflict-free column reads
+  const int tx = threadIdx.x % RED_GROUPS, ty = threadIdx.x / RED_GROUPS;
+  const int n = (blockIdx.x * RED_GROUPS + tx) * 8;
+  const int m = blockIdx.y * RED_ROWS + ty;
+  const bool ok = n < P.N && m < P.M;
+  float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = 0.f;
-    for (int sidx = 0; sidx < P.splits; ++sidx) {
-      const float* src = P.ws + ((size_t)sidx * P.M + m) * P.N + n;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if (ok) {
+    const float* src = P.ws + (size_t)m * P.N + n;
+    const size_t slice = (size_t)P.M * P.N;
+    int sidx = 0;
+    for (; sidx + 4 <= P.splits; sidx += 4) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] = *reinterpret_cast<const f32x4*>(src + (sidx + k) * slice);
+        b[k] = *reinterpret_cast<const f32x4*>(src + (sidx + k) * slice + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {     // same order as a plain loop over the splits
+        v[0] += a[k][0]; v[1] += a[k][1]; v[2] += a[k][2]; v[3] += a[k][3];
+        v[4] += b[k][0]; v[5] += b[k][1]; v[6] += b[k][2]; v[7] += b[k][3];
+      }
+    }
+    for (; sidx < P.splits; ++sidx) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + sidx * slice), b = *reinterpret_cast<const f32x4*>(src + sidx * slice + 4);
       v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
     }
     if (P.bias) {
@@ -886,7 +909,26 @@ __global__ void splitk_reduce_kernel(const GemmParams P) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += e[i];
     }
-    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = lr_pack8<T>(v);
+    const uint4 pk = lr_pack8<T>(v);
+    *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = pk;
+    if (P.gs_out) lr_unpack8<T>(pk, v);       // statistics of what the consumer will read
+  }
+  if (P.gs_out) {      // block-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = ok ? v[i] : 0.f;
+      red[ty][tx][2 * i] = x; red[ty][tx][2 * i + 1] = x * x;
+    }
+    __syncthreads();
+    // RED_GROUPS channel groups x 16 values, summed over the 32 rows in a fixed order by the first 16 RED_GROUPS threads
+    if (threadIdx.x < 16 * RED_GROUPS) {
+      const int cg = threadIdx.x >> 4, pr = threadIdx.x & 15;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < RED_ROWS; ++k) s += red[k][cg][pr];
+      const int nn = (blockIdx.x * RED_GROUPS + cg) * 8;
+      if (nn < P.N) P.gs_out[((size_t)blockIdx.y * P.N + nn) * 2 + pr] = s;      // [row block][N][2], (sum, sumsq) interleaved
+    }
   }
 }
 
@@ -925,11 +967,10 @@ static int launch_gemm(const GemmParams& P, hipStream_t st) {
 }
 
 static int launch_reduce(const GemmParams& P, hipStream_t st) {
-  long long chunks = (long long)P.M * (P.N >> 3);
-  int grid = (int)((chunks + 255) / 256);
-  if (grid > 4096) grid = 4096;
-  if (P.bf16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(splitk_reduce_kernel<f16>, dim3(grid), dim3(256), 0, st, P);
+  const dim3 grid((P.N + 8 * RED_GROUPS - 1) / (8 * RED_GROUPS), (P.M + RED_ROWS - 1) / RED_ROWS);
+  if (grid.y > 65535) return LR_E_UNSUPPORTED;
+  if (P.bf16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, grid, dim3(RED_ROWS * RED_GROUPS), 0, st, P);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<f16>, grid, dim3(RED_ROWS * RED_GROUPS), 0, st, P);
   return lr_launch_status();
 }
 
@@ -1001,7 +1042,11 @@ static int tile_wave_rows(int tm, int tn, int geglu) {
 extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
   if (!a) return 0;
   int tn = a->tile_n, tm = a->tile_m;
-  choose_tile(a->B * a->H * a->W, a->N, a->geglu != 0, &tm, &tn);
+  const int M = a->B * a->H * a->W;
+  choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
+  if (splits > 1) return RED_ROWS;     // the statistics come out of the split-K reduce kernel
   return tile_wave_rows(tm, tn, a->geglu == 1);
 }
 
@@ -1090,7 +1135,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.bf16 = a->dtype == LR_DTYPE_BF16;
   if (P.bf16 && P.gelu) return LR_E_UNSUPPORTED;
   P.gs_out = a->gn_stats_out;
-  if (P.gs_out && (splits > 1 || P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
+  if (P.gs_out && (P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
   P.st_out = a->stats_out;
   P.st_parts = ((P.N + tn - 1) / tn) * tile_wnw(tm, tn, P.geglu);
   if (P.st_out && (splits > 1 || ((uintptr_t)P.st_out & 7))) return LR_E_ARG;

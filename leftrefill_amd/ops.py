@@ -173,7 +173,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     are the gamma / beta folded weights, see lr_gemm_args).  want_stats: also return the per-row (sum, sumsq) partials of
     the output, [M, parts, 2] fp32 -- the `stats` a following LayerNorm-folded GEMM consumes; returns (out, stats).
     want_gn_stats: also return per-channel (sum, sumsq) over row blocks for the GroupNorm that consumes the output:
-    returns (out, (partials [M / R, N, 2] fp32, R)), or (out, None) when the plan splits K (statistics need the whole sum)."""
+    returns (out, (partials [M / R, N, 2] fp32, R)), or (out, None) when R does not divide H*W."""
     lib = _lib.load()
     _chk16(x1, "x1")
     _chk16(wt, "wt")
@@ -242,10 +242,10 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     if want_gn_stats:
         plan = (ctypes.c_int32 * 4)()
         lib.lr_gemm_plan(a, plan)
+        a.splits = plan[2]                  # pinned: the row-block size of the statistics depends on it (32 behind split-K)
         rows = lib.lr_gemm_gn_rows(a)
-        if plan[2] == 1 and (H * W) % rows == 0:     # whole K in one block; row blocks never straddle two samples
-            a.splits = 1
-            gstats = (torch.empty(M // rows, n_out, 2, device=x1.device, dtype=torch.float32), rows)
+        if (H * W) % rows == 0:             # row blocks never straddle two samples
+            gstats = (torch.empty((M + rows - 1) // rows, n_out, 2, device=x1.device, dtype=torch.float32), rows)
             a.gn_stats_out = _p(gstats[0])
     ws = _workspace(lib, a, x1.device)
     _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")

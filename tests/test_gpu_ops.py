@@ -384,6 +384,40 @@ def test_groupnorm_statistics_from_gemm_epilogue(tile):
     report(name + " gn(single)", from_tok(out1, N, H, W), ref1)
 
 
+def test_groupnorm_statistics_from_splitk_reduce():
+    """A split-K producer hands the GroupNorm statistics over from its reduce kernel (32-row blocks of the rounded output):
+    block sums match the stored tensor, the output equals the unsplit GEMM's bit for bit, GroupNorm matches F.group_norm."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W, Cin, Cout = 2, 8, 16, 640, 320              # M = 256 rows, K = 5760
+    x = h16(G.T("gns.x", (N, Cin, H, W)) * 1.2 + 0.2)
+    w = h16(torch.from_numpy(weights.fill_like("gns.w", (Cout, Cin, 3, 3))))
+    b = torch.from_numpy(weights.fill_like("gns.b", (Cout,))) + 0.3
+    rs = h16(G.T("gns.rs", (N, Cout, H, W)))
+    wp, bp = packing.pack_conv(w, cin_pad=Cin).to(d), packing.pack_bias(b).to(d)
+    for splits in (2, 3, 5):
+        y, gs = ops.gemm_conv(to_tok(x), wp, B=N, H=H, W=W, taps=9, bias=bp, resid=to_tok(rs), want_gn_stats=True, splits=splits)
+        assert gs is not None and gs[1] == 32
+        part, R = gs
+        yf = y.float().reshape(N * H * W // R, R, Cout)
+        assert torch.allclose(part[..., 0], yf.sum(1), rtol=1e-5, atol=2e-3)
+        assert torch.allclose(part[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=2e-3)
+        y1 = ops.gemm_conv(to_tok(x), wp, B=N, H=H, W=W, taps=9, bias=bp, resid=to_tok(rs), splits=splits)
+        assert torch.equal(y, y1)
+        report(f"splitk{splits} conv", from_tok(y, N, H, W), F.conv2d(x, w, b, padding=1) + rs)
+        gam = 1.0 + 0.3 * G.T("gns.g", (Cout,))
+        bet = 0.2 * G.T("gns.be", (Cout,))
+        out = ops.group_norm_fused(y, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gs)
+        report(f"splitk{splits} gn", from_tok(out, N, H, W), F.silu(F.group_norm(from_tok(y, N, H, W), 32, gam, bet, 1e-5)))
+    # ragged M and N (tails of the reduce kernel's 32-row x 256-channel blocks), rowvec, no statistics
+    M, K, Nn = 300, 2560, 328
+    a = h16(G.T("gns.a", (M, K)))
+    w2 = h16(torch.from_numpy(weights.fill_like("gns.w2", (Nn, K))))
+    rv = h16(G.T("gns.rv", (1, Nn)))
+    y2 = ops.gemm_conv(a.half().to(d), w2.half().to(d), B=1, H=1, W=M, taps=1, rowvec=rv.half().to(d), splits=4)
+    report("splitk ragged", y2, F.linear(a, w2) + rv)
+
+
 def test_tile_plan_is_static_and_tiles_agree_bitwise():
     """The (tile, split-K) plan is a pure function of the shape (in-tree table or the static heuristic -- never timing),
     and with the split factor pinned every tile gives bit-identical results (same K order per output element)."""
