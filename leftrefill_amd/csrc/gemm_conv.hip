@@ -132,7 +132,11 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   constexpr int NPJ = TE / 2;
   constexpr int NUJ = TM * NPJ;
   constexpr int NU = NUJ + (TE & 1) * (TM / 2);
-  constexpr int G = TM * TN >= 40 ? 4 : 8;   // residual loads in flight per wave (16 B per lane each); 6 / 8 for the 40-tile instances spill and measured 3-5 % slower
+  // Addend loads in flight per wave (16 B per lane each).  The ring carries ONE operand per unit -- the residual when there
+  // is one, else the per-sample row vector (no layer of the model has both; if a caller passes both, the row vector is
+  // loaded synchronously) -- so 8 units fit in the registers 4 two-operand units took: the 40-tile epilogue was bound by
+  // bytes in flight (32 KiB per CU at ~2.5 us loaded latency = 3.3 TB/s chip-wide), not by bandwidth.
+  constexpr int G = TM * TN >= 40 ? 8 : (NU < 16 ? NU : 16);
   const int fr = lane & 15, fq = lane >> 4;
   const int odd = fq & 1, ch8 = (fq >> 1) * 8;
   const int N_out = GEGLU ? P.N >> 1 : P.N;
@@ -229,17 +233,23 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   };
   // sample index of row m for the per-sample row vector: one division per wave, then boundary compares
   const int b_w0 = P.rowvec ? m_w0 / P.rows_per_batch : 0;
-  auto fetch = [&](const int u, u32x4& rres, u32x4& rvec) {
+  const bool has_res = P.resid != nullptr && fin;
+  const bool both = has_res && P.rowvec != nullptr;
+  auto rowvec_offset = [&](const int m, const int n, const bool ok) -> unsigned {
+    int b = b_w0;
+    for (int lim = (b_w0 + 1) * P.rows_per_batch; m >= lim; lim += P.rows_per_batch) ++b;
+    return ok ? (unsigned)(((size_t)b * P.ld_rowvec + n) * 2) : OOB;
+  };
+  const __amdgpu_buffer_rsrc_t rsX = has_res ? rsR : rsV;     // the operand the ring carries
+  auto fetch = [&](const int u, u32x4& r) {
     int m, n;
     coords(u, m, n);
     const bool ok = m < P.M && n < N_out;
-    rres = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? (unsigned)(((size_t)m * P.ld_resid + n) * 2) : OOB, 0, 0);
-    int b = b_w0;
-    if (P.rowvec)
-      for (int lim = (b_w0 + 1) * P.rows_per_batch; m >= lim; lim += P.rows_per_batch) ++b;
-    rvec = __builtin_amdgcn_raw_buffer_load_b128(rsV, ok ? (unsigned)(((size_t)b * P.ld_rowvec + n) * 2) : OOB, 0, 0);
+    const unsigned off = has_res ? (ok ? (unsigned)(((size_t)m * P.ld_resid + n) * 2) : OOB)
+                                 : (P.rowvec ? rowvec_offset(m, n, ok) : OOB);
+    r = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
   };
-  auto finish = [&](const int u, const u32x4& rres, const u32x4& rvec) {
+  auto finish = [&](const int u, const u32x4& rx) {
     f32x4 a, b;
     int ia, ib;          // statistics slots of the even / odd lane rows
     if (u < NUJ) {
@@ -265,16 +275,29 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     }
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     float e[8];
-    lr_unpack8<T>(__builtin_bit_cast(uint4, rvec), e);
+    lr_unpack8<T>(__builtin_bit_cast(uint4, rx), e);
+    if (both) {                        // row vector next to a residual: not prefetched (no layer of the model does this)
+      float e2[8];
+      const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(rsV, rowvec_offset(m, n, ok), 0, 0);
+      lr_unpack8<T>(__builtin_bit_cast(uint4, r2), e2);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] += e[q];
-    if constexpr (MODE == 2) {
+      for (int q = 0; q < 8; ++q) v[q] += e2[q];
+    }
+    if constexpr (MODE == 2) {         // erf-GELU sits between the row vector and the residual
+      if (!has_res) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += e[q];
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = lr_gelu_erf(v[q]);
-    }
-    lr_unpack8<T>(__builtin_bit_cast(uint4, rres), e);
+      if (has_res) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] += e[q];
+        for (int q = 0; q < 8; ++q) v[q] += e[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += e[q];
+    }
     const uint4 pk = lr_pack8<T>(v);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rsO,
                                            ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, 0);
@@ -301,14 +324,14 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   };
 
   // software pipeline: the loads of unit u + G are issued right after unit u is finished (a ring of G register sets)
-  u32x4 rr[G], rv[G];
+  u32x4 rr[G];
 #pragma unroll
   for (int k = 0; k < G; ++k)
-    if (k < NU) fetch(k, rr[k], rv[k]);
+    if (k < NU) fetch(k, rr[k]);
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    finish(u, rr[u % G], rv[u % G]);
-    if (u + G < NU) fetch(u + G, rr[u % G], rv[u % G]);
+    finish(u, rr[u % G]);
+    if (u + G < NU) fetch(u + G, rr[u % G]);
   }
   if (P.st_out) {   // row sums over this wave's column range: the four fq lanes of an fr hold pieces of the same row
 #pragma unroll
