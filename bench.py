@@ -484,6 +484,10 @@ def main():
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
+    # The metric times the FULL classifier-free-guidance batch: the sampler's exact shared-prefix optimisation (the context-free
+    # first block computed once for the identical uncond / cond halves, UNetModel.cfg_shared_prefix, on by default for users)
+    # is switched off for `value` and measured next to it as `cfg_shared_prefix` below.
+    os.environ["LEFTREFILL_CFG_SHARED_PREFIX"] = "0"
     B, h, w = a.batch, 64, 128
     samples_per_step = B
     if a.workload != "single":      # B counts canvases from here on; one sample = (view_num - 1 | view_num) canvases
@@ -528,7 +532,7 @@ def main():
                                   "(UNet batch 8 under CFG), 50 DDIM steps, cfg=2.5, eta=1.0, fp16",
                       "global_batch": world * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
                       "parallelism": f"dp{world} (sample-sharded, no data-path collective)",
-                      "note": "every DDIM step runs the full UNet at batch 2B; the only loop-invariant hoisted out of the step is the "
+                      "note": "every DDIM step runs the full UNet at batch 2B (the exact shared-prefix optimisation of the sampler is OFF for this number); the only loop-invariant hoisted out of the step is the "
                               "cross-attention K/V projection of the constant context (3.9 of 1850 GFLOP per sample per forward, "
                               "0.2 %), computed once per sampling"},
            "per_unet_step_ms": unet_step_ms}
@@ -569,6 +573,25 @@ def main():
             except Exception as e:      # noqa: BLE001
                 res[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+        def shared_prefix():
+            os.environ["LEFTREFILL_CFG_SHARED_PREFIX"] = "1"
+            try:
+                sample_once(model, batch, B, steps=4)        # capture the graph of the shared-prefix step
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n = max(1, min(a.steps, 3))
+                for _ in range(n):
+                    o = sample_once(model, batch, B)
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t1) / n
+                return {"images_per_s": B / dt1, "per_unet_step_ms": 1e3 * dt1 / S_DDIM, "finite": bool(torch.isfinite(o).all()),
+                        "note": "same sampling with the context-free prefix of the UNet (conv_in, first ResBlock, first self-attention, "
+                                "first cross-attention query projection) computed once for the identical uncond / cond halves -- bit-identical "
+                                "results (tests/test_gpu_unet.py::test_cfg_shared_prefix_is_exact); not the metric"}
+            finally:
+                os.environ["LEFTREFILL_CFG_SHARED_PREFIX"] = "0"
+        if a.workload == "single":
+            side("cfg_shared_prefix", shared_prefix)
         side("unet_step_events", lambda: unet_step_events(model, batch, B))
         side("vae_512x1024", lambda: vae_timing(B, device))
         v = res["vae_512x1024"]

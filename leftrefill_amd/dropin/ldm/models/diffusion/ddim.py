@@ -150,6 +150,7 @@ class DDIMSampler(object):
     # the conditioning is constant over the loop: build the [uncond; cond] batch once instead of 50 torch.cat calls
     def _prepare_cfg_inputs(self, c, uc, scale):
         self._cfg_cache = None
+        self._cfg_shared = False
         if uc is None or scale == 1. or not isinstance(c, dict):
             return
         c_in = {}
@@ -159,6 +160,12 @@ class DDIMSampler(object):
             else:
                 c_in[k] = torch.cat([uc[k], c[k]])
         self._cfg_cache = (id(c), id(uc), c_in)
+        # the two halves of the CFG batch differ only in the cross-attention context when every other conditioning tensor
+        # is the same for uncond and cond: checked once per sampling, lets the UNet share the context-free prefix
+        import os
+        self._cfg_shared = os.environ.get("LEFTREFILL_CFG_SHARED_PREFIX", "1") != "0" and all(
+            all(torch.equal(u_, c_) for u_, c_ in zip(uc[k], c[k])) if isinstance(c[k], list) else torch.equal(uc[k], c[k])
+            for k in c if k != "c_crossattn")
 
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
@@ -187,7 +194,16 @@ class DDIMSampler(object):
                         for k in c}
             x_in = torch.cat([x] * 2)
             t_in = torch.cat([t] * 2)
-            eps = self.model.apply_model(x_in, t_in, c_in)   # [2B, 4, h, w], uncond half first (ddim.py:317-342)
+            unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+            shared = (cache is not None and c_in is cache[2] and getattr(self, "_cfg_shared", False)
+                      and hasattr(unet, "cfg_shared_prefix"))
+            if shared:
+                unet.cfg_shared_prefix = True
+            try:
+                eps = self.model.apply_model(x_in, t_in, c_in)   # [2B, 4, h, w], uncond half first (ddim.py:317-342)
+            finally:
+                if shared:
+                    unet.cfg_shared_prefix = False
         eps = eps.contiguous()
         # randn is drawn every step like the reference (ddim.py:378), also when sigma_t == 0
         noise = noise_like(x.shape, device, repeat_noise)

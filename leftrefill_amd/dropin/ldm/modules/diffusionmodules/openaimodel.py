@@ -181,6 +181,12 @@ class UNetModel(nn.Module):
         self.dtype = th.float16 if use_fp16 else th.float32
         # 16-bit type of the HIP path's activations / packed weights: float16 (reference autocast, appendix B) or bfloat16
         self.compute_dtype = th.float16
+        # Set by DDIMSampler while it runs classifier-free guidance on an [x; x] batch (the reference's
+        # `torch.cat([x] * 2)`, ddim.py:317-342): both halves see the same latent, timestep and concat conditioning, and the
+        # context enters only at the first cross-attention, so conv_in, the first ResBlock, the first self-attention and
+        # the first cross-attention's query projection are computed ONCE for the two halves and duplicated.  Exact (no
+        # approximation); `LEFTREFILL_CFG_SHARED_PREFIX=0` keeps the sampler from setting it.
+        self.cfg_shared_prefix = False
         self.num_heads = num_heads
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
@@ -348,8 +354,9 @@ class UNetModel(nn.Module):
             res.append((kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot)))   # V^T: the V tile streams by LDS-DMA
         return res
 
-    def _run_plan(self, x, timesteps, context, kv_cache=None):
-        """x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,D] fp16 -> eps [N,Cout,H,W] fp16."""
+    def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False):
+        """x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,D] fp16 -> eps [N,Cout,H,W] fp16.
+        shared_prefix: x[:N/2] == x[N/2:] and timesteps likewise (see `cfg_shared_prefix`)."""
         P = self._plan
         E = engine
         N, _, H, W = x.shape
@@ -382,13 +389,19 @@ class UNetModel(nn.Module):
             y = torch_checkpoint(body, act.tok, act.tok2, *tensors, use_reentrant=False)
             return E.Act(y, n_, *shape["hw"])
 
-        def run(steps, act):
+        def run(steps, act, half=False):
+            """half: `act` is the first half of a CFG batch with identical halves; a SpatialTransformer ends that state."""
             for kind, p in steps:
-                if kind == "res":
-                    emb_p = emb_all[:, p.emb_off:p.emb_off + p.cout]
+                if kind in ("res", "conv") and half:      # planned like the full batch: identical partial sums
+                    with E.plan_batch_scale(2):
+                        act = (E.resblock(act, p, emb_all[:act.N, p.emb_off:p.emb_off + p.cout]) if kind == "res"
+                               else E.conv(act, p, gn_stats=True))
+                elif kind == "res":
+                    emb_p = emb_all[:act.N, p.emb_off:p.emb_off + p.cout]      # (both halves share the timesteps)
                     act = ckpt(lambda a_, p=p, emb_p=emb_p: E.resblock(a_, p, emb_p), act)
                 elif kind == "st":
-                    act = ckpt(lambda a_, c_, p=p: E.spatial_transformer(a_, c_, L, p, kv_cache), act, ctx)
+                    act = ckpt(lambda a_, c_, p=p, d_=half: E.spatial_transformer(a_, c_, L, p, kv_cache, dup=d_), act, ctx)
+                    half = False
                 elif kind == "down":
                     act = E.conv(act, p, gn_stats=True)
                 elif kind == "up":
@@ -403,12 +416,24 @@ class UNetModel(nn.Module):
             if taps is not None:
                 taps[name] = E.act_to_nchw(a, dtype=torch.float32)
 
-        act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"], dtype=self.compute_dtype), N, H, W)
+        # CFG batch with identical halves: blocks 0 and 1 (up to the first cross-attention) run on the first half only
+        shared = (shared_prefix and N % 2 == 0 and len(P["input"]) > 1 and len(P["input"][0]) == 1
+                  and P["input"][0][0][0] == "conv" and [k for k, _ in P["input"][1]] == ["res", "st"]
+                  and E.st_dup_ok(P["input"][1][1][1]) and not recompute)
+        if shared:
+            Nh = N // 2
+            act = E.Act(ops.nchw_to_nhwc(x[:Nh], cpad=P["cin_pad"], dtype=self.compute_dtype), Nh, H, W)
+        else:
+            act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"], dtype=self.compute_dtype), N, H, W)
         hs = []
         for i, steps in enumerate(P["input"]):
-            act = run(steps, act)
-            hs.append(act)
-            tap(f"in{i}", act)
+            act = run(steps, act, half=shared and i < 2)
+            if shared and i == 0:      # the skip connection of the last output block wants the full batch
+                hs.append(E.Act(E.dup2(act.tok), N, act.H, act.W,
+                                gs=None if act.gs is None else (E.dup2(act.gs[0]), act.gs[1])))
+            else:
+                hs.append(act)
+            tap(f"in{i}", hs[-1])
         act = run(P["middle"], act)
         tap("mid", act)
         for i, steps in enumerate(P["output"]):
@@ -433,10 +458,11 @@ class UNetModel(nn.Module):
             # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
             # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
-        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype)
+        shared = bool(self.cfg_shared_prefix)
+        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared)
         g = self._graphs.pop(key, None)
         if g is None:
-            g = _StepGraph(self, x, timesteps, context)
+            g = _StepGraph(self, x, timesteps, context, shared)
             while len(self._graphs) >= self.MAX_GRAPHS:      # LRU: dicts keep insertion order, re-inserted on every use
                 self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = g
@@ -446,7 +472,7 @@ class UNetModel(nn.Module):
 class _StepGraph:
     """One captured hipGraph of the UNet forward for a fixed (x, context) shape."""
 
-    def __init__(self, model, x, t, ctx):
+    def __init__(self, model, x, t, ctx, shared_prefix=False):
         self.model = model
         self.x = x.clone()
         self.t = t.clone()
@@ -456,12 +482,12 @@ class _StepGraph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.kv = model._context_kv(self.ctx)                  # static per-context buffers
-            model._run_plan(self.x, self.t, self.ctx, self.kv)     # warm-up: kernel attributes / tile autotune
+            model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix)     # warm-up: kernel attributes / tile autotune
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = model._run_plan(self.x, self.t, self.ctx, self.kv)
+            self.out = model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix)
 
     def replay(self, x, t, ctx, ctx_src):
         self.x.copy_(x)

@@ -21,6 +21,7 @@ import torch
 
 from . import packing
 from . import train_ops as ops     # == leftrefill_amd.ops unless autograd is recording and an input requires grad
+from .ops import plan_batch_scale
 
 # 16-bit storage / MFMA operand type of activations and packed weights: float16 (the reference's autocast type, every
 # inference config) or bfloat16 (BASELINE configs[4]).  Accumulation, statistics and the softmax stay fp32 in both.
@@ -260,10 +261,22 @@ def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False):
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False):
+def dup2(t):
+    """[rows, ...] -> [2 * rows, ...]: the (uncond | cond) halves of a classifier-free-guidance batch that are still identical."""
+    return torch.cat([t, t], dim=0)
+
+
+def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False, dup=False):
     """x + to_out(attention(LayerNorm(x) Wq, ctx Wk, ctx Wv)).  kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T,
-    V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv."""
-    q = ln_linear(x, st, pn, pa.q)
+    V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv.
+    dup: x holds only the first B / 2 samples (the two CFG halves are identical up to here): the query projection runs
+    once, then x and q are duplicated for the B contexts."""
+    if dup:
+        with plan_batch_scale(2):
+            q = ln_linear(x, st, pn, pa.q)
+        q, x = dup2(q), dup2(x)
+    else:
+        q = ln_linear(x, st, pn, pa.q)
     vt = None
     if kv is None:
         kv = linear(ctx, pa.kv)
@@ -273,11 +286,16 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False):
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468.
-    st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None)."""
+    st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
+    dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
+    self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix)."""
     ws = fold_ok(x)       # ask the residual GEMMs for the row statistics the next LayerNorm needs
-    if pt.view_num is None:
+    if pt.view_num is None and dup:
+        with plan_batch_scale(2):
+            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
+    elif pt.view_num is None:
         x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws)
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
         x = _mv_sharded_self_attention(x, pt, N, L)
@@ -299,7 +317,7 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         x = self_attention(x, st, pt.n1, pt.attn1, b, v * L, want_stats=ws)
     x, st = x if ws else (x, None)
     ws = fold_ok(x)
-    x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws)
+    x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
     x, st = x if ws else (x, None)
     if st is not None:
         g = ops.gemm_conv(x, pt.geglu_wf, B=1, H=1, W=x.shape[0], taps=1, bias=pt.geglu_bf, geglu=True,
@@ -346,15 +364,27 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
     return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
 
 
-def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None):
+def st_dup_ok(ps: PackedST):
+    return len(ps.blocks) > 0 and ps.blocks[0].view_num is None
+
+
+def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=False):
+    """dup: `act` holds the first half of a CFG batch whose halves are still identical (ctx has all 2 * act.N contexts);
+    the result is the full batch."""
     x_in = act.materialize()
-    h = gn(Act(x_in, act.N, act.H, act.W, gs=act.gs if act.tok2 is None else None), ps.norm, False).tok
-    ws = fold_ok(h)
-    h = linear(h, ps.proj_in, want_stats=ws)
+    with plan_batch_scale(2 if dup else 1):
+        h = gn(Act(x_in, act.N, act.H, act.W, gs=act.gs if act.tok2 is None else None), ps.norm, False).tok
+        ws = fold_ok(h)
+        h = linear(h, ps.proj_in, want_stats=ws)
     h, st = h if ws else (h, None)
+    if dup:
+        assert st_dup_ok(ps)
+        x_in = dup2(x_in)
+        act = Act(x_in, 2 * act.N, act.H, act.W)
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
-        h, st = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=i + 1 < len(ps.blocks))
+        h, st = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=i + 1 < len(ps.blocks),
+                                  dup=dup and i == 0)
     want = gn_fuse_ok(h)
     y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want)
     y, gs = y if want else (y, None)

@@ -29,6 +29,23 @@ TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile
 _tile_cache = None
 
 
+# Plan GEMMs as if the batch were `scale` times larger (the shared prefix of a CFG batch runs on half the samples but must
+# form every partial sum exactly like the full batch would: same tile, same split-K, same statistics partials).
+_PLAN_BATCH_SCALE = [1]
+
+
+class plan_batch_scale:
+    def __init__(self, scale):
+        self.scale = int(scale)
+
+    def __enter__(self):
+        self.prev = _PLAN_BATCH_SCALE[0]
+        _PLAN_BATCH_SCALE[0] = self.scale
+
+    def __exit__(self, *exc):
+        _PLAN_BATCH_SCALE[0] = self.prev
+
+
 def tile_key(M, N, K, taps=1, stride=1, up=0, geglu=False, concat=False, asym=False, gelu=False, ln=False, stats=False):
     return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (M, N, K, taps, stride, up, int(geglu), int(concat), int(asym),
                                                       int(gelu), int(ln), int(stats))
@@ -221,8 +238,15 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum = _p(st_in), st_in.shape[1], float(eps), _p(colsum)
     st = _stream()
     if tile_m == 0 and tile_n == 0 and splits == 0:
-        key = tile_key(M, Nw, wt.shape[1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
+        scale = _PLAN_BATCH_SCALE[0]
+        key = tile_key(M * scale, Nw, wt.shape[1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
+        if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
+            a.B = B * scale
+            plan = (ctypes.c_int32 * 4)()
+            lib.lr_gemm_plan(a, plan)
+            a.B = B
+            best = tuple(plan)
         if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)
             tile_cache()[key] = best

@@ -100,6 +100,46 @@ def test_sample_is_deterministic_and_graph_reused():
     assert len(m.model.diffusion_model._graphs) >= 1
 
 
+def test_sampler_shared_prefix_matches_full_cfg(monkeypatch):
+    """DDIMSampler sets UNetModel.cfg_shared_prefix for its [x; x] CFG batches when the non-context conditioning of uncond
+    and cond is identical: same samples, bit for bit, as with LEFTREFILL_CFG_SHARED_PREFIX=0; and it does NOT set it when
+    c_concat differs between the two."""
+    dev = torch.device("cuda:0")
+    m, cfg = model(dev)
+    B, h, w = 2, 8, 16
+    x_T = G.T("shp.x_T", (B, 4, h, w)).to(dev)
+    cond = {"c_concat": [G.T("shp.cc", (B, 5, h, w)).to(dev)], "c_crossattn": [G.T("shp.c", (B, 77, cfg.context_dim)).to(dev)]}
+    uc = {"c_concat": [cond["c_concat"][0].clone()], "c_crossattn": [G.T("shp.uc", (B, 77, cfg.context_dim)).to(dev)]}
+    unet = m.model.diffusion_model
+    seen = []
+    orig = unet._run_plan
+
+    def spy(x, t, c, kv=None, shared_prefix=False):
+        seen.append(bool(shared_prefix))
+        return orig(x, t, c, kv, shared_prefix)
+    unet._run_plan = spy
+    try:
+        outs = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("LEFTREFILL_CFG_SHARED_PREFIX", flag)
+            unet._graphs.clear()
+            seen.clear()
+            outs[flag], _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=5, eta=0.0, x_T=x_T,
+                                         unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+            assert seen and all(s_ == (flag == "1") for s_ in seen), (flag, seen)
+        assert torch.equal(outs["1"], outs["0"])
+        monkeypatch.setenv("LEFTREFILL_CFG_SHARED_PREFIX", "1")
+        uc2 = {"c_concat": [cond["c_concat"][0] + 0.5], "c_crossattn": uc["c_crossattn"]}
+        unet._graphs.clear()
+        seen.clear()
+        m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=4, eta=0.0, x_T=x_T, unconditional_guidance_scale=2.5,
+                     unconditional_conditioning=uc2)
+        assert seen and not any(seen)
+    finally:
+        unet._run_plan = orig
+        unet._graphs.clear()
+
+
 def test_log_images_end_to_end_glue():
     """RefInpaintLDM.log_images (ref_inpainting_ldm.py:37-72): VAE encode of image / masked image, nearest mask
     down-sampling, channel order [z | mask | masked latent], unconditional prompt, 50->5 step CFG sampling, VAE decode.
