@@ -16,12 +16,21 @@ from collections import defaultdict
 
 
 def family(name):
-    for key in ("gemm_conv_pipe_kernel<256, 8, 320, 2, 2", "gemm_conv_pipe_kernel<256, 8, 256, 2, 2", "gemm_conv_pipe_kernel",
-                "gemm_conv_kernel",
-                "attention_kernel<true", "attention_kernel<false", "gn_apply", "gn_stats", "layernorm", "splitk_reduce",
-                "transpose_v"):
+    # (rocprofv3 reports mangled names for templates: ILi256ELi8ELi320ELi2ELi2E... = <256, 8, 320, 2, 2, ...>)
+    for mangled, label in (("gemm_conv_pipe_kernelILi256ELi8ELi320ELi2ELi2ELi0", "gemm_conv_pipe_kernel<256,8,320,2,2> (wave tile 128x80)"),
+                           ("gemm_conv_pipe_kernelILi256ELi8ELi320ELi4ELi2ELi1", "gemm_conv_pipe_kernel<256,8,320,4,2,GEGLU>"),
+                           ("gemm_conv_pipe_kernelILi256ELi8ELi256", "gemm_conv_pipe_kernel<256,8,256,2,2>"),
+                           ("gemm_conv_pipe_kernelILi256ELi8ELi160", "gemm_conv_pipe_kernel<256,8,160,4,3>"),
+                           ("gemm_conv_pipe_kernelILi256ELi8ELi128", "gemm_conv_pipe_kernel<256,8,128,4,3>"),
+                           ("gemm_conv_pipe_kernelILi128", "gemm_conv_pipe_kernel<128,4,*,2,4> (4-stage)")):
+        if mangled in name:
+            return label
+    for key in ("gemm_conv_pipe_kernel", "gemm_conv_kernel", "gn_apply", "gn_stats", "gn_finalize", "layernorm", "splitk_reduce", "transpose_v"):
         if key in name:
             return key
+    if "attention_kernel" in name:      # attention_kernel<T, VT, CAUSAL>
+        vt = ", true," in name or "_Lb1ELb" in name
+        return "attention_kernel (V^T by LDS-DMA)" if vt else "attention_kernel (V transposed in registers)"
     return None
 
 
