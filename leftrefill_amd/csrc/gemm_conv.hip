@@ -572,11 +572,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //                        L2->LDS traffic per flop than 256 x 160; 2-stage ring (144 KB); N = 320 is ONE tile wide.
 //   <256, 8, 256, 2, 2>: wave tile 128 x 64 for N = 256 / 512 (the VAE's widths) and the GEGLU projections;
 //   <256, 8, 320, 4, 2>: wave tile 64 x 160 (even number of N tiles per wave, needed by the GEGLU u|g pairing).
-//   <128, 4, 128, 2, 4>, <128, 4, 160, 2, 4>: the small-M levels (M = 4096 / 1024 rows: 128 x 160 tiles of
-//                        4096 x 1280 are exactly 256 blocks).  Wave tile 64 x BN/2 as above, but the block's K-step is
-//                        only 2.6 MFLOP, so the loads run THREE K-steps ahead (4-stage ring, 147 KB): with the 2-stage
-//                        ring of gemm_conv_kernel every K-step of these shapes waits out a full L2/HBM latency
-//                        (measured 32 us for 13.4 GFLOP whatever the tile).
+//   <128, 8, 128, 4, 4>, <128, 8, 160, 4, 4>: the small-M levels (M = 4096 / 1024 rows: 128 x 160 tiles of
+//                        4096 x 1280 are exactly 256 blocks).  The block's K-step is only 2.6 MFLOP, so the loads run
+//                        THREE K-steps ahead (4-stage ring, 147 KB, one block per CU) and the 8 waves (4 x 2, wave tile
+//                        32 x BN/2) give every SIMD two waves to overlap ds_reads, LDS-DMA issue and MFMAs -- with the
+//                        2-stage ring of gemm_conv_kernel every K-step of these shapes waits out a full memory latency,
+//                        and a 4-wave version of this instance spent 2080 cycles per K-step for 680 cycles of MFMA.
 template <int BM2, int NW, int BN, int WMW, int NSTAGE, int MODE, typename T>
 __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1055,8 +1056,8 @@ extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
 }
 
 // rows per wave tile of the instance that serves tile (tm, tn): the row-block size of gn_stats_out
-static int tile_wave_rows(int tm, int tn, int geglu) {
-  if (tm == 128) return 64;
+static int tile_wave_rows(int tm, int tn, int geglu, int stages = 0) {
+  if (tm == 128) return choose_stages(tm, tn, stages) == 4 ? 32 : 64;     // 4-stage instance: 8 waves as 4 x 2, wave tile 32 x BN/2
   if (tn == 256) return 128;
   if (tn == 320) return geglu ? 64 : 128;
   return 64;   // 256 x {128, 160}: 4 x 2 waves
@@ -1070,7 +1071,7 @@ extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
   const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
   if (splits > 1) return RED_ROWS;     // the statistics come out of the split-K reduce kernel
-  return tile_wave_rows(tm, tn, a->geglu == 1);
+  return tile_wave_rows(tm, tn, a->geglu == 1, a->stages);
 }
 
 extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
@@ -1168,8 +1169,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (a->stages != 0 && a->stages != choose_stages(tm, tn, a->stages)) return LR_E_UNSUPPORTED;
   const bool deep = tm == 128 && choose_stages(tm, tn, a->stages) == 4;
   if (mode == 0) {
-    if (deep && tn == 128) rc = launch_pipe<128, 4, 128, 2, 4, 0>(P, st);
-    else if (deep && tn == 160) rc = launch_pipe<128, 4, 160, 2, 4, 0>(P, st);
+    if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 0>(P, st);
+    else if (deep && tn == 160) rc = launch_pipe<128, 8, 160, 4, 4, 0>(P, st);
     else if (tm == 128 && tn == 128) rc = launch_gemm<128, 0>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 0>(P, st);
     else if (tm == 128 && tn == 160) rc = launch_gemm<160, 0>(P, st);
@@ -1179,7 +1180,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     else if (tm == 256 && tn == 320) rc = launch_gemm256<320, 2, 2, 0>(P, st);                 // wave tile 128 x 80
     else return LR_E_UNSUPPORTED;
   } else if (mode == 1) {
-    if (deep && tn == 128) rc = launch_pipe<128, 4, 128, 2, 4, 1>(P, st);
+    if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 1>(P, st);
     else if (tm == 128 && tn == 128) rc = launch_gemm<128, 1>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 1>(P, st);
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 1>(P, st);
