@@ -32,6 +32,9 @@ typedef uint16_t lr_half;  /* 16-bit activation / weight element: IEEE binary16 
  * lr_<op> (lr_<op>_f16) and read / write bfloat16 (declared at the end of this header); lr_gemm_args carries a `dtype` field. */
 #define LR_DTYPE_F16 0
 #define LR_DTYPE_BF16 1
+/* lr_gemm_args.pipe */
+#define LR_PIPE_DEFAULT 0
+#define LR_PIPE_W8_DEEP 4
 
 /* ABI version; bump on any signature change. */
 int lr_abi_version(void);
@@ -135,13 +138,15 @@ typedef struct lr_gemm_args {
    * Fixed order, no atomics.  Not with GEGLU. */
   float* gn_stats_out;
   int32_t dtype;            /* LR_DTYPE_F16 | LR_DTYPE_BF16: type of p1, p2, wt, rowvec, resid, out (geglu == 2 is fp16 only) */
-  int32_t stages;           /* depth of the LDS ring: 0 = the tile's default (tile_m 128: 2; 256 x {128,160}: 3; 256 x {256,320}: 2);
-                             * 4 with tile_m 128, tile_n 128 | 160 selects the 4-stage one-block-per-CU instance (small-M levels);
-                             * any other non-default value: LR_E_UNSUPPORTED */
+  int32_t pipe;             /* pipeline variant of the tile: LR_PIPE_DEFAULT (0) = the tile's standard instance (tile_m 128: 4 waves,
+                             * 2-stage ring, 2-4 blocks per CU; 256 x {128,160}: 3-stage ring; 256 x {256,320}: 2-stage ring).
+                             * LR_PIPE_W8_DEEP (4), tile_m 128 with tile_n 128 | 160: 8 waves (4 x 2, wave tile 32 x tile_n/2), 4-stage
+                             * ring, one block per CU (the 4096- / 1024-row levels).
+                             * Anything else: LR_E_UNSUPPORTED */
 } lr_gemm_args;
 /* rows per block of gn_stats_out (a function of the tile that will be used) */
 int lr_gemm_gn_rows(const lr_gemm_args* args);
-/* plan[0..3] = (tile_m, tile_n, splits, stages) the call would use: explicit requests as given, zeros resolved by the static
+/* plan[0..3] = (tile_m, tile_n, splits, pipe) the call would use: explicit requests as given, zeros resolved by the static
  * heuristics (a pure function of the shape -- never of timing; the Python front end ships its tuned choices as a table). */
 int lr_gemm_plan(const lr_gemm_args* args, int32_t* plan);
 /* number of per-row partials this call writes to stats_out (a function of N and the tile that will be used) */

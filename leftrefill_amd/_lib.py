@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -37,7 +37,7 @@ class GemmArgs(ctypes.Structure):
         ("stats_out", c_void_p),
         ("gn_stats_out", c_void_p),
         ("dtype", ctypes.c_int32),
-        ("stages", ctypes.c_int32),
+        ("pipe", ctypes.c_int32),
     ]
 
 

@@ -1028,8 +1028,11 @@ static int choose_splits(int M, int N, int K, int tm, int tn, int geglu, int sta
   return s < 1 ? 1 : s;
 }
 
-// ring depth of the instance that serves tile (tm, tn): 128-row tiles come as the 2-stage 4-wave kernel (several blocks
-// per CU cover each other's waits) and, for tn = 128 | 160, as the 4-stage one (one block per CU, loads three K-steps ahead)
+// pipeline variant (lr_gemm_args.pipe) of the instance that serves tile (tm, tn): for 128-row tiles 2 = the 4-wave 2-stage
+// kernel (several blocks per CU cover each other's waits) and, for tn = 128 | 160, LR_PIPE_W8_DEEP (4: 8 waves, 4-stage ring,
+// one block per CU, loads three K-steps ahead); for 256-row tiles the ring depth of the only instance.
+// (An 8-wave 2-stage variant with two blocks per CU was measured too: 2-3 us faster on the short-K linears in isolation,
+// no difference in the step -- not kept.)
 static int choose_stages(int tm, int tn, int stages) {
   if (tm == 128) return (stages == 4 && (tn == 128 || tn == 160)) ? 4 : 2;
   return (tn == 128 || tn == 160) ? 3 : 2;
@@ -1050,14 +1053,14 @@ extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
   plan[0] = tm; plan[1] = tn;
-  plan[2] = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
-  plan[3] = choose_stages(tm, tn, a->stages);
+  plan[2] = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
+  plan[3] = choose_stages(tm, tn, a->pipe);
   return 0;
 }
 
 // rows per wave tile of the instance that serves tile (tm, tn): the row-block size of gn_stats_out
 static int tile_wave_rows(int tm, int tn, int geglu, int stages = 0) {
-  if (tm == 128) return choose_stages(tm, tn, stages) == 4 ? 32 : 64;     // 4-stage instance: 8 waves as 4 x 2, wave tile 32 x BN/2
+  if (tm == 128) return choose_stages(tm, tn, stages) == 4 ? 32 : 64;     // 8-wave instance: 4 x 2 waves, wave tile 32 x BN/2
   if (tn == 256) return 128;
   if (tn == 320) return geglu ? 64 : 128;
   return 64;   // 256 x {128, 160}: 4 x 2 waves
@@ -1069,9 +1072,9 @@ extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
   const int M = a->B * a->H * a->W;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
-  const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
+  const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
   if (splits > 1) return RED_ROWS;     // the statistics come out of the split-K reduce kernel
-  return tile_wave_rows(tm, tn, a->geglu == 1, a->stages);
+  return tile_wave_rows(tm, tn, a->geglu == 1, a->pipe);
 }
 
 extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
@@ -1087,7 +1090,7 @@ extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
-  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->stages);
+  int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
   return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
@@ -1134,7 +1137,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(P.M, P.N, P.geglu || P.gelu, &tm, &tn);
   int splits = a->splits;
-  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu, a->stages);
+  if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu, a->pipe);
   if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
   if (splits > 1) {
     const int64_t need = (int64_t)splits * P.M * P.N * (int64_t)sizeof(float);
@@ -1166,11 +1169,12 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   hipStream_t st = (hipStream_t)s;
   int rc;
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
-  if (a->stages != 0 && a->stages != choose_stages(tm, tn, a->stages)) return LR_E_UNSUPPORTED;
-  const bool deep = tm == 128 && choose_stages(tm, tn, a->stages) == 4;
+  if (a->pipe != 0 && a->pipe != choose_stages(tm, tn, a->pipe)) return LR_E_UNSUPPORTED;
+  const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
   if (mode == 0) {
     if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 0>(P, st);
     else if (deep && tn == 160) rc = launch_pipe<128, 8, 160, 4, 4, 0>(P, st);
+
     else if (tm == 128 && tn == 128) rc = launch_gemm<128, 0>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 0>(P, st);
     else if (tm == 128 && tn == 160) rc = launch_gemm<160, 0>(P, st);

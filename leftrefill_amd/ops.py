@@ -22,7 +22,8 @@ GN_CHUNKS = 256
 # LEFTREFILL_AUTOTUNE=1 is a developer mode: unknown shapes are timed on first sight and added to the in-memory table
 # (dump it with tile_cache()); it is never on by default.
 AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "0") == "1"
-# (tile_m, tile_n, stages): stages 0 = the tile's default LDS ring depth, 4 = the deep one-block-per-CU 128-row instance
+# (tile_m, tile_n, pipe): pipe 0 = the tile's standard instance; 4 = the 8-wave 4-stage one-block-per-CU 128-row instance
+# (lr_gemm_args.pipe)
 TILE_CANDIDATES = ((128, 64, 0), (128, 128, 0), (128, 160, 0), (128, 128, 4), (128, 160, 4), (256, 128, 0), (256, 160, 0),
                    (256, 256, 0), (256, 320, 0))
 TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
@@ -182,7 +183,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
-              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, stages=0, ln=None,
+              resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, pipe=0, ln=None,
               want_stats=False, want_gn_stats=False):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
 
@@ -226,7 +227,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.tile_n = tile_n
     a.tile_m = tile_m
     a.splits = splits
-    a.stages = stages
+    a.pipe = pipe
     a.workspace, a.workspace_bytes = 0, 0
     a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
@@ -252,7 +253,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             tile_cache()[key] = best
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
-            a.stages = best[3] if len(best) > 3 else 0
+            a.pipe = best[3] if len(best) > 3 else 0
     stats = None
     if want_stats:
         if a.splits == 0:
@@ -279,7 +280,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
 
 
 def gemm_plan(M, N, K, **kw):
-    """(tile_m, tile_n, splits, stages) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
+    """(tile_m, tile_n, splits, pipe) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
     best = tile_cache().get(tile_key(M, N, K, **kw))
     if best is not None:
         return tuple(best) if len(best) > 3 else tuple(best) + (0,)
@@ -324,7 +325,7 @@ def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
     for tm, tn, stg in TILE_CANDIDATES:
         if geglu and tn == 160:
             continue
-        a.tile_m, a.tile_n, a.splits, a.stages = tm, tn, 0, stg
+        a.tile_m, a.tile_n, a.splits, a.pipe = tm, tn, 0, stg
         lib.lr_gemm_plan(a, plan)
         cands = {1} if no_split else {1, int(plan[2])}
         for sp in sorted(cands):

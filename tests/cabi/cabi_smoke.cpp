@@ -14,7 +14,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 2; } } while (0)
 
 int main() {
-  if (lr_abi_version() < 14) { printf("unexpected ABI version %d\n", lr_abi_version()); return 1; }
+  if (lr_abi_version() < 15) { printf("unexpected ABI version %d\n", lr_abi_version()); return 1; }
   const int M = 300, C = 128;
   std::vector<__half> hx(M * C), hw(C * C), hr(M * C), hy(M * C), hz(M * C);
   std::vector<float> hb(C), hg(C, 1.0f), hbeta(C, 0.0f);

@@ -281,12 +281,12 @@ def test_conv_golden_cases(golden):
         report("golden " + name, from_tok(y, N, H, W), torch.from_numpy(g[name]), rtol=4e-3, atol=4e-3)
 
 
-# (tile_m, tile_n[, stages]): every GEMM instance; stages 4 = the deep-ring 128-row kernel
+# (tile_m, tile_n[, pipe]): every GEMM instance; pipe 4 = the 8-wave 4-stage 128-row kernel
 ALL_TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320), (128, 128, 4), (128, 160, 4)]
 
 
 def tile_kw(t):
-    return dict(tile_m=t[0], tile_n=t[1], stages=t[2] if len(t) > 2 else 0)
+    return dict(tile_m=t[0], tile_n=t[1], pipe=t[2] if len(t) > 2 else 0)
 
 
 @pytest.mark.parametrize("tile", ALL_TILES, ids=lambda t_: "x".join(map(str, t_)))
@@ -693,7 +693,7 @@ def test_gemm_conv_randomised_shapes():
             y = ops.gemm_conv(to_tok(x[:, :C1]), wp, B=B, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym,
                               x2=to_tok(x[:, C1:]) if C2 else None, bias=b.to(d) if use_bias else None,
                               rowvec=rv.half().to(d) if use_rv else None, resid=to_tok(rs) if use_res else None,
-                              tile_m=tm, tile_n=tn, splits=splits, stages=stg)
+                              tile_m=tm, tile_n=tn, splits=splits, pipe=stg)
         except RuntimeError as e:        # an explicit split request that the shape cannot honour is an argument error
             assert splits > 1 and "gemm_conv" in str(e), (case, str(e))
             continue

@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leftrefill_amd import ops  # noqa: E402
 
-TILES = list(ops.TILE_CANDIDATES)     # (tile_m, tile_n, stages)
+TILES = list(ops.TILE_CANDIDATES)     # (tile_m, tile_n, pipe)
 # name, M, N, K, taps, flags
 SHAPES = [
     ("l0 KC resid+stats", 65536, 320, 320, 1, dict(resid=1, stats=1)),
@@ -65,7 +65,7 @@ def make_case(M, N, K, taps, fl, dev, nsets):
     rv = torch.randn(B, N, device=dev).half() if fl.get("rowvec") else None
 
     def launch(d, tm, tn, sp, stg=0):
-        return ops.gemm_conv(d["x"], w, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp, stages=stg,
+        return ops.gemm_conv(d["x"], w, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp, pipe=stg,
                              geglu=bool(fl.get("geglu")), resid=d.get("resid"), rowvec=rv,
                              ln=(d["st"], 1e-5, cs) if fl.get("ln") else None, want_stats=bool(fl.get("stats")))
     return sets, launch
