@@ -96,6 +96,20 @@ def sample_once(model, batch, B, steps=S_DDIM):
     return samples
 
 
+def eager_unet_step(unet, x, t, ctx, hook=None):
+    """One UNet forward with the launches of the captured step, eagerly: the cross-attention K / V projections of the
+    (constant) context come from `_context_kv` like in the hipGraph path -- computed BEFORE `hook()` arms the instrumentation,
+    so the measured launches are exactly those a DDIM step replays."""
+    unet.prepare()
+    x = x.float().contiguous()
+    t = t.to(torch.int64).contiguous()
+    ctx = ctx.to(unet.compute_dtype).contiguous()
+    kv = unet._context_kv(ctx)
+    if hook is not None:
+        hook()
+    return unet._run_plan(x, t, ctx, kv)
+
+
 def kernel_roofline(model, batch, B, dump=None):
     """One instrumented eager UNet step: HIP events around every gemm_conv / attention launch on the launch stream."""
     from leftrefill_amd import ops
@@ -126,12 +140,14 @@ def kernel_roofline(model, batch, B, dump=None):
 
     unet.use_hip_graph = False
     try:
-        for _ in range(2):
+        def arm():
             for k in rec:
                 rec[k].clear()
             ops.gemm_conv, ops.attention = wrap("gemm_conv"), wrap("attention")
+        for _ in range(2):
+            ops.gemm_conv, ops.attention = orig["gemm_conv"], orig["attention"]
             with torch.no_grad():
-                unet(x, t, ctx)
+                eager_unet_step(unet, x, t, ctx, hook=arm)
             torch.cuda.synchronize()
     finally:
         ops.gemm_conv, ops.attention = orig["gemm_conv"], orig["attention"]
@@ -359,7 +375,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
                                    
                                    "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
                        "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
-            "forward_only_ms": fwd_ms, "final_loss": float(loss), "peak_memory_gib": peak_gb,
+            "forward_only_ms": fwd_ms, "final_loss": float(loss.detach()), "peak_memory_gib": peak_gb,
             "recompute_in_backward": bool(getattr(a, "recompute", False)), "hip_graph": graph is not None,
             "loss_scale": scaler["scale"], "skipped_steps": scaler["skipped"]}
 
