@@ -603,9 +603,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
 
   // XCD-aware bijective remap: hardware block b lives on XCD b & 7; XCD x owns the contiguous logical tiles
   // [t_begin, t_begin + t_cnt) (shared A rows / halos stay in its L2).
-  // (A persistent variant -- min(tiles, CUs) blocks walking the tiles and prefetching the next tile's first stages under
-  // the epilogue -- was built and measured in round 2: slower on every shape, e.g. the level-0 GEGLU projection 220 vs
-  // 184 us; the next tile's gather state has to stay live across an epilogue that already sits at the 256-VGPR limit.)
+  // (Persistent variants were built and measured twice in round 2.  (1) min(tiles, CUs) blocks that prefetch the next
+  // tile's first stages between main loop and epilogue: slower on every shape (level-0 GEGLU 220 vs 184 us; the next
+  // tile's gather state stays live across an epilogue at the 256-VGPR limit, and the tile start drained the stores).
+  // (2) ONE continuous LDS ring over a block's tiles -- the refill slots of a tile's last K-steps take the next tile's
+  // first stages, the gather state is switched in place, stores stay in flight across the boundary; bit-identical, no
+  // spills on 256 x {128, 256}: level-0 GEGLU 181 vs 184 us (256 x 256), 203 vs 213 (256 x 128), levels 1 / 2 +-1 %.
+  // The prologue is not what these short-K tiles wait for; neither variant was kept.)
   const int xcd = blockIdx.x & 7;
   const int q8 = P.nblocks >> 3, r8 = P.nblocks & 7;
   const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;

@@ -384,6 +384,36 @@ def test_groupnorm_statistics_from_gemm_epilogue(tile):
     report(name + " gn(single)", from_tok(out1, N, H, W), ref1)
 
 
+@pytest.mark.parametrize("M,C", [(10240, 320), (9000, 640)])
+def test_geglu_many_tiles_agree_bitwise(M, C):
+    """GEGLU projections with more tiles than CUs (several tile waves per launch): every 256-row instance gives the bits of
+    the 128 x 128 tile, with and without the LayerNorm fold, ragged M.  (Also the regression test of the persistent
+    continuous-ring variant that was measured in round 2 and not kept.)"""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    x = h16(G.T(f"gps.x{C}", (M, C)) * 1.5 + 0.2)
+    w = h16(torch.from_numpy(weights.fill_like(f"gps.w{C}", (8 * C, C))))
+    b = torch.from_numpy(weights.fill_like(f"gps.b{C}", (8 * C,)))
+    gam = 1.0 + 0.3 * G.T("gps.g", (C,))
+    bet = 0.2 * G.T("gps.be", (C,))
+    wp, bp = packing.pack_geglu(w, b)
+    wf, bf, cs = packing.fold_layernorm(w, b, gam, bet)
+    perm = packing.geglu_perm(4 * C)
+    xd = x.half().to(d)
+    st = torch.stack([x.sum(1), (x * x).sum(1)], dim=1).reshape(M, 1, 2).contiguous().to(d)
+    ref = ops.gemm_conv(xd, wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=128, tile_n=128)
+    ref_ln = ops.gemm_conv(xd, wf[perm].contiguous().to(d), B=1, H=1, W=M, taps=1, bias=bf[perm].contiguous().to(d), geglu=True,
+                           ln=(st, 1e-5, cs[perm].contiguous().to(d)), tile_m=128, tile_n=128)
+    for tn in (128, 256, 320):
+        y = ops.gemm_conv(xd, wp.to(d), B=1, H=1, W=M, taps=1, bias=bp.to(d), geglu=True, tile_m=256, tile_n=tn)
+        assert torch.equal(y, ref), f"256x{tn}"
+        y = ops.gemm_conv(xd, wf[perm].contiguous().to(d), B=1, H=1, W=M, taps=1, bias=bf[perm].contiguous().to(d), geglu=True,
+                          ln=(st, 1e-5, cs[perm].contiguous().to(d)), tile_m=256, tile_n=tn)
+        assert torch.equal(y, ref_ln), f"256x{tn} ln"
+    u, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    report(f"geglu many tiles {M}x{C}", ref[:2048], (u * F.gelu(gate))[:2048])
+
+
 def test_groupnorm_statistics_from_splitk_reduce():
     """A split-K producer hands the GroupNorm statistics over from its reduce kernel (32-row blocks of the rounded output):
     block sums match the stored tensor, the output equals the unsplit GEMM's bit for bit, GroupNorm matches F.group_norm."""
