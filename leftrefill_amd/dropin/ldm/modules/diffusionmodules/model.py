@@ -1,10 +1,12 @@
-"""KL-VAE encoder / decoder (host-side PyTorch-ROCm code; NOT on the HIP hot path).
+"""KL-VAE encoder / decoder modules with the reference's class names and state-dict keys
+(ldm/modules/diffusionmodules/model.py: Upsample 51-66, Downsample 69-88, ResnetBlock 91-150, AttnBlock 153-204,
+Encoder 453-544, Decoder 547-653) so `first_stage_config` instantiates and the SD2 VAE weights (`first_stage_model.*`,
+248 tensors) load.
 
-The north star keeps VAE encode/decode on PyTorch-ROCm; this module only has to exist with the reference's class names
-and state-dict keys (ldm/modules/diffusionmodules/model.py: Upsample 51-66, Downsample 69-88, ResnetBlock 91-150,
-AttnBlock 153-204, Encoder 453-544, Decoder 547-653) so `first_stage_config` instantiates and the SD2 VAE weights
-(`first_stage_model.*`, 248 tensors) load.  Moving the decoder onto the conv / GroupNorm / attention HIP kernels is the
-first "next" row.
+These nn.Modules hold the parameters and define the PyTorch formulation; on a HIP device `AutoencoderKL.encode / decode`
+run `leftrefill_amd/vae_engine.py` (the same implicit-GEMM conv / GroupNorm / attention kernels as the UNet step, SURVEY.md
+section 8f-1) on the weights packed from them.  The module `forward`s below are the host-side formulation the north star
+leaves on PyTorch-ROCm: they serve CPU tensors, autograd through the VAE, and `use_hip=False`.
 """
 import torch
 import torch.nn as nn
