@@ -71,6 +71,41 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lr_attn_bwd_args), offset
     assert [int(v) for v in out] == got
 
 
+def test_gemm_plan_is_a_pure_function_of_the_shape():
+    """Tile / split-K / pipeline selection never depends on timing: the committed table (tile_table.json) answers the shapes
+    of the shipped workloads, the library's static heuristic (lr_gemm_plan, host code -- no GPU needed) everything else;
+    `plan_batch_scale` plans a half batch exactly like the full one (the shared CFG prefix relies on it)."""
+    import ctypes
+    import json
+    from leftrefill_amd import _lib, ops
+    assert not ops.AUTOTUNE
+    table = json.load(open(ops.TILE_TABLE_PATH))
+    assert len(table) >= 200
+    valid = {(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)}
+    for key, plan in table.items():
+        assert len(key.split(",")) == 12 and (plan[0], plan[1]) in valid and plan[2] >= 1, (key, plan)
+        assert (plan[3] if len(plan) > 3 else 0) in (0, 4) and (len(plan) < 4 or plan[3] == 0 or (plan[0] == 128 and plan[1] in (128, 160)))
+        M, N, K, taps, stride, up, geglu, cat, asym, gelu, ln, stats = map(int, key.split(","))
+        got = ops.gemm_plan(M, N, K, taps=taps, stride=stride, up=up, geglu=bool(geglu), concat=bool(cat), asym=bool(asym),
+                            gelu=bool(gelu), ln=bool(ln), stats=bool(stats))
+        assert tuple(got[:3]) == tuple(plan[:3])
+    # untabulated shapes: the heuristic, twice the same answer, and a sane one
+    lib = _lib.load()
+    for M, N, K in ((777, 192, 1088), (3000, 320, 2880), (50000, 640, 5760), (96, 1280, 23040)):
+        p1, p2 = ops.gemm_plan(M, N, K), ops.gemm_plan(M, N, K)
+        assert p1 == p2 and (p1[0], p1[1]) in valid and 1 <= p1[2] <= 8, (M, N, K, p1)
+    # the plan of a scaled batch is the plan of the larger shape
+    a = _lib.GemmArgs()
+    a.B, a.H, a.W, a.N, a.taps, a.C1 = 4, 64, 128, 320, 9, 320
+    small, big = (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 4)()
+    lib.lr_gemm_plan(a, small)
+    a.B = 8
+    lib.lr_gemm_plan(a, big)
+    with ops.plan_batch_scale(2):
+        assert ops._PLAN_BATCH_SCALE[0] == 2
+    assert ops._PLAN_BATCH_SCALE[0] == 1 and tuple(big)[:2] in valid and tuple(small)[:2] in valid
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from leftrefill_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
