@@ -276,17 +276,28 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     const float inv = 1.0f / lt;
     if (P.lse && hi == 0 && qrow[qb] < P.Nq)
       P.lse[((size_t)b * P.heads + h) * P.Nq + qrow[qb]] = fmaf(m_run[qb], P.c, __builtin_amdgcn_logf(lt));
-    if (qrow[qb] < P.Nq) {
+    // The two half-waves of a query (lane, lane ^ 32) hold the two 4-channel halves of every 8-channel group: one
+    // v_permlane32_swap per dword hands group g to the lower and group g + 1 to the upper half-wave, so each lane stores
+    // 16 contiguous bytes (8 x dwordx4 per lane instead of 16 x dwordx2: the store tail is issue-bound, and it is most of
+    // the kernel for the 77-key cross-attention).
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          vec4<T> ov;
+      for (int g = 0; g < 4; g += 2) {
+        vec4<T> x, y;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ov[i] = (T)(oacc[qb][db][g * 4 + i] * inv);
-          *reinterpret_cast<vec4<T>*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * g + 4 * hi) = ov;
+        for (int i = 0; i < 4; ++i) {
+          x[i] = (T)(oacc[qb][db][g * 4 + i] * inv);
+          y[i] = (T)(oacc[qb][db][(g + 1) * 4 + i] * inv);
         }
-    }
+        const uint2 xu = __builtin_bit_cast(uint2, x), yu = __builtin_bit_cast(uint2, y);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(xu.x, yu.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(xu.y, yu.y, false, false);
+        // lower half-wave: (x.lo, x.hi) = channels 8 g .. 8 g + 7 ; upper half-wave: (y.lo, y.hi) = 8 (g + 1) .. + 7
+        const uint4 o4 = make_uint4((unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]);
+        if (qrow[qb] < P.Nq)
+          *reinterpret_cast<uint4*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * (g + hi)) = o4;
+      }
   }
 }
 
@@ -295,8 +306,8 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
                             int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt,
                             float* lse = nullptr) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nkv <= 0) return LR_E_ARG;
-  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return LR_E_ALIGN;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return LR_E_ALIGN;
   if (vt && (ldv % ATT_KB || ldv < Nkv)) return LR_E_ALIGN;
   AttnParams<T> P;
   P.q = (const T*)q; P.k = (const T*)k; P.v = (const T*)v; P.o = (T*)o;
@@ -321,8 +332,8 @@ template <typename T>
 static int lr_attention_causal_t(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv,
                                        lr_half* o, int ldo, int B, int heads, int N, float scale, lr_stream_t s) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || N <= 0) return LR_E_ARG;
-  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LR_E_ALIGN;
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return LR_E_ALIGN;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return LR_E_ALIGN;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return LR_E_ALIGN;
   AttnParams<T> P;
   P.q = (const T*)q; P.k = (const T*)k; P.v = (const T*)v; P.o = (T*)o;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
