@@ -119,8 +119,8 @@ def kernel_roofline(model, batch, B, dump=None):
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
-    rec = {"gemm_conv": [], "attention": []}
-    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention}
+    rec = {"gemm_conv": [], "attention": [], "xattn_block": []}
+    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block}
 
     def wrap(name):
         def f(*a, **k):
@@ -132,6 +132,8 @@ def kernel_roofline(model, batch, B, dump=None):
                 desc = dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[0], K=a[1].shape[1], taps=k.get("taps", 1),
                             stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
                             cat=k.get("x2") is not None, resid=k.get("resid") is not None)
+            elif name == "xattn_block":      # fused LayerNorm + to_q + 77-key attention + to_out + residual (level 0)
+                desc = dict(M=a[0].shape[0], C=a[0].shape[1], Lc=k["Lc"], heads=k["heads"])
             else:
                 desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
             rec[name].append((e0, e1, desc))
@@ -143,14 +145,14 @@ def kernel_roofline(model, batch, B, dump=None):
         def arm():
             for k in rec:
                 rec[k].clear()
-            ops.gemm_conv, ops.attention = wrap("gemm_conv"), wrap("attention")
+            ops.gemm_conv, ops.attention, ops.xattn_block = wrap("gemm_conv"), wrap("attention"), wrap("xattn_block")
         for _ in range(2):
-            ops.gemm_conv, ops.attention = orig["gemm_conv"], orig["attention"]
+            ops.gemm_conv, ops.attention, ops.xattn_block = orig["gemm_conv"], orig["attention"], orig["xattn_block"]
             with torch.no_grad():
                 eager_unet_step(unet, x, t, ctx, hook=arm)
             torch.cuda.synchronize()
     finally:
-        ops.gemm_conv, ops.attention = orig["gemm_conv"], orig["attention"]
+        ops.gemm_conv, ops.attention, ops.xattn_block = orig["gemm_conv"], orig["attention"], orig["xattn_block"]
         unet.use_hip_graph = True
     fl = unet_flops(unet, x.shape[2], x.shape[3])
     n = 2 * B
@@ -161,11 +163,20 @@ def kernel_roofline(model, batch, B, dump=None):
         n_out = d["N"] // 2 if d["geglu"] else d["N"]
         gbytes += 2.0 * (src_rows * d["K"] / d["taps"] + d["N"] * d["K"] + d["M"] * n_out * (2 if d["resid"] else 1))
     out = {}
+    # the fused cross-attention block runs two of the UNet's pointwise linears and a 77-key attention: its flops leave the
+    # numerators of the GEMM / attention families (which only count what those kernels still execute)
+    moved = {"gemm": sum(4.0 * d["M"] * d["C"] * d["C"] for _, _, d in rec["xattn_block"]),
+             "attn": sum(4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
         out[name] = {"launches": len(rec[name]), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(rec[name])),
-                     "tflops": n * fl[key] / (ms * 1e-3) / 1e12}
+                     "tflops": (n * fl[key] - moved[key]) / (ms * 1e-3) / 1e12}
+    if rec["xattn_block"]:
+        ms = sum(a.elapsed_time(b) for a, b, _ in rec["xattn_block"])
+        out["xattn_block"] = {"launches": len(rec["xattn_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["xattn_block"]),
+                              "tflops": (moved["gemm"] + moved["attn"]) / (ms * 1e-3) / 1e12}
     out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
+    out["gemm_conv"]["algorithmic_gflop"] = (n * fl["gemm"] - moved["gemm"]) / 1e9
     # per-shape table of this instrumented step (what tools/kernel_table.py prints from --dump-kernels)
     agg = {}
     for name in rec:
@@ -174,6 +185,9 @@ def kernel_roofline(model, batch, B, dump=None):
             if name == "gemm_conv":
                 key = f'gemm {d["M"]}x{d["N"]}x{d["K"]} taps{d["taps"]} s{d["stride"]} up{d["up"]}' + (" geglu" if d["geglu"] else "") + (" cat" if d["cat"] else "")
                 fl_ = 2.0 * d["M"] * d["N"] * d["K"]
+            elif name == "xattn_block":
+                key = f'xattn {d["M"]}x{d["C"]} keys{d["Lc"]} (ln + to_q + attention + to_out + resid)'
+                fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
             else:
                 key = f'attn B{d["B"]} h{d["heads"]} {d["Nq"]}x{d["Nkv"]}'
                 fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
@@ -188,6 +202,8 @@ def kernel_roofline(model, batch, B, dump=None):
                 us = 1e3 * a.elapsed_time(b)
                 if name == "gemm_conv":
                     fl_ = 2.0 * d["M"] * d["N"] * d["K"]
+                elif name == "xattn_block":
+                    fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
                 else:
                     fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
                 rows.append(dict(kernel=name, us=us, tflops=fl_ / us / 1e6, **d))
@@ -575,10 +591,10 @@ def main():
                            "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
                            "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
                            "launches_per_unet_step": g["launches"], "avg_launch_us": g["avg_us"],
-                           "algorithmic_gflop_per_unet_step": 2 * B * fl["gemm"] / 1e9}
+                           "algorithmic_gflop_per_unet_step": g["algorithmic_gflop"]}
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
         res["kernel_table"] = kern.get("table", [])[:48]
-        res["kernels"] = {"attention_kernel": kern["attention"],
+        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"),
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline and a.workload == "single":

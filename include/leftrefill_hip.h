@@ -173,6 +173,33 @@ int lr_attention_vt_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, co
                         int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s);
 
+/* ---- fused cross-attention block (C = 320, 5 heads of 64: level 0 of the SD2 UNet) --------------------------------
+ * replaces: `x = self.attn2(self.norm2(x), context=context) + x` (attention.py:281) = norm2 (LayerNorm, attention.py:272),
+ *           CrossAttention.to_q, softmax(q k^T * d^-0.5) v over the <= 96 context tokens, to_out[0] + bias
+ *           (attention.py:165-196) and the residual add, in ONE launch: x is read once, out written once, q and the attention
+ *           output never leave the registers (instead of LayerNorm-folded to_q GEMM -> attention -> to_out GEMM).
+ *   x, out [M][320]; M = B * HW rows, a block of 128 rows stays inside one sample (M % 128 == 0, HW % 128 == 0).
+ *   wq [320][320] = to_q.weight * gamma (LayerNorm folded along K), bq [320] = to_q.weight @ beta (fp32);
+ *   k  [B * Lc][ldk]: K projection of the context whose columns are permuted inside every head: position 32 p + 8 f + i
+ *      (f < 4, i < 8) holds channel 32 p + 16 (i >> 2) + 4 f + (i & 3) -- project the context with the same permutation
+ *      of to_k.weight's rows;
+ *   vt [B][5][2][64][64]: lr_xattn_pack_vt_f16 of the V projection (transposed, key slots in the same order);
+ *   wo [320][320] = to_out[0].weight with the in-head COLUMNS in that order, bo [320] = to_out[0].bias (fp32);
+ *   stats_out (optional) [M][2]: per-row (sum, sumsq) of the rounded output (lr_gemm_args.ln_stats of the next GEMM, ln_parts = 1).
+ * Anything else (other widths, Lc > 96, ragged M): LR_E_UNSUPPORTED -- callers keep the three-kernel path for those. */
+typedef struct lr_xattn_args {
+  const lr_half* x; lr_half* out;
+  const lr_half* wq; const float* bq;
+  const lr_half* k; int32_t ldk;
+  const lr_half* vt;
+  const lr_half* wo; const float* bo;
+  float* stats_out;
+  int32_t M, HW, C, heads, Lc;
+  float ln_eps, scale;
+} lr_xattn_args;
+int lr_xattn_block_f16(const lr_xattn_args* args, lr_stream_t s);
+int lr_xattn_pack_vt_f16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
+
 /* ---- row softmax of materialised logits (VAE AttnBlock: single head, d_head = C = 512) ---------------------------
  * replaces: `w_ = w_ * (int(c)**(-0.5)); w_ = softmax(w_, dim=2)` (ldm/modules/diffusionmodules/model.py:186-187) between
  *           the two bmm's (185, 192), which run through lr_gemm_conv_f16 (logits = q k^T with wt = k; out = p v with
@@ -279,6 +306,8 @@ int lr_attention_vt_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, c
     o, int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 int lr_transpose_v_bf16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s);
 int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s);
+int lr_xattn_block_bf16(const lr_xattn_args* args, lr_stream_t s);
+int lr_xattn_pack_vt_bf16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -7,8 +7,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 15
+# LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
+LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
+ABI_VERSION = 16
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -46,6 +47,14 @@ class AttnBwdArgs(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "o", "dout", "qt", "kt", "dot", "lse", "dsum", "dq", "dk", "dv")] +
                 [(n, ctypes.c_int32) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "ld_qt", "ld_kt", "lddq", "lddk", "lddv",
                                                "B", "heads", "Nq", "Nkv")] + [("scale", ctypes.c_float)])
+
+
+class XattnArgs(ctypes.Structure):
+    """struct lr_xattn_args (include/leftrefill_hip.h)."""
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("wq", c_void_p), ("bq", c_void_p), ("k", c_void_p), ("ldk", ctypes.c_int32),
+                ("vt", c_void_p), ("wo", c_void_p), ("bo", c_void_p), ("stats_out", c_void_p),
+                ("M", ctypes.c_int32), ("HW", ctypes.c_int32), ("C", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("Lc", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("scale", ctypes.c_float)]
 
 
 # symbol -> argtypes; every function returns int
@@ -87,6 +96,8 @@ SIGNATURES = {
                              c_int, c_float, c_void_p],
     "lr_attention_bwd_f16": [ctypes.POINTER(AttnBwdArgs), c_void_p],
     "lr_transpose_v_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_xattn_block_f16": [ctypes.POINTER(XattnArgs), c_void_p],
+    "lr_xattn_pack_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_ddim_cfg_step": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -98,7 +109,8 @@ BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n"
               "lr_groupnorm_bwd", "lr_nchw_f32_to_nhwc_f16", "lr_nhwc_f16_to_nchw", "lr_timestep_embedding", "lr_linear_small_m",
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
-              "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16"]
+              "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",
+              "lr_xattn_pack_vt_f16"]
 
 
 def twin(name):

@@ -348,10 +348,15 @@ class UNetModel(nn.Module):
         ctx = context.reshape(N * L, D)
         res = []
         for i, pt in enumerate(P["tblocks"]):
-            o, ot = (None, None) if out is None else out[i]
+            o, ot, xk, xvt = (None,) * 4 if out is None else (tuple(out[i]) + (None, None))[:4]
             kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=N * L, taps=1, out=o)
             C = kv.shape[1] // 2
-            res.append((kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot)))   # V^T: the V tile streams by LDS-DMA
+            ent = (kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot))   # V^T: the V tile streams by LDS-DMA
+            if pt.attn2.xk is not None and L <= ops.XATTN_MAX_KEYS:
+                # operands of the fused cross-attention block: K in its k-slot order, V^T pack
+                ent += (ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=N * L, taps=1, out=xk),
+                        ops.xattn_pack_vt(kv[:, C:], N, pt.attn2.heads, L, out=xvt))
+            res.append(ent)
         return res
 
     def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False):

@@ -138,6 +138,10 @@ class PackedAttn:
             self.q = PackedLinear(weight=attn.to_q.weight, norm=norm)
             self.kv = PackedLinear(weight=torch.cat([attn.to_k.weight, attn.to_v.weight], 0))
         self.out = PackedLinear(attn.to_out[0])
+        self.xk = None
+        if not is_self and norm is not None and attn.to_q.weight.shape[0] == ops.XATTN_C:
+            # operands of the fused cross-attention block (lr_xattn_block_f16): to_k rows / to_out columns in its k-slot order
+            self.xk, self.xwo = packing.pack_xattn(attn.to_k.weight.detach(), attn.to_out[0].weight.detach(), compute_dtype())
         self.dim_head = attn.to_q.weight.shape[0] // attn.heads
         if self.dim_head != 64:
             raise RuntimeError(f"attention kernel is specialised for d_head=64 (got {self.dim_head})")
@@ -271,6 +275,13 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv.
     dup: x holds only the first B / 2 samples (the two CFG halves are identical up to here): the query projection runs
     once, then x and q are duplicated for the B contexts."""
+    if (XATTN and kv is not None and len(kv) > 2 and fold_ok(x)
+            and ops.xattn_ok(B * L, L, x.shape[1], pa.heads, Lc)):
+        # one launch: LayerNorm + to_q + attention + to_out + residual (+ the row statistics of the next LayerNorm)
+        if dup:
+            x = dup2(x)
+        return ops.xattn_block(x, pa.q.wf, pa.q.bf, kv[2], kv[3], pa.xwo, pa.out.b, HW=L, heads=pa.heads, Lc=Lc, eps=pa.q.eps,
+                               scale=pa.dim_head ** -0.5, want_stats=want_stats)
     if dup:
         with plan_batch_scale(2):
             q = ln_linear(x, st, pn, pa.q)
@@ -281,7 +292,7 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     if kv is None:
         kv = linear(ctx, pa.kv)
     else:
-        kv, vt = kv
+        kv, vt = kv[0], kv[1]
     a = ops.attention_q_kv(q, kv, B, pa.heads, L, Lc, pa.dim_head ** -0.5, vt=vt)
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
@@ -329,6 +340,10 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     y = linear(g, pt.ff2, resid=x, want_stats=ws)
     return y if ws else (y, None)
 
+
+# Fused cross-attention block for the C = 320 level (needs the per-context K / V^T pack of UNetModel._context_kv);
+# LEFTREFILL_XATTN=0 keeps the to_q -> attention -> to_out launches.
+XATTN = __import__("os").environ.get("LEFTREFILL_XATTN", "1") != "0"
 
 # LayerNorm folded into the consuming GEMM (inference path); LEFTREFILL_LN_FOLD=0 runs the stand-alone LayerNorm kernel.
 LN_FOLD = __import__("os").environ.get("LEFTREFILL_LN_FOLD", "1") != "0"

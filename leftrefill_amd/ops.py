@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GemmArgs
+from ._lib import GemmArgs, XattnArgs
 
 GN_CHUNKS = 256
 
@@ -405,6 +405,47 @@ def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=None):
     transpose_v of the v block (the context is constant over the DDIM steps)."""
     C = heads * 64
     return attention(q, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, scale, vt=vt)
+
+
+XATTN_C, XATTN_ROWS, XATTN_MAX_KEYS = 320, 128, 96
+
+
+def xattn_ok(M, HW, C, heads, Lc):
+    """Shapes lr_xattn_block_f16 takes (everything else keeps the to_q -> attention -> to_out path)."""
+    return C == XATTN_C and heads * 64 == C and M % XATTN_ROWS == 0 and HW % XATTN_ROWS == 0 and 0 < Lc <= XATTN_MAX_KEYS
+
+
+def xattn_pack_vt(v, B, heads, Lc, out=None):
+    """v [B*Lc, >= heads*64] (V projection of the context, unit column stride) -> V^T pack [B, heads, 2, 64, 64]."""
+    lib = _lib.load()
+    assert v.is_cuda and v.dtype in HALF_TYPES and v.stride(1) == 1 and v.shape[0] == B * Lc
+    vt = torch.empty(B, heads, 2, 64, 64, device=v.device, dtype=v.dtype) if out is None else out
+    assert vt.shape == (B, heads, 2, 64, 64) and vt.is_contiguous()
+    _lib.check(_fn(lib, "lr_xattn_pack_vt_f16", v.dtype)(_p(v), v.stride(0), _p(vt), B, heads, Lc, _stream()), "xattn_pack_vt")
+    return vt
+
+
+def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_stats=False, out=None):
+    """x + to_out(attention(LayerNorm(x) Wq, K, V)) in one launch (lr_xattn_block_f16).  wq / bq: LayerNorm-folded to_q;
+    k [B*Lc, ld] = context projection with packing.pack_xattn's row order; vt = xattn_pack_vt(V); wo: column-permuted.
+    Returns out [M, C] (, stats [M, 1, 2] for the LayerNorm fold of the next GEMM)."""
+    lib = _lib.load()
+    _chk16(x, "x")
+    M, C = x.shape
+    assert xattn_ok(M, HW, C, heads, Lc), (M, HW, C, heads, Lc)
+    for t_ in (wq, wo):
+        assert t_.dtype == x.dtype and t_.is_contiguous() and t_.shape == (C, C)
+    assert bq.dtype == torch.float32 and bo.dtype == torch.float32 and bq.numel() == C and bo.numel() == C
+    assert k.dtype == x.dtype and k.stride(1) == 1 and k.shape[0] == (M // HW) * Lc and vt.dtype == x.dtype and vt.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(M, 1, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    a = XattnArgs()
+    a.x, a.out, a.wq, a.bq, a.k, a.ldk, a.vt, a.wo, a.bo = _p(x), _p(out), _p(wq), _p(bq), _p(k), k.stride(0), _p(vt), _p(wo), _p(bo)
+    a.stats_out = _p(stats)
+    a.M, a.HW, a.C, a.heads, a.Lc, a.ln_eps, a.scale = M, HW, C, heads, Lc, float(eps), float(scale)
+    _lib.check(_fn(lib, "lr_xattn_block_f16", x.dtype)(a, _stream()), "xattn_block")
+    return (out, stats) if want_stats else out
 
 
 def softmax_rows(s, scale, out=None):

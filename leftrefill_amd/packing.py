@@ -59,3 +59,19 @@ def fold_layernorm(w, b, gamma, beta, dtype=torch.float16):
     if b is not None:
         bf = bf + b.float()
     return wf, bf.contiguous(), cs
+
+
+def xattn_perm(n, device=None):
+    """k-slot order of the fused cross-attention block (lr_xattn_block_f16): inside every head of 64 channels, position
+    32 p + 8 f + i (f < 4, i < 8) holds channel 32 p + 16 (i >> 2) + 4 f + (i & 3) -- the order in which a 16x16x32 MFMA's
+    accumulator lanes hand a tile pair on as the next product's B operand."""
+    pos = torch.arange(n, device=device)
+    h, r = pos // 64, pos % 64
+    p, f, i = r // 32, (r % 32) // 8, r % 8
+    return h * 64 + 32 * p + 16 * (i // 4) + 4 * f + (i % 4)
+
+
+def pack_xattn(wk, wo, dtype=torch.float16):
+    """(to_k.weight with its ROWS in k-slot order, to_out[0].weight with its COLUMNS in k-slot order)."""
+    perm = xattn_perm(wk.shape[0], wk.device)
+    return wk[perm].to(dtype).contiguous(), wo[:, perm].to(dtype).contiguous()

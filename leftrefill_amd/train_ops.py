@@ -358,6 +358,13 @@ class _MvScatter(torch.autograd.Function):
         return dseq, None, None, None
 
 
+def xattn_block(*a, **k):
+    """Fused cross-attention block: inference only (engine.cross_attention takes it only when nothing requires grad); looked up
+    on `ops` at call time like every wrapper here, so instrumentation that patches ops.xattn_block sees the launches."""
+    assert not _needs_grad(a[0])
+    return ops.xattn_block(*a, **k)
+
+
 def mv_gather(x, b, v, s):
     return _MvGather.apply(x, b, v, s) if _needs_grad(x) else ops.mv_gather(x, b, v, s)
 

@@ -1,0 +1,122 @@
+"""GPU parity of the fused cross-attention block (lr_xattn_block_f16) against the CPU oracle.
+
+Reference semantics: `x = self.attn2(self.norm2(x), context=context) + x` (ldm/modules/attention.py:281) with
+CrossAttention.forward (attention.py:165-196); oracle: unet_ref.layer_norm + unet_ref.cross_attention.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_spec as G, unet_ref, weights  # noqa: E402
+from tests.test_gpu_ops import dev, h16, report  # noqa: E402
+
+C, HEADS = 320, 5
+
+
+def _params(tag):
+    sd = {}
+    for n in ("to_q", "to_k", "to_v"):
+        sd[f"a.{n}.weight"] = h16(torch.from_numpy(weights.fill_like(f"xa.{tag}.{n}.weight", (C, C if n == "to_q" else 1024))))
+    sd["a.to_out.0.weight"] = h16(torch.from_numpy(weights.fill_like(f"xa.{tag}.to_out.0.weight", (C, C))))
+    sd["a.to_out.0.bias"] = torch.from_numpy(weights.fill_like(f"xa.{tag}.to_out.0.bias", (C,)))
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like(f"xa.{tag}.norm.weight", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like(f"xa.{tag}.norm.bias", (C,), kind="unit"))
+    return sd, gamma, beta
+
+
+def _oracle(sd, gamma, beta, x, ctx):
+    """fp32 restatement on the fp16-rounded inputs: x + to_out(attention(LN(x) Wq, ctx Wk, ctx Wv))."""
+    m = unet_ref._Mode("fp32")
+    n = unet_ref.layer_norm(x, gamma, beta)
+    return x + unet_ref.cross_attention(sd, "a", n, ctx, HEADS, m)
+
+
+def _run_fused(sd, gamma, beta, x, ctx, want_stats=True):
+    from leftrefill_amd import ops, packing
+    d = dev()
+    B, L, _ = x.shape
+    Lc = ctx.shape[1]
+    wq, bq, _cs = packing.fold_layernorm(sd["a.to_q.weight"], None, gamma, beta)
+    xk_w, xwo = packing.pack_xattn(sd["a.to_k.weight"], sd["a.to_out.0.weight"])
+    ctx_t = ctx.reshape(B * Lc, -1).half().to(d)
+    k = ops.gemm_conv(ctx_t, xk_w.to(d), B=1, H=1, W=B * Lc, taps=1)
+    v = ops.gemm_conv(ctx_t, sd["a.to_v.weight"].half().to(d), B=1, H=1, W=B * Lc, taps=1)
+    vt = ops.xattn_pack_vt(v, B, HEADS, Lc)
+    xt = x.reshape(B * L, C).half().to(d)
+    return ops.xattn_block(xt, wq.to(d), bq.to(d), k, vt, xwo.to(d), sd["a.to_out.0.bias"].to(d), HW=L, heads=HEADS, Lc=Lc,
+                           eps=1e-5, scale=64 ** -0.5, want_stats=want_stats)
+
+
+@pytest.mark.parametrize("B,L,Lc", [(1, 128, 77), (2, 256, 77), (2, 128, 96), (1, 384, 5), (2, 128, 80), (1, 128, 81)])
+def test_xattn_block_vs_oracle(B, L, Lc):
+    sd, gamma, beta = _params("p")
+    x = h16(G.T(f"xa.{L}.{Lc}.x", (B, L, C)) * 1.3 + 0.2)
+    ctx = h16(G.T(f"xa.{L}.{Lc}.ctx", (B, Lc, 1024)))
+    ref = _oracle(sd, gamma, beta, x, ctx)
+    out, st = _run_fused(sd, gamma, beta, x, ctx)
+    # composite of four products with fp16 hand-offs (q, P, O) and two 16-bit roundings of the result
+    report(f"xattn B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, atol=3e-3)
+    # row statistics of the ROUNDED output, as the LayerNorm fold of the next GEMM reads them
+    o32 = out.float()
+    assert st.shape == (B * L, 1, 2)
+    torch.testing.assert_close(st[:, 0, 0], o32.sum(1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[:, 0, 1], (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
+
+
+def test_xattn_block_hot_shape_and_reruns():
+    """configs[1] shape of the level-0 blocks: M = 8 x 8192 rows (sampled rows against the oracle), bit-identical reruns."""
+    B, L, Lc = 8, 8192, 77
+    sd, gamma, beta = _params("hot")
+    g = torch.Generator().manual_seed(5)
+    x = h16(torch.randn(B, L, C, generator=g))
+    ctx = h16(torch.randn(B, Lc, 1024, generator=g))
+    out = _run_fused(sd, gamma, beta, x, ctx, want_stats=False)
+    out2 = _run_fused(sd, gamma, beta, x, ctx, want_stats=False)
+    assert torch.equal(out, out2)
+    rows = torch.arange(0, L, 37)
+    ref = _oracle(sd, gamma, beta, x[:, rows], ctx)
+    report("xattn hot", out.reshape(B, L, C)[:, rows], ref, atol=3e-3)
+
+
+def test_xattn_unsupported_shapes_are_reported():
+    from leftrefill_amd import ops
+    assert not ops.xattn_ok(100, 100, 320, 5, 77)      # ragged rows
+    assert not ops.xattn_ok(256, 128, 640, 10, 77)     # other widths keep the three-kernel path
+    assert not ops.xattn_ok(256, 128, 320, 5, 97)
+    assert ops.xattn_ok(65536, 8192, 320, 5, 77)
+
+
+def test_engine_cross_attention_fused_equals_unfused_path():
+    """engine.cross_attention with the per-context K / V^T pack (fused launch) vs the to_q -> attention -> to_out launches."""
+    import importlib
+    from leftrefill_amd import engine, ops
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(0)
+    d = dev()
+    ca = att.CrossAttention(320, context_dim=1024, heads=5, dim_head=64).to(d).eval()
+    norm = torch.nn.LayerNorm(320).to(d)
+    with torch.no_grad():
+        for p_ in list(ca.parameters()) + list(norm.parameters()):
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        norm.weight.add_(1.0)
+    pa, pn = engine.PackedAttn(ca, False, norm), engine.PackedNorm(norm)
+    assert pa.xk is not None
+    B, L, Lc = 2, 256, 77
+    x = torch.randn(B * L, 320, device=d).half()
+    ctx = torch.randn(B * Lc, 1024, device=d).half()
+    kv = ops.gemm_conv(ctx, pa.kv.w, B=1, H=1, W=B * Lc, taps=1)
+    ent = (kv, None, ops.gemm_conv(ctx, pa.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, 320:], B, 5, Lc))
+    with torch.no_grad():
+        fused, st = engine.cross_attention(x, None, pn, ctx, pa, B, L, Lc, kv=ent, want_stats=True)
+        engine.XATTN = False
+        try:
+            plain, st2 = engine.cross_attention(x, None, pn, ctx, pa, B, L, Lc, kv=ent, want_stats=True)
+        finally:
+            engine.XATTN = True
+    err = (fused.float() - plain.float()).abs().max().item()
+    print(f"[fused vs unfused cross-attention] max abs diff {err:.3e} at |out| {plain.float().abs().max().item():.2f}")
+    assert err <= 8e-3 * max(1.0, plain.float().abs().max().item())
+    torch.testing.assert_close(st.sum(1)[:, 0], st2.sum(1)[:, 0], rtol=1e-3, atol=2e-1)

@@ -71,6 +71,44 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lr_attn_bwd_args), offset
     assert [int(v) for v in out] == got
 
 
+def test_xattn_args_struct_layout_matches_header():
+    import subprocess, tempfile
+    from leftrefill_amd._lib import XattnArgs
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "leftrefill_hip.h"
+int main(){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(lr_xattn_args), offsetof(lr_xattn_args, k), offsetof(lr_xattn_args, ldk),
+  offsetof(lr_xattn_args, vt), offsetof(lr_xattn_args, stats_out), offsetof(lr_xattn_args, M), offsetof(lr_xattn_args, scale)); }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")],
+                       check=True)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
+    got = [ctypes.sizeof(XattnArgs), XattnArgs.k.offset, XattnArgs.ldk.offset, XattnArgs.vt.offset, XattnArgs.stats_out.offset,
+           XattnArgs.M.offset, XattnArgs.scale.offset]
+    assert [int(v) for v in out] == got
+
+
+def test_xattn_k_slot_permutation():
+    """packing.xattn_perm is the accumulator -> B-operand hand-off order of a 16x16x32 MFMA tile pair (csrc/xattn_block.hip)."""
+    import torch
+    from leftrefill_amd import packing
+    perm = packing.xattn_perm(128)
+    assert sorted(perm.tolist()) == list(range(128))
+    # lane group f of k-step p holds, in slots 0..7, the four channels 4 f .. 4 f + 3 of tile 2p and of tile 2p + 1
+    for h in range(2):
+        for p in range(2):
+            for f in range(4):
+                got = perm[h * 64 + 32 * p + 8 * f: h * 64 + 32 * p + 8 * f + 8].tolist()
+                want = [h * 64 + 16 * (2 * p) + 4 * f + r for r in range(4)] + [h * 64 + 16 * (2 * p + 1) + 4 * f + r for r in range(4)]
+                assert got == want
+    wk, wo = torch.arange(128.0)[:, None].repeat(1, 8), torch.arange(128.0)[None, :].repeat(4, 1)
+    xk, xwo = packing.pack_xattn(wk, wo, torch.float32)
+    assert torch.equal(xk[:, 0], perm.float()) and torch.equal(xwo[0], perm.float())
+
+
 def test_gemm_plan_is_a_pure_function_of_the_shape():
     """Tile / split-K / pipeline selection never depends on timing: the committed table (tile_table.json) answers the shapes
     of the shipped workloads, the library's static heuristic (lr_gemm_plan, host code -- no GPU needed) everything else;
