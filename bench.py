@@ -87,7 +87,8 @@ def synthetic_batch(B, h, w, device, seed):
     return c_concat, c_cross, uc_cross, x_T
 
 
-def sample_once(model, batch, B, steps=S_DDIM):
+def sample_once(model, batch, B, steps=None):
+    steps = steps or S_DDIM
     c_concat, c_cross, uc_cross, x_T = batch
     cond = {"c_concat": [c_concat], "c_crossattn": [c_cross]}
     uc = {"c_concat": [c_concat], "c_crossattn": [uc_cross]}
@@ -396,43 +397,73 @@ def train_bench(a, rank, world, device, model=None, steps=None):
             "loss_scale": scaler["scale"], "skipped_steps": scaler["skipped"]}
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this box from /proc/cpuinfo (stated beside every CPU figure)."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or logical or (os.cpu_count() or 1)), logical or (os.cpu_count() or 1)
+
+
 def cpu_baseline():
-    """Oracle (fp32 torch CPU restatement of the reference, oracle/unet_ref.py) on the host cores, SURVEY 8d: configs[0] fully
-    (256x512 canvas = latent 32x64, B = 1, 10 DDIM steps under CFG = 10 UNet forwards at batch 2) and ONE CFG step of configs[1]
-    (latent 64x128, batch 2), after a warm-up forward (thread pool, allocator)."""
-    from oracle import unet_ref
-    cfg = unet_ref.FULL
-    g = torch.Generator().manual_seed(0)
-    sd = {}
-    for k, shp in unet_ref.param_shapes(cfg).items():
-        if len(shp) >= 2:
-            fan = 1
-            for s_ in shp[1:]:
-                fan *= s_
-            sd[k] = torch.randn(shp, generator=g) * (1.0 / fan) ** 0.5
-        elif k.endswith(".weight"):
-            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
-        else:
-            sd[k] = 0.02 * torch.randn(shp, generator=g)
-    ctx = torch.randn(2, 77, 1024, generator=g)
-    t = torch.tensor([501, 501])
-    x0 = torch.randn(2, 9, 32, 64, generator=g)
-    unet_ref.unet_forward(sd, cfg, x0, t, ctx)                      # warm-up (not timed)
-    t0 = time.time()
-    xs = x0
-    for i in range(10):                                             # configs[0]: 10 CFG UNet steps + the DDIM / CFG update
-        eps = unet_ref.unet_forward(sd, cfg, xs, torch.tensor([901 - 100 * i] * 2), ctx)
-        e = eps[:1] + CFG * (eps[1:] - eps[:1])                    # classifier-free guidance, ddim.py:343
-        xs = torch.cat([xs[:, :4] - 0.1 * e, xs[:, 4:]], 1)        # stand-in for the x_{t-1} update (negligible time)
-    dt0 = time.time() - t0
-    x = torch.randn(2, 9, 64, 128, generator=g)
-    t0 = time.time()
-    unet_ref.unet_forward(sd, cfg, x, t, ctx)
-    dt = time.time() - t0
-    return {"value": 1.0 / (S_DDIM * dt), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"after one warm-up forward: configs[0] in full (latent 32x64, B=1, 10 CFG UNet steps) {dt0:.2f} s = "
-                      f"{1.0 / dt0:.4f} images/s; configs[1]: 1 CFG UNet step (batch 2) at latent 64x128 {dt:.2f} s/step, "
-                      f"extrapolated x{S_DDIM} steps per image for `value`",
+    """Oracle (fp32 torch CPU restatement of the reference, oracle/unet_ref.py + oracle/ddim_ref.py) on the host cores, SURVEY 8d,
+    one torch thread per PHYSICAL core: configs[0] in full through the oracle's sampler (256x512 canvas = latent 32x64, B = 1,
+    10 DDIM steps under CFG 2.5 = 10 UNet forwards at batch 2 + the guided updates) and ONE CFG step of configs[1] (latent
+    64x128, batch 2), after a warm-up forward (thread pool, allocator)."""
+    from oracle import ddim_ref, unet_ref
+    cpu_model, phys, logical = host_cpu()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, phys))
+    try:
+        cfg = unet_ref.FULL
+        g = torch.Generator().manual_seed(0)
+        sd = {}
+        for k, shp in unet_ref.param_shapes(cfg).items():
+            if len(shp) >= 2:
+                fan = 1
+                for s_ in shp[1:]:
+                    fan *= s_
+                sd[k] = torch.randn(shp, generator=g) * (1.0 / fan) ** 0.5
+            elif k.endswith(".weight"):
+                sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+            else:
+                sd[k] = 0.02 * torch.randn(shp, generator=g)
+        ctx = torch.randn(2, 77, 1024, generator=g)
+        t = torch.tensor([501, 501])
+        unet_ref.unet_forward(sd, cfg, torch.randn(2, 9, 32, 64, generator=g), t, ctx)      # warm-up (not timed)
+        # configs[0] exactly as stated: the oracle's DDIM / CFG sampler, eta = 1 noise drawn per step like the reference
+        x_T = torch.randn(1, 4, 32, 64, generator=g)
+        c_concat = torch.randn(1, 5, 32, 64, generator=g)
+        t0 = time.time()
+        ddim_ref.ddim_sample(lambda xc, tt, cc: unet_ref.unet_forward(sd, cfg, xc, tt, cc), 10, x_T, c_concat, ctx[:1], ctx[1:], CFG,
+                             eta=ETA, noises=[torch.randn(1, 4, 32, 64, generator=g) for _ in range(10)])
+        dt0 = time.time() - t0
+        x = torch.randn(2, 9, 64, 128, generator=g)
+        t0 = time.time()
+        unet_ref.unet_forward(sd, cfg, x, t, ctx)
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(prev_threads)
+    return {"value": 1.0 / (50 * dt), "unit": "images/s", "cores": phys, "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": phys, "logical_cpus": logical, "torch_threads": phys,
+            "sample": f"{cpu_model}, {phys} physical cores ({logical} logical), torch threads = {phys}; after one warm-up forward: "
+                      f"configs[0] in full through oracle/ddim_ref.ddim_sample (latent 32x64, B=1, 10 DDIM steps, cfg 2.5, eta 1) "
+                      f"{dt0:.2f} s = {1.0 / dt0:.4f} images/s; configs[1]: 1 CFG UNet step (batch 2) at latent 64x128 {dt:.2f} s/step, "
+                      f"extrapolated x50 steps per image for `value`",
             "s_per_unet_step_b2": dt, "config0_full_s": dt0, "config0_images_per_s": 1.0 / dt0}
 
 
@@ -470,6 +501,7 @@ def measure_traffic(launches):
 
 
 def main():
+    global S_DDIM
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -487,11 +519,33 @@ def main():
     ap.add_argument("--train-graph", action="store_true", help="train workload: capture the whole step into one hipGraph")
     ap.add_argument("--recompute", action="store_true", help="train workload: recompute blocks in the backward (use_checkpoint)")
     ap.add_argument("--dump-kernels", default=None, help="write per-launch (shape, us, TFLOP/s) records as JSON lines")
+    ap.add_argument("--mv-shard", action="store_true",
+                    help="mv5 workload in its configs[3] form: ONE canvas per rank (--gpus 4 = view_num - 1), per-block RCCL "
+                         "all-gather of the reference halves + broadcast of the target half, captured in the hipGraph")
+    ap.add_argument("--split-cfg", action="store_true",
+                    help="single workload with B < #GPUs: the unconditional / conditional UNet passes of the same samples on rank "
+                         "pairs (2 j, 2 j + 1), one all-gather of the eps halves per DDIM step")
+    ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="DDIM steps per sampling (the metric is quoted at 50)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: re-launch as N ranks (one per GPU) under torch.distributed.run, like the driver does
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: one rank per GPU, the two must agree")
+    S_DDIM = a.ddim_steps
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -504,7 +558,11 @@ def main():
         if share:
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == a.gpus
+        backend = dist.get_backend()
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -522,14 +580,33 @@ def main():
     os.environ["LEFTREFILL_CFG_SHARED_PREFIX"] = "0"
     B, h, w = a.batch, 64, 128
     samples_per_step = B
+    replicas = world            # independent copies of the workload (weak scaling): ranks / ranks-per-replica
+    seed = 1234 + rank
     if a.workload != "single":      # B counts canvases from here on; one sample = (view_num - 1 | view_num) canvases
         mv = MV_WORKLOADS[a.workload]
         views = mv["view_num"] - 1 if mv["concat_target"] else mv["view_num"]
         samples_per_step = max(1, a.batch // 4)
         B, h, w = samples_per_step * views, mv["h"], mv["w"]
+        if a.mv_shard:              # configs[3]: the canvases of a sample spread over the ranks, one each
+            if a.workload != "mv5" or world != views:
+                raise SystemExit(f"--mv-shard: --workload mv5 with --gpus {views} (one canvas [ref_i | target] per rank)")
+            B, replicas = samples_per_step, 1
+    if a.split_cfg:
+        if a.workload != "single" or world % 2:
+            raise SystemExit("--split-cfg: the single workload on an even number of ranks (pairs run uncond / cond)")
+        replicas = world // 2
+        seed = 1234 + rank // 2     # a pair works on the same samples and draws the same DDIM noise
+        torch.manual_seed(4321 + rank // 2)
+        torch.cuda.manual_seed(4321 + rank // 2)
 
     model = build_model(device, a.workload)
-    batch = synthetic_batch(B, h, w, device, 1234 + rank)
+    batch = synthetic_batch(B, h, w, device, seed)
+    if a.mv_shard:
+        unet = model.model.diffusion_model
+        unet.mv_shard, unet.mv_shard_graph = True, True     # the graph (incl. its RCCL collectives) is captured under `nccl` only
+    if a.split_cfg:
+        from leftrefill_amd import dist as lrd
+        lrd.enable_split_cfg(True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -554,7 +631,7 @@ def main():
         dt = tt.item()
     assert torch.isfinite(out).all()
     ms_per_step = 1e3 * dt / a.steps
-    images_per_s = world * samples_per_step * a.steps / dt
+    images_per_s = replicas * samples_per_step * a.steps / dt
     unet_step_ms = ms_per_step / S_DDIM     # per DDIM iteration (UNet step at batch 2B + fused update), incl. host loop
 
     res = {"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": images_per_s,
@@ -562,16 +639,30 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
            "config": {"workload": "configs[1]: 1-ref inpainting, 512x1024 canvas (latent 64x128), B=4 per GPU "
                                   "(UNet batch 8 under CFG), 50 DDIM steps, cfg=2.5, eta=1.0, fp16",
-                      "global_batch": world * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
+                      "global_batch": replicas * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
                       "parallelism": f"dp{world} (sample-sharded, no data-path collective)",
+                      "ranks": world, "backend": backend,
                       "note": "every DDIM step runs the full UNet at batch 2B (the exact shared-prefix optimisation of the sampler is OFF for this number); the only loop-invariant hoisted out of the step is the "
                               "cross-attention K/V projection of the constant context (3.9 of 1850 GFLOP per sample per forward, "
                               "0.2 %), computed once per sampling"},
            "per_unet_step_ms": unet_step_ms}
     if a.workload != "single":
         res["config"]["workload"] = (f"config 4 ({a.workload}): {MV_WORKLOADS[a.workload]}, {samples_per_step} sample(s) = {B} "
-                                     f"canvases per GPU (UNet batch {2 * B}), 50 DDIM steps, cfg=2.5, eta=1.0, fp16")
-        res["config"]["global_batch"], res["config"]["per_gpu_batch"] = world * samples_per_step, samples_per_step
+                                     f"canvases per GPU (UNet batch {2 * B}), {S_DDIM} DDIM steps, cfg=2.5, eta=1.0, fp16")
+        res["config"]["global_batch"], res["config"]["per_gpu_batch"] = replicas * samples_per_step, samples_per_step
+        if a.mv_shard:
+            res["scaling"] = "strong"
+            res["metric"] = "multi-view samples/sec (4-ref, 5 x 4096-token cross-view self-attention) @ 50 DDIM steps, cfg=2.5; canvases sharded over ranks"
+            res["unit"] = "samples/s"
+            res["config"]["parallelism"] = (f"mv-shard x{world}: one canvas per rank; per transformer block one all_gather_into_tensor of the "
+                                            f"reference halves + one broadcast of rank 0's target half ({backend}), "
+                                            + ("captured in the hipGraph" if backend == "nccl" else "eager (gloo test hook)"))
+    if a.split_cfg:
+        res["config"]["parallelism"] = (f"split-cfg x{world}: {replicas} pair(s) of ranks, uncond pass on rank 2j / cond pass on 2j+1 at UNet "
+                                        f"batch {B}, one all-gather of the eps halves per DDIM step ({backend})")
+        res["config"]["global_batch"] = replicas * B
+    if S_DDIM != 50:
+        res["config"]["note"] = f"NOT the metric's configuration: {S_DDIM} DDIM steps per sampling (test / smoke run)"
 
     if rank == 0 and not a.no_roofline:
         kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)

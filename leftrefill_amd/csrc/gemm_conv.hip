@@ -375,15 +375,16 @@ __device__ __forceinline__ void stage_params(const GemmParams& P, float* par, co
 __device__ __forceinline__ void ln_rows_to_lds(const GemmParams& P, float* rs, const int m0, const int rows, const int t) {
   if (t < rows) {
     const int m = m0 + t;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
     if (m < P.M) {
       const float2* p = reinterpret_cast<const float2*>(P.ln_part) + (size_t)m * P.ln_parts;
-      for (int k = 0; k < P.ln_parts; ++k) { const float2 v = p[k]; s += v.x; q += v.y; }
+      for (int k = 0; k < P.ln_parts; ++k) { const float2 v = p[k]; s += (double)v.x; q += (double)v.y; }
     }
-    const float mean = s * P.ln_invc;
-    const float var = fmaxf(fmaf(-mean, mean, q * P.ln_invc), 0.f);
-    rs[2 * t] = mean;
-    rs[2 * t + 1] = rsqrtf(var + P.ln_eps);
+    // E[x^2] - mean^2 in fp64: with |mean| >> std (outlier tokens) the fp32 difference cancels to 0 and rstd jumps to 1/sqrt(eps)
+    const double mean = s * (double)P.ln_invc;
+    const double var = fmax(q * (double)P.ln_invc - mean * mean, 0.0);
+    rs[2 * t] = (float)mean;
+    rs[2 * t + 1] = (float)(1.0 / sqrt(var + (double)P.ln_eps));
   }
 }
 
@@ -1125,6 +1126,10 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.rowvec = (const f16*)a->rowvec; P.ld_rowvec = a->ld_rowvec;
   P.resid = (const f16*)a->resid; P.ld_resid = a->ld_resid;
   P.out = (f16*)a->out; P.ld_out = a->ld_out;
+  // the epilogue addresses out / resid / rowvec through buffer descriptors with 32-bit byte offsets (bit 31 = out of range)
+  if ((int64_t)P.M * a->ld_out * 2 >= lim || (a->resid && (int64_t)P.M * a->ld_resid * 2 >= lim) ||
+      (a->rowvec && (int64_t)a->B * a->ld_rowvec * 2 >= lim))
+    return LR_E_UNSUPPORTED;
   if (a->geglu < 0 || a->geglu > 2) return LR_E_ARG;
   P.geglu = a->geglu == 1 ? 1 : 0;
   P.gelu = a->geglu == 2 ? 1 : 0;      // plain erf-GELU of (acc + bias [+ rowvec]), applied before the residual

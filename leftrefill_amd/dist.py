@@ -169,3 +169,53 @@ def allreduce_mean_grads(params):
         n = g.numel()
         g.copy_(flat[off:off + n].reshape(g.shape).to(g.dtype))
         off += n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Classifier-free guidance split over two ranks ("cond + uncond x2 batch"): when the user batch is
+# smaller than the number of GPUs, rank 2j runs the UNCONDITIONAL pass and rank 2j + 1 the CONDITIONAL pass of the same
+# samples (reference ddim.py:317-343 runs them as one batch of 2B); per DDIM step the two eps halves are exchanged with ONE
+# all-gather inside the pair ([2, B, 4, h, w] fp16: 262 KB at B = 4, 64 x 128) and both ranks apply the same guided update
+# (same noise: the pair shares its RNG seed).  World sizes > 2 form independent pairs (2 j, 2 j + 1).
+# ---------------------------------------------------------------------------------------------------------------
+_SPLIT_CFG = {"on": False, "group": None}
+
+
+def enable_split_cfg(on=True):
+    """Switch the sampler's split mode (collective: every rank must call it).  With no process group (world 1) the mode still
+    runs -- the two passes go through the UNet one after the other at batch B -- which is what the single-GPU test covers."""
+    _SPLIT_CFG["on"] = bool(on)
+    _SPLIT_CFG["group"] = None
+    if on and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        assert world % 2 == 0, "split CFG pairs ranks (2 j, 2 j + 1): the world size must be even"
+        for j in range(world // 2):
+            g = dist.new_group([2 * j, 2 * j + 1])
+            if rank // 2 == j:
+                _SPLIT_CFG["group"] = g
+
+
+def split_cfg_active():
+    return _SPLIT_CFG["on"]
+
+
+def split_cfg_role():
+    """0: this rank runs the unconditional pass, 1: the conditional pass, None: both (no process group)."""
+    if _SPLIT_CFG["group"] is None:
+        return None
+    return dist.get_rank() % 2
+
+
+def cfg_exchange(e_local):
+    """e_local [B, ...] = this rank's eps half -> [2B, ...], unconditional half first, on both ranks of the pair."""
+    g = _SPLIT_CFG["group"]
+    assert g is not None
+    e_local = e_local.contiguous()
+    if _staged(e_local):
+        h = e_local.cpu()
+        out = torch.empty((2 * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=g)
+        return out.to(e_local.device)
+    out = torch.empty((2 * e_local.shape[0],) + tuple(e_local.shape[1:]), dtype=e_local.dtype, device=e_local.device)
+    dist.all_gather_into_tensor(out, e_local, group=g)
+    return out

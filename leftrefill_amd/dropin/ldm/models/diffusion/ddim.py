@@ -192,6 +192,19 @@ class DDIMSampler(object):
                 c_in = {k: ([torch.cat([unconditional_conditioning[k][i], c[k][i]]) for i in range(len(c[k]))]
                             if isinstance(c[k], list) else torch.cat([unconditional_conditioning[k], c[k]]))
                         for k in c}
+            from leftrefill_amd import dist as lrd
+            if lrd.split_cfg_active():
+                # cond / uncond passes on two ranks (or, without a process group, one after the other): batch B each, one
+                # all-gather of the eps halves per step -- leftrefill_amd/dist.py
+                role = lrd.split_cfg_role()
+                if role is None:
+                    eps = torch.cat([self.model.apply_model(x, t, unconditional_conditioning), self.model.apply_model(x, t, c)])
+                else:
+                    eps = lrd.cfg_exchange(self.model.apply_model(x, t, unconditional_conditioning if role == 0 else c))
+                noise = noise_like(x.shape, device, repeat_noise)
+                sigma = float(self.ddim_sigmas[index])
+                return ops.ddim_cfg_step(x, eps.contiguous(), noise, scale, self.ddim_alphas[index], self.ddim_alphas_prev[index],
+                                         sigma * float(temperature), self.ddim_sqrt_one_minus_alphas[index])
             x_in = torch.cat([x] * 2)
             t_in = torch.cat([t] * 2)
             unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)

@@ -459,10 +459,15 @@ class UNetModel(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the noisy latent is not produced (p_losses feeds x_noisy without grad)")
         context = context.to(self.compute_dtype).contiguous()
-        if not self.use_hip_graph or (torch.is_grad_enabled() and context.requires_grad):
+        if torch.is_grad_enabled() and context.requires_grad:
             # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
             # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
+        if not self.use_hip_graph:
+            # eager inference: the same launches as the captured step (per-context K / V operands computed first), so the
+            # two modes stay bit-identical
+            with torch.no_grad():
+                return self._run_plan(x, timesteps, context, self._context_kv(context))
         shared = bool(self.cfg_shared_prefix)
         key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared)
         g = self._graphs.pop(key, None)

@@ -244,9 +244,11 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         best = tile_cache().get(key)
         if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
             a.B = B * scale
+            if ln is not None or want_stats:
+                a.splits = 1                 # row statistics / the LayerNorm fold never split K -- like the unscaled plan below
             plan = (ctypes.c_int32 * 4)()
             lib.lr_gemm_plan(a, plan)
-            a.B = B
+            a.B, a.splits = B, 0
             best = tuple(plan)
         if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)

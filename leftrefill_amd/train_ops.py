@@ -201,12 +201,14 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 class _ToNCHW(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, N, H, W, C, out_dtype):
-        ctx.meta = (y.shape[-1],)
+        ctx.meta = (y.shape[-1], y.dtype)
         return ops.nhwc_to_nchw(y, N, H, W, C, out_dtype)
 
     @staticmethod
     def backward(ctx, dout):
-        return ops.nchw_to_nhwc(dout.float().contiguous(), cpad=ctx.meta[0]), None, None, None, None, None
+        # the gradient takes the activation's 16-bit type: an fp16 detour would flush the unscaled bf16 gradients
+        # (~1e-6 at training sizes) to zero before autograd casts them back
+        return ops.nchw_to_nhwc(dout.float().contiguous(), cpad=ctx.meta[0], dtype=ctx.meta[1]), None, None, None, None, None
 
 
 def nhwc_to_nchw(y, N, H, W, C, out_dtype=None):

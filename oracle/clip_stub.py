@@ -43,19 +43,24 @@ class ResidualAttentionBlock(nn.Module):
 
 
 class _Transformer(nn.Module):
-    def __init__(self):
+    def __init__(self, width=WIDTH, heads=HEADS, layers=LAYERS):
         super().__init__()
-        self.resblocks = nn.ModuleList([ResidualAttentionBlock(WIDTH, HEADS) for _ in range(LAYERS)])
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
         self.grad_checkpointing = False
 
 
+# arch "stub-1024": the real tower's width (the NVS encoder's pose MLP is hard-wired to 1024 channels, NVS_modules.py:167), 2 layers
+ARCHS = {"stub-1024": (1024, 16, 2)}
+
+
 class TextModel(nn.Module):
-    def __init__(self):
+    def __init__(self, width=WIDTH, heads=HEADS, layers=LAYERS):
         super().__init__()
+        WIDTH = width
         self.vocab_size = BASE_VOCAB + 2
         self.token_embedding = nn.Embedding(self.vocab_size, WIDTH)
         self.positional_embedding = nn.Parameter(torch.zeros(CTX, WIDTH))
-        self.transformer = _Transformer()
+        self.transformer = _Transformer(width, heads, layers)
         self.ln_final = nn.LayerNorm(WIDTH)
         self.visual = nn.Identity()
         self.register_buffer("attn_mask", torch.full((CTX, CTX), float("-inf")).triu_(1), persistent=False)
@@ -66,7 +71,7 @@ class TextModel(nn.Module):
 
 
 def create_model_and_transforms(arch, device=None, pretrained=None):
-    return TextModel(), None, None
+    return TextModel(*ARCHS.get(arch, (WIDTH, HEADS, LAYERS))), None, None
 
 
 class SimpleTokenizer:

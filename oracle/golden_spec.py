@@ -198,3 +198,32 @@ TEXT_CASES = [
                       deep_prompt=True, cross_attn_layers=4),
      [["".join(f"<special-token{i}-layer{l}>" for i in range(3)), ""] for l in range(4)]),
 ]
+
+# multi-view prompt encoder (multiview_Refill_modules.PromptCLIPEmbedder: per-view learned tokens, one prompt list per view) and the
+# NVS encoder (NVS_modules.NVSCLIPEmbedder: pose token from RelPosModel, optional second pose head / per-view tokens); the prompts
+# follow the reference's callers (multiview_ref_inpainting_ldm.py / NVS_ldm.py build them from the token names)
+_MV_KW = dict(layer="penultimate", special_tokens=["repeat_4_<special-token>"], init_text=[_TXT], view_num=3, view_token_len=2)
+_MV_SP = "".join(f"<special-token{i}>" for i in range(4))
+MV_TEXT_CASES = [
+    ("txt_mv_views", _MV_KW, [[_MV_SP + "".join(f"<view_direct-{j}-{l}" for l in range(2)), ""] for j in range(3)]),
+    ("txt_mv_plain", dict(layer="last", special_tokens=["<left>", "<right>"], init_text=["left part", "right part"], view_prompt=False),
+     ["<left> and <right>", "no special token here"]),
+]
+_NVS_SP = "".join(f"<special-token{i}>" for i in range(6))
+NVS_Z_ROWS = [0, 1, 6, 7, 8, 40, 75, 76]      # positions of z kept in the fixture of the 1024-wide cases (7 = the pose slot, 76 = the 2nd head's)
+
+
+def nvs_pose_state(name, like):
+    """RNG-free values for RelPosModel's parameters (the reference draws them from torch's default init)."""
+    return {k: torch.from_numpy(weights.fill_like(f"{name}.rel_pos_model.{k}", tuple(v.shape))) for k, v in like.items()}
+
+NVS_TEXT_CASES = [
+    # name, kwargs, prompts, rel_pos shape (None: prompts only)
+    ("txt_nvs_pose", dict(arch="stub-1024", layer="penultimate", special_tokens=["repeat_6_<special-token>"], init_text=[_TXT]),
+     [_NVS_SP, _NVS_SP, ""], (3, 4)),
+    ("txt_nvs_pose2", dict(arch="stub-1024", layer="penultimate", special_tokens=["repeat_6_<special-token>"], init_text=[_TXT],
+                           pos_strengthen=True),
+     [_NVS_SP, _NVS_SP], (2, 4)),
+    ("txt_nvs_views", dict(layer="last", special_tokens=["repeat_2_<special-token>"], init_text=[_TXT], view_prompt=True, view_num=2,
+                           view_token_len=1), ["<special-token0><special-token1><view_direct-1-0>", "<view_direct-0-0>"], None),
+]

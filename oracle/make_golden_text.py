@@ -19,6 +19,9 @@ from oracle import clip_stub, golden_spec as G, ref_import  # noqa: E402
 
 def main():
     sys.modules["open_clip"] = clip_stub
+    # the multi-view encoder file imports four names from `transformers` it never uses on this path: resolve them before the
+    # torchvision stub exists (transformers probes for torchvision at import time)
+    from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5Tokenizer  # noqa: F401
     ref_import.install_stubs()
     if ref_import.REF not in sys.path:
         sys.path.insert(0, ref_import.REF)
@@ -40,6 +43,31 @@ def main():
         with torch.no_grad():
             out[name + ".z"] = emb(prompts).numpy()
         print(name, out[name + ".tokens"].shape, out[name + ".z"].shape, len(emb.special_tokens))
+    from ldm.modules.encoders import multiview_Refill_modules as MV
+    for name, kw, prompts in G.MV_TEXT_CASES:
+        torch.manual_seed(0)
+        emb = MV.PromptCLIPEmbedder(device="cpu", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        emb.eval()
+        out[name + ".special_embeddings"] = emb.special_embeddings.weight.detach().numpy().copy()
+        out[name + ".n_special"] = np.asarray(len(emb.special_tokens))
+        with torch.no_grad():
+            out[name + ".z"] = emb(prompts).numpy()
+        print(name, out[name + ".z"].shape, len(emb.special_tokens))
+    from ldm.modules.encoders import NVS_modules as NV
+    for name, kw, prompts, pose_shape in G.NVS_TEXT_CASES:
+        torch.manual_seed(0)
+        emb = NV.NVSCLIPEmbedder(device="cpu", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        emb.eval()
+        out[name + ".special_embeddings"] = emb.special_embeddings.weight.detach().numpy().copy()
+        if emb.rel_pos_model is not None:      # the pose MLP is randomly initialised by the reference: name-keyed fills instead
+            emb.rel_pos_model.load_state_dict(G.nvs_pose_state(name, emb.rel_pos_model.state_dict()))
+        with torch.no_grad():
+            if pose_shape is None:
+                z = emb(prompts)
+            else:
+                z = emb([prompts, G.T(name + ".rel_pos", pose_shape)])
+        out[name + ".z"] = z[:, G.NVS_Z_ROWS].numpy() if z.shape[-1] > 256 else z.numpy()      # 1024-wide cases: sampled positions
+        print(name, out[name + ".z"].shape, len(emb.special_tokens))
     path = os.path.join(ROOT, "tests", "golden", "text.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path))

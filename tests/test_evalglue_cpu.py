@@ -81,3 +81,25 @@ def test_ssim_matches_bruteforce_definition():
     assert abs(evalglue.ssim_gray(torch.from_numpy(a), torch.from_numpy(b)) - np.mean(vals)) < 1e-9
     g = evalglue.rgb_to_gray01(torch.tensor([[[1.0]], [[-1.0]], [[0.0]]]))
     assert abs(g.item() - (0.2989 * 1.0 + 0.587 * 0.0 + 0.114 * 0.5)) < 1e-6
+
+
+def test_dropin_dataloaders_does_not_shadow_other_dataset_modules(tmp_path, monkeypatch):
+    """the reference's `dataloaders` directory also holds the training / multi-view datasets; after install()
+    those must still import while `dataloaders.test_dataset` resolves to the drop-in."""
+    import importlib
+    import sys
+    other = tmp_path / "refroot" / "dataloaders"
+    other.mkdir(parents=True)
+    (other / "inpainting_crossview_dataset.py").write_text("MARK = 'reference module'\n")
+    (other / "test_dataset.py").write_text("MARK = 'reference test_dataset'\n")
+    monkeypatch.syspath_prepend(str(tmp_path / "refroot"))
+    for name in [n for n in sys.modules if n == "dataloaders" or n.startswith("dataloaders.")]:
+        monkeypatch.delitem(sys.modules, name)
+    from leftrefill_amd.dropin import install
+    root = install()
+    mod = importlib.import_module("dataloaders.inpainting_crossview_dataset")
+    assert mod.MARK == "reference module"
+    td = importlib.import_module("dataloaders.test_dataset")
+    assert td.__file__.startswith(root) and hasattr(td, "TestInpaintingDataset")
+    for name in [n for n in sys.modules if n == "dataloaders" or n.startswith("dataloaders.")]:
+        monkeypatch.delitem(sys.modules, name)

@@ -34,16 +34,51 @@ def test_bench_single_gpu_json_contract():
 
 
 def test_bench_two_ranks_share_gpu():
+    """The driver's own command line: plain `python bench.py --gpus 2` spawns its two ranks itself."""
     env = dict(os.environ, LR_BENCH_SHARE_GPU="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-                        "--warmup", "0", "--no-roofline", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-roofline",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = _json_lines(p.stdout)
     assert len(lines) == 1, p.stdout[-2000:]      # rank 0 only
     r = lines[0]
-    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak" and r["config"]["ranks"] == 2
+
+
+def test_bench_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_bench_mv_shard_four_ranks_share_gpu():
+    """configs[3] in its sharded form (one canvas per rank, per-block exchange) through the driver-style command; the four ranks
+    share the GPU over gloo here, so the step runs eagerly (the hipGraph with its RCCL collectives needs `nccl`)."""
+    env = dict(os.environ, LR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "mv5", "--mv-shard", "--steps", "1",
+                        "--warmup", "0", "--ddim-steps", "2", "--no-roofline", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = _json_lines(p.stdout)[0]
+    assert r["n_gpus"] == 4 and r["unit"] == "samples/s" and r["scaling"] == "strong" and r["config"]["global_batch"] == 1
+    assert "mv-shard x4" in r["config"]["parallelism"] and r["value"] > 0
+
+
+def test_bench_split_cfg_two_ranks_share_gpu():
+    env = dict(os.environ, LR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--split-cfg", "--steps", "1", "--warmup", "0",
+                        "--ddim-steps", "5", "--no-roofline", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = _json_lines(p.stdout)[0]
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and "split-cfg x2" in r["config"]["parallelism"] and r["value"] > 0
 
 
 def test_train_workload_two_ranks_share_gpu():

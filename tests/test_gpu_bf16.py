@@ -352,3 +352,12 @@ def test_training_step_bf16_vs_reference_golden(golden, case, B, h, w, ts):
           f"|grad| max {ref.abs().max().item():.3e}")
     assert abs(loss.item() - float(g[case + ".loss"])) <= 1e-2 * float(g[case + ".loss"])
     assert torch.isfinite(grad).all() and rel <= 6e-2
+    # gradients of realistic size (dLoss/deps ~ 1e-6 at B = 16, 64 x 128 x 4) must not take an fp16 detour: the
+    # same backward with the loss scaled by 2^-14 has to give the same gradient up to that factor (bf16 keeps fp32's exponent)
+    c_cross.grad = None
+    loss2, _ = m.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [c_cross]}, t, noise=noise)
+    (loss2 * 2.0 ** -14).backward()
+    small = c_cross.grad.float().cpu() * 2.0 ** 14
+    rel2 = ((small - grad).norm() / grad.norm()).item()
+    print(f"[bf16 train {case}] gradient from a 2^-14-scaled loss: rel_l2 {rel2:.3e} vs the unscaled one")
+    assert rel2 <= 1e-2

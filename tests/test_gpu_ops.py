@@ -324,6 +324,28 @@ def test_gemm_row_stats_and_layernorm_fold(tile):
         report(name + " consumer", y, ref, rtol=4e-3, atol=4e-3)
 
 
+def test_layernorm_fold_large_mean_rows():
+    """rows with |mean| >> std (outlier / massive-activation tokens).  The fold derives mean / rstd from
+    (sum, sumsq) partials, combined in fp64 inside the consumer: the result must track the two-pass LayerNorm."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    C, N2, M = 320, 320, 256
+    x = G.T("lnbig.x", (M, C)) * 0.5
+    x[::3] += 40.0                       # every third row: mean 40, std 0.5
+    x[1::3] -= 25.0
+    x = h16(x)
+    xf = x.float()
+    st = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).reshape(M, 1, 2).contiguous().to(d)
+    gam = 1.0 + 0.3 * G.T("lnbig.g", (C,))
+    bet = 0.2 * G.T("lnbig.be", (C,))
+    w1 = h16(torch.from_numpy(weights.fill_like("lnbig.w1", (N2, C))))
+    ref = F.linear(F.layer_norm(xf, (C,), gam, bet, 1e-5), w1)
+    wf, bf, cs = packing.fold_layernorm(w1, None, gam, bet)
+    y = ops.gemm_conv(x.half().to(d), wf.to(d), B=1, H=1, W=M, taps=1, bias=bf.to(d), ln=(st, 1e-5, cs.to(d)))
+    # fp32 (sum, sumsq) carry ~1e-7 * mean^2 / var of relative error into the variance (6e-4 here): graceful, not a collapse
+    report("layernorm fold, large-mean rows", y, ref, rtol=6e-3, atol=6e-3)
+
+
 @pytest.mark.parametrize("tile", [(128, 64), (128, 128), (256, 128), (256, 256), (256, 320), (128, 128, 4)],
                          ids=lambda t_: "x".join(map(str, t_)))
 def test_geglu_layernorm_fold(tile):

@@ -140,6 +140,43 @@ def test_sampler_shared_prefix_matches_full_cfg(monkeypatch):
         unet._graphs.clear()
 
 
+def test_sampler_split_cfg_matches_joint_cfg():
+    """Split classifier-free guidance (leftrefill_amd.dist.enable_split_cfg: the unconditional and the conditional pass run as
+    two UNet calls of batch B -- on two ranks when a process group exists, one after the other here) against the reference's
+    joint [uncond; cond] batch of 2B (ddim.py:317-343): the same samples up to fp16 noise (different tile plans for M and 2M)."""
+    from leftrefill_amd import dist as lrd
+    dev = torch.device("cuda:0")
+    m, cfg = model(dev)
+    B, h, w = 2, 16, 32
+    x_T = G.T("spl.x_T", (B, 4, h, w)).to(dev)
+    cond = {"c_concat": [G.T("spl.cc", (B, 5, h, w)).to(dev)], "c_crossattn": [G.T("spl.c", (B, 77, cfg.context_dim)).to(dev)]}
+    uc = {"c_concat": [cond["c_concat"][0].clone()], "c_crossattn": [G.T("spl.uc", (B, 77, cfg.context_dim)).to(dev)]}
+    calls = []
+    orig_apply = m.apply_model
+
+    def spy(x, t, c, **kw):
+        calls.append(x.shape[0])
+        return orig_apply(x, t, c, **kw)
+    m.apply_model = spy
+    try:
+        joint, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=6, eta=0.0, x_T=x_T,
+                                unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+        assert calls == [2 * B] * 6
+        calls.clear()
+        lrd.enable_split_cfg(True)
+        try:
+            split, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=6, eta=0.0, x_T=x_T,
+                                    unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+        finally:
+            lrd.enable_split_cfg(False)
+        assert calls == [B] * 12
+    finally:
+        m.apply_model = orig_apply
+    rel = ((split - joint).norm() / joint.norm()).item()
+    print(f"[split cfg vs joint cfg] rel_l2 {rel:.3e}")
+    assert torch.isfinite(split).all() and rel < 2e-2
+
+
 def test_log_images_end_to_end_glue():
     """RefInpaintLDM.log_images (ref_inpainting_ldm.py:37-72): VAE encode of image / masked image, nearest mask
     down-sampling, channel order [z | mask | masked latent], unconditional prompt, 50->5 step CFG sampling, VAE decode.

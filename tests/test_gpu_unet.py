@@ -4,9 +4,11 @@ Whole-network tolerance.  The reference runs this path under fp16 autocast; roun
 fp16 moves the output of the 60-layer UNet by ~2e-3 relative (measured with the oracle's `autocast16` emulation
 against its fp32 mode -- see test_oracle_golden.py).  No fp16 pipeline can therefore match the fp32 golden
 element-wise at atol 1e-3; the whole-UNet criterion is:
-  (1) relative L2 error vs the fp32 golden <= 1.5 x the autocast16-emulation's own error (we are at least as
-      accurate as the reference's production numerics), and <= 4e-3 absolute cap;
-  (2) element-wise |err| <= atol 1e-3 + rtol 2e-3 |ref| scaled by the same emulation factor (max-norm).
+  (1) relative L2 error vs the fp32 golden <= the autocast16-emulation's own error (we are at least as accurate as
+      the reference's production numerics; no slack factor), and <= 4e-3 absolute cap;
+  (2) the fraction of elements outside atol 1e-3 + rtol 2e-3 |ref| is no larger than the emulation's, max-abs within
+      2x the emulation's, and HIP against the emulation is bounded by the sum of the two errors (assert_unet_row);
+      every case's numbers are written to profiles/rNN_parity_table.txt by tools/parity_table.py.
 Per-operator tests (test_gpu_ops.py) use the north-star rtol 2e-3 / atol 1e-3 directly.
 """
 import numpy as np
@@ -105,42 +107,67 @@ def get_model(cname, multiview=None):
     return _models[key]
 
 
-def check_unet(golden, case, cname, N, H, W, ts, fname="unet", multiview=None, bisect=True):
+def measure_unet(case, cname, N, H, W, ts, ref=None, multiview=None, bisect=False, emulate=True):
+    """Runs one whole-UNet case eagerly and through the hipGraph and returns its parity metrics against `ref` (the reference
+    golden; None: the oracle's fp32 forward, which is pinned to the reference by tests/test_oracle_golden.py):
+    rel-L2 / max-abs / fraction of elements outside the north-star tolerance (rtol 2e-3, atol 1e-3), for the HIP path and
+    for the oracle's emulation of the reference's own fp16-autocast numerics, plus HIP against that emulation."""
     m, sd, cfg = get_model(cname, multiview)
     x, t, ctx = G.unet_inputs(case, cfg, N, H, W, ts)
-    ref = torch.from_numpy(golden(fname)[case])
     taps = {}
     m.use_hip_graph = False
-    m.__dict__["_lr_taps"] = taps
+    if bisect:
+        m.__dict__["_lr_taps"] = taps
     with torch.no_grad():
         y_eager = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
-    m.__dict__.pop("_lr_taps")
+    m.__dict__.pop("_lr_taps", None)
     m.use_hip_graph = True
     with torch.no_grad():
         y_graph = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
         y_graph2 = m(x.to(dev()), t.to(dev()), ctx.to(dev()))
-    assert y_eager.dtype == torch.float16 and y_eager.shape == ref.shape
+    assert y_eager.dtype == torch.float16
     assert torch.equal(y_eager, y_graph), "hipGraph replay must be bit-identical to eager launches"
     assert torch.equal(y_graph, y_graph2), "replays must be bit-identical"
-    emul = unet_ref.unet_forward(sd, cfg, x, t, ctx, mode="autocast16")
-    rel, mx = stats("unet " + case, y_eager, ref)
-    rel_e, mx_e = stats("  autocast16-emulation " + case, emul, ref)
-    if bisect:
-        otaps = {}
+    otaps = {} if bisect else None
+    if ref is None:
+        ref = unet_ref.unet_forward(sd, cfg, x, t, ctx, taps=otaps)
+    elif bisect:
         unet_ref.unet_forward(sd, cfg, x, t, ctx, taps=otaps)
+    assert y_eager.shape == ref.shape
+    rel, mx = stats("unet " + case, y_eager, ref)
+    row = dict(case=case, shape=tuple(ref.shape), rel=rel, max_abs=mx, viol=viol_frac(y_eager, ref), ref_absmax=ref.abs().max().item())
+    if emulate:
+        emul = unet_ref.unet_forward(sd, cfg, x, t, ctx, mode="autocast16")
+        rel_e, mx_e = stats("  autocast16-emulation " + case, emul, ref)
+        row.update(rel_emu=rel_e, max_abs_emu=mx_e, viol_emu=viol_frac(emul, ref), viol_hip_vs_emu=viol_frac(y_eager, emul),
+                   rel_hip_vs_emu=((y_eager.float().cpu() - emul).norm() / emul.norm()).item())
+        print(f"    north-star rtol 2e-3 / atol 1e-3 violations: HIP vs fp32 {100 * row['viol']:.3f} %  autocast16-emulation vs "
+              f"fp32 {100 * row['viol_emu']:.3f} %  HIP vs emulation {100 * row['viol_hip_vs_emu']:.3f} %  ({ref.numel()} elements)")
+    if bisect:
         for k in otaps:
             e = (taps[k].cpu() - otaps[k]).norm() / otaps[k].norm()
             print(f"    tap {k:6s} rel_l2 {e.item():.3e}")
-    assert rel <= min(max(1.5 * rel_e, 1.5e-3), 4e-3), (rel, rel_e)
-    assert mx <= max(2.0 * mx_e, 5e-3), (mx, mx_e)
-    # element-wise north-star tolerance (fp16 rtol 2e-3 / atol 1e-3) over the WHOLE network: the fraction of outputs
-    # outside it, for the HIP path and for the reference's own fp16-autocast numerics (oracle emulation), both against
-    # the fp32 golden, and HIP against the emulation.  No fp16 pipeline of ~60 layers meets it on every element; the bound
-    # is that the HIP path violates it no more often than the reference's own precision mode does.
-    v_hip, v_emu, v_he = viol_frac(y_eager, ref), viol_frac(emul, ref), viol_frac(y_eager, emul)
-    print(f"    north-star rtol 2e-3 / atol 1e-3 violations: HIP vs fp32 {100 * v_hip:.3f} %  autocast16-emulation vs fp32 "
-          f"{100 * v_emu:.3f} %  HIP vs emulation {100 * v_he:.3f} %  ({ref.numel()} elements)")
-    assert v_hip <= 1.25 * v_emu + 2e-3, (v_hip, v_emu)
+    return row
+
+
+def assert_unet_row(row):
+    """Whole-network criterion (no slack factors).  Against the fp32 reference the HIP path is at least as
+    accurate as the reference's own fp16-autocast numerics (oracle emulation) in relative L2 and in the fraction of elements
+    outside the north-star tolerance; its largest error stays within 2x the emulation's (a max over ~1e5..1e6 elements is a
+    noisy statistic); and HIP against the emulation is bounded too (two fp16 pipelines around the same fp32 answer differ by
+    at most the sum of their errors)."""
+    rel, rel_e = row["rel"], row["rel_emu"]
+    assert rel <= min(rel_e, 4e-3), (rel, rel_e)
+    assert row["max_abs"] <= max(2.0 * row["max_abs_emu"], 5e-3), (row["max_abs"], row["max_abs_emu"])
+    assert row["viol"] <= row["viol_emu"], (row["viol"], row["viol_emu"])
+    assert row["rel_hip_vs_emu"] <= rel + rel_e, (row["rel_hip_vs_emu"], rel, rel_e)
+
+
+def check_unet(golden, case, cname, N, H, W, ts, fname="unet", multiview=None, bisect=True):
+    ref = torch.from_numpy(golden(fname)[case])
+    row = measure_unet(case, cname, N, H, W, ts, ref=ref, multiview=multiview, bisect=bisect)
+    assert_unet_row(row)
+    return row
 
 
 def viol_frac(out, ref, rtol=2e-3, atol=1e-3):
@@ -246,11 +273,38 @@ def test_context_kv_cache_is_invalidated_correctly():
     assert not torch.equal(ref_a, ref_b)
 
 
+def test_unet_full_width_headline_resolution_vs_oracle():
+    """the shipped 866 M-parameter UNet at the HEADLINE resolution (configs[1]: latent 64x128) with N = 2,
+    HIP vs the CPU oracle's fp32 forward (~25 s on the GPU box's host cores) and vs its fp16-autocast emulation -- the same
+    criterion as every other whole-network case.  (The oracle restatement is pinned to the real reference by the goldens of
+    tests/test_oracle_golden.py, incl. this config at 8x16 / 16x32.)"""
+    row = measure_unet("unet_full_64x128_headline", "FULL", 2, 64, 128, [981, 21])
+    assert_unet_row(row)
+
+
+def test_multiview_mv5_full_size_sample_vs_oracle():
+    """One mv5 sample of BASELINE configs[3] at full size: view_num = 5, concat_target (4 canvases [ref_i | target] of latent
+    64x128, re-arranged cross-view self-attention over 5 x 4096 = 20 480 tokens), full width, HIP vs the oracle's fp32 forward."""
+    V, concat = 5, True
+    install()
+    from ldm.modules.diffusionmodules.multiview_unet import MultiViewUnetModel
+    cfg = unet_ref.UNetConfig(multiview=True, view_num=V, concat_target=concat)      # shipped widths (320, 64-channel heads, ctx 1024)
+    key = ("MV_FULL", (V, concat))
+    if key not in _models:
+        m = MultiViewUnetModel(**cfg.kwargs())
+        sd = weights.fill_state_dict(unet_ref.param_shapes(cfg), prefix="unet.MVF.")
+        m.load_state_dict(sd, strict=True)
+        _models[key] = (m.to(dev()).eval(), sd, cfg)
+    row = measure_unet("mv5_full_64x128", "MV_FULL", 4, 64, 128, [501] * 4, multiview=(V, concat), emulate=False)
+    assert row["rel"] <= 4e-3 and row["viol"] <= 0.2, row
+
+
 def test_full_size_properties_config2():
-    """BASELINE configs[1] shape (full width, latent 64x128, UNet batch 8) -- too large for the CPU oracle, so
-    size-independent properties: reruns and hipGraph replay are bit-identical; the network is equivariant to a permutation
-    of the batch (bit-exact: every row / sample is computed independently of its position); the two halves of the batch
-    run separately agree with the joint run to fp16 noise (tile / split-K choices are functions of M, so not bit-exact)."""
+    """BASELINE configs[1] shape (full width, latent 64x128, UNet batch 8): size-independent properties on top of the direct
+    oracle comparison at this resolution (test_unet_full_width_headline_resolution_vs_oracle): reruns and hipGraph replay are
+    bit-identical; the network is equivariant to a permutation of the batch (bit-exact: every row / sample is computed
+    independently of its position); the two halves of the batch run separately agree with the joint run to fp16 noise
+    (tile / split-K choices are functions of M, so not bit-exact)."""
     m, sd, cfg = get_model("FULL")
     N, H, W = 8, 64, 128
     x, t, ctx = G.unet_inputs("full_size", cfg, N, H, W, [981, 801, 601, 401, 201, 101, 21, 1])

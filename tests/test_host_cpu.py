@@ -314,6 +314,41 @@ def test_sample_sharding_gloo_world2():
     assert res[0] == (0, True, (0, 3)) and res[1] == (1, True, (3, 5))
 
 
+def _split_cfg_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from leftrefill_amd import dist as lrd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lrd.enable_split_cfg(True)
+    role = lrd.split_cfg_role()
+    e_local = torch.full((3, 4, 2, 2), float(10 * (rank // 2) + role))       # eps half of this rank's pass
+    eps = lrd.cfg_exchange(e_local)
+    ok = (eps.shape == (6, 4, 2, 2) and bool(torch.all(eps[:3] == 10.0 * (rank // 2))) and bool(torch.all(eps[3:] == 10.0 * (rank // 2) + 1)))
+    q.put((rank, role, ok, lrd.split_cfg_active()))
+    lrd.enable_split_cfg(False)
+    dist.destroy_process_group()
+
+
+def test_split_cfg_pairs_gloo_world4():
+    """cond / uncond passes on rank pairs (2 j, 2 j + 1): roles, pair-local all-gather with the unconditional half first."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_cfg_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(4))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, 0, True, True), (1, 1, True, True), (2, 0, True, True), (3, 1, True, True)]
+
+
 def _grad_worker(rank, world, port, q):
     import torch.distributed as dist
     from leftrefill_amd import dist as lrd

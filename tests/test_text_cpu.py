@@ -69,3 +69,69 @@ def test_random_init_and_unconditional_prompt(embedder_cls):
     with torch.no_grad():
         z = emb([""] * 3)          # get_unconditional_conditioning (ref_inpainting_ldm.py:31-35)
     assert z.shape == (3, 77, clip_stub.WIDTH) and torch.isfinite(z).all()
+
+
+@pytest.fixture()
+def stub_open_clip():
+    import leftrefill_amd.dropin as dropin
+    dropin.install()
+    old = sys.modules.get("open_clip")
+    sys.modules["open_clip"] = clip_stub
+    yield
+    if old is None:
+        sys.modules.pop("open_clip", None)
+    else:
+        sys.modules["open_clip"] = old
+
+
+@pytest.mark.parametrize("name,kw,prompts", G.MV_TEXT_CASES, ids=[c[0] for c in G.MV_TEXT_CASES])
+def test_multiview_prompt_embedder_matches_reference(stub_open_clip, name, kw, prompts):
+    """multiview_Refill_modules.PromptCLIPEmbedder (per-view learned tokens, one prompt list per view) vs the reference's own class
+    on the open_clip stand-in (oracle/make_golden_text.py)."""
+    from ldm.modules.encoders.multiview_Refill_modules import PromptCLIPEmbedder
+    g = _gold()
+    emb = PromptCLIPEmbedder(device="cpu", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}).eval()
+    assert len(emb.special_tokens) == int(g[name + ".n_special"])
+    assert torch.equal(emb.special_embeddings.weight.detach(), torch.from_numpy(g[name + ".special_embeddings"]))
+    with torch.no_grad():
+        z = emb(prompts)
+    ref = torch.from_numpy(g[name + ".z"])
+    assert z.shape == ref.shape                      # view prompts: [B * view, 77, C], one context per canvas
+    assert torch.allclose(z, ref, rtol=1e-5, atol=1e-5), (z - ref).abs().max()
+
+
+@pytest.mark.parametrize("name,kw,prompts,pose_shape", G.NVS_TEXT_CASES, ids=[c[0] for c in G.NVS_TEXT_CASES])
+def test_nvs_prompt_embedder_matches_reference(stub_open_clip, name, kw, prompts, pose_shape):
+    """NVS_modules.NVSCLIPEmbedder: pose token from RelPosModel spliced over the last learned token, second pose head on the last
+    output position (pos_strengthen), per-view tokens -- vs the reference's own class on the stand-in."""
+    from ldm.modules.encoders.NVS_modules import NVSCLIPEmbedder
+    g = _gold()
+    emb = NVSCLIPEmbedder(device="cpu", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}).eval()
+    assert torch.equal(emb.special_embeddings.weight.detach(), torch.from_numpy(g[name + ".special_embeddings"]))
+    if emb.rel_pos_model is not None:
+        emb.rel_pos_model.load_state_dict(G.nvs_pose_state(name, emb.rel_pos_model.state_dict()))
+    with torch.no_grad():
+        z = emb(prompts) if pose_shape is None else emb([prompts, G.T(name + ".rel_pos", pose_shape)])
+    ref = torch.from_numpy(g[name + ".z"])
+    if z.shape[-1] > 256:
+        z = z[:, G.NVS_Z_ROWS]
+    assert z.shape == ref.shape
+    assert torch.allclose(z, ref, rtol=1e-5, atol=2e-5), (z - ref).abs().max()
+    if pose_shape is not None:      # the pose really lands where the reference puts it
+        with torch.no_grad():
+            z2 = emb([prompts, G.T(name + ".rel_pos", pose_shape) + 1.0])
+        z2 = z2[:, G.NVS_Z_ROWS] if z2.shape[-1] > 256 else z2
+        assert not torch.allclose(z2, ref)
+
+
+def test_nvs_training_cfg_dropout_replaces_whole_samples(stub_open_clip):
+    from ldm.modules.encoders.NVS_modules import NVSCLIPEmbedder
+    name, kw, prompts, pose_shape = G.NVS_TEXT_CASES[1]
+    emb = NVSCLIPEmbedder(device="cpu", cfg_rate=1.0, freeze=False, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    emb.train()
+    with torch.no_grad():
+        z_drop = emb([prompts, G.T(name + ".rel_pos", pose_shape)])
+        emb.eval()
+        z_null = emb([""] * len(prompts))
+    # cfg_rate = 1: every sample is encoded as the empty prompt, and the second pose head is replaced by the encoder's own output
+    assert torch.allclose(z_drop, z_null, atol=1e-5)
