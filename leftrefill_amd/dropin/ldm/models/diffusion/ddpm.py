@@ -48,6 +48,8 @@ class DiffusionWrapper(nn.Module):
             # a single context tensor is passed through as-is (torch.cat would copy it every step and defeat the
             # UNet's per-context K/V cache); the value is identical
             cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+            if c_input is not None:      # NVS input refinement (reference 1355, inpainting_ldm/NVS_ldm.py:64-68)
+                return self.diffusion_model(xc, t, context=cc, c_input=c_input)
             return self.diffusion_model(xc, t, context=cc)
         raise NotImplementedError(f"conditioning_key {key!r} is not used by the inpainting path")
 

@@ -359,9 +359,18 @@ class UNetModel(nn.Module):
             res.append(ent)
         return res
 
-    def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False):
+    # hooks of subclasses that reshape a block's input / output (inpainting_ldm.NVS_ldm.NVSUnetModel: separator column, c_input)
+    def _block_in(self, act, steps):
+        return act, None
+
+    def _block_out(self, act, state):
+        return act
+
+    def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False, c_input=None):
         """x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,D] fp16 -> eps [N,Cout,H,W] fp16.
-        shared_prefix: x[:N/2] == x[N/2:] and timesteps likewise (see `cfg_shared_prefix`)."""
+        shared_prefix: x[:N/2] == x[N/2:] and timesteps likewise (see `cfg_shared_prefix`).
+        c_input: optional [N, model_channels, H, W (or W/2: right half)] added to the output of the first input block
+        (reference NVS_ldm.py:64-68)."""
         P = self._plan
         E = engine
         N, _, H, W = x.shape
@@ -432,22 +441,44 @@ class UNetModel(nn.Module):
             act = E.Act(ops.nchw_to_nhwc(x, cpad=P["cin_pad"], dtype=self.compute_dtype), N, H, W)
         hs = []
         for i, steps in enumerate(P["input"]):
+            act, bstate = self._block_in(act, steps)
             act = run(steps, act, half=shared and i < 2)
+            if i == 0 and c_input is not None:
+                act = self._add_c_input(act, c_input)
+            act = self._block_out(act, bstate)
             if shared and i == 0:      # the skip connection of the last output block wants the full batch
                 hs.append(E.Act(E.dup2(act.tok), N, act.H, act.W,
                                 gs=None if act.gs is None else (E.dup2(act.gs[0]), act.gs[1])))
             else:
                 hs.append(act)
             tap(f"in{i}", hs[-1])
-        act = run(P["middle"], act)
+        act, bstate = self._block_in(act, P["middle"])
+        act = self._block_out(run(P["middle"], act), bstate)
         tap("mid", act)
         for i, steps in enumerate(P["output"]):
             skip = hs.pop()
-            act = run(steps, E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok, gs=act.gs, gs2=skip.gs))   # virtual th.cat([h, hs.pop()], 1)
+            act, bstate = self._block_in(E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok, gs=act.gs, gs2=skip.gs), steps)   # virtual th.cat([h, hs.pop()], 1)
+            act = self._block_out(run(steps, act), bstate)
             tap(f"out{i}", act)
         act = E.gn(act, P["out_norm"], True)
         act = E.conv(act, P["out_conv"])
         return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels)
+
+    def _needs_autograd(self, context):
+        return torch.is_grad_enabled() and context.requires_grad
+
+    def _add_c_input(self, act, c_input):
+        """h += c_input, or its right half when c_input is half as wide (NVS_ldm.py:64-68).  Layout conversion + one add of a
+        [N, H, W, C] tensor per forward (c_input is constant over the DDIM loop); differentiable (torch ops on the token tensor)."""
+        E = engine
+        N, H, W = act.N, act.H, act.W
+        tok = act.materialize().reshape(N, H, W, -1)
+        c = c_input.to(tok.dtype).permute(0, 2, 3, 1)
+        if tuple(c_input.shape[2:]) == (H, W):
+            tok = tok + c
+        else:
+            tok = torch.cat([tok[:, :, :W // 2], tok[:, :, W // 2:] + c], dim=2)
+        return E.Act(tok.reshape(N * H * W, -1).contiguous(), N, H, W)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """eps = UNet(x, t, context).  Returns fp16 (the reference's output dtype under autocast, appendix B)."""
@@ -459,15 +490,16 @@ class UNetModel(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the noisy latent is not produced (p_losses feeds x_noisy without grad)")
         context = context.to(self.compute_dtype).contiguous()
-        if torch.is_grad_enabled() and context.requires_grad:
+        if self._needs_autograd(context):
             # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
             # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
             return self._run_plan(x, timesteps, context)
-        if not self.use_hip_graph:
+        c_input = kwargs.get("c_input")
+        if not self.use_hip_graph or c_input is not None or getattr(self, "eager_only", False):
             # eager inference: the same launches as the captured step (per-context K / V operands computed first), so the
-            # two modes stay bit-identical
+            # two modes stay bit-identical.  (c_input / separator tokens of the NVS UNet: eager only.)
             with torch.no_grad():
-                return self._run_plan(x, timesteps, context, self._context_kv(context))
+                return self._run_plan(x, timesteps, context, self._context_kv(context), c_input=c_input)
         shared = bool(self.cfg_shared_prefix)
         key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared)
         g = self._graphs.pop(key, None)

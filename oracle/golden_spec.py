@@ -227,3 +227,28 @@ NVS_TEXT_CASES = [
     ("txt_nvs_views", dict(layer="last", special_tokens=["repeat_2_<special-token>"], init_text=[_TXT], view_prompt=True, view_num=2,
                            view_token_len=1), ["<special-token0><special-token1><view_direct-1-0>", "<view_direct-0-0>"], None),
 ]
+
+
+# ---- NVS task model (inpainting_ldm/NVS_ldm.py:22-104): NVSUnetModel at the shipped width (the separator tokens are keyed by the
+# SD2 channel counts), latent 8x16 ----------------------------------------------------------------------------------------------
+# (case, use_sep, c_input shape or None, N, H, W, timesteps)
+NVS_UNET_CASES = [
+    ("nvs_sep_cinput", True, (2, 320, 8, 17), 2, 8, 16, [981, 21]),      # separator column + c_input over the whole (W + 1) canvas
+    ("nvs_cinput_half", False, (2, 320, 8, 8), 2, 8, 16, [501, 501]),   # plain UNet + c_input on the right half
+    ("nvs_sep_only", True, None, 2, 8, 16, [701, 301]),
+]
+NVS_SEP_CHANNELS = (9, 320, 640, 1280, 2560, 1920, 960)
+
+
+def nvs_unet_state(use_sep):
+    sd = dict(unet_state("FULL"))
+    if use_sep:
+        for ch in NVS_SEP_CHANNELS:
+            sd[f"sep_token.{ch}"] = torch.from_numpy(weights.fill_like(f"nvs.sep_token.{ch}", (ch,), "normalish"))
+    return sd
+
+
+def nvs_unet_inputs(case, c_shape, N, H, W, ts):
+    x, t, ctx = unet_inputs(case, CONFIGS["FULL"], N, H, W, ts)
+    c_input = None if c_shape is None else T(case + ".c_input", c_shape) * 0.5
+    return x, t, ctx, c_input

@@ -159,17 +159,17 @@ def test_sampler_split_cfg_matches_joint_cfg():
         return orig_apply(x, t, c, **kw)
     m.apply_model = spy
     try:
-        joint, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=6, eta=0.0, x_T=x_T,
+        joint, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=5, eta=0.0, x_T=x_T,
                                 unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
-        assert calls == [2 * B] * 6
+        assert calls == [2 * B] * 5
         calls.clear()
         lrd.enable_split_cfg(True)
         try:
-            split, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=6, eta=0.0, x_T=x_T,
+            split, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=5, eta=0.0, x_T=x_T,
                                     unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
         finally:
             lrd.enable_split_cfg(False)
-        assert calls == [B] * 12
+        assert calls == [B] * 10
     finally:
         m.apply_model = orig_apply
     rel = ((split - joint).norm() / joint.norm()).item()
