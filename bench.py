@@ -49,6 +49,13 @@ def build_model(device, workload="single"):
     dropin.install()
     from inpainting_ldm.ref_inpainting_ldm import RefInpaintLDM
     target, params = "ldm.modules.diffusionmodules.openaimodel.UNetModel", dict(UNET_PARAMS)
+    if workload == "nvs":       # BASELINE configs[4]: the NVS task model (configs/nvs_training_config.yaml: plain UNetModel, no separator tokens)
+        from inpainting_ldm.NVS_ldm import NVSLDM
+        model = NVSLDM(first_stage_config={"target": "torch.nn.Identity"}, cond_stage_config={"target": "torch.nn.Identity"},
+                       unet_config={"target": target, "params": params}, conditioning_key="hybrid", scale_factor=0.18215,
+                       linear_start=0.00085, linear_end=0.0120, timesteps=1000, channels=4, image_size=64, first_stage_key="image",
+                       cond_stage_key="txt", data_config={"img_size": 256})
+        return _init_weights(model, device)
     if workload != "single":
         mv = MV_WORKLOADS[workload]
         target = "ldm.modules.diffusionmodules.multiview_unet.MultiViewUnetModel"
@@ -59,6 +66,10 @@ def build_model(device, workload="single"):
                           conditioning_key="hybrid", scale_factor=0.18215, linear_start=0.00085, linear_end=0.0120,
                           timesteps=1000, channels=4, image_size=64, first_stage_key="image", cond_stage_key="txt",
                           data_config={"img_size": 512})
+    return _init_weights(model, device)
+
+
+def _init_weights(model, device):
     model = model.to(device).eval()
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
@@ -120,8 +131,8 @@ def kernel_roofline(model, batch, B, dump=None):
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
-    rec = {"gemm_conv": [], "attention": [], "xattn_block": []}
-    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block}
+    rec = {"gemm_conv": [], "attention": [], "xattn_block": [], "ffn_block": []}
+    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block, "ffn_block": ops.ffn_block}
 
     def wrap(name):
         def f(*a, **k):
@@ -135,6 +146,8 @@ def kernel_roofline(model, batch, B, dump=None):
                             cat=k.get("x2") is not None, resid=k.get("resid") is not None)
             elif name == "xattn_block":      # fused LayerNorm + to_q + 77-key attention + to_out + residual (level 0)
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], Lc=k["Lc"], heads=k["heads"])
+            elif name == "ffn_block":        # fused LayerNorm + GEGLU projection + gate + second Linear + residual (level 0)
+                desc = dict(M=a[0].shape[0], C=a[0].shape[1], H=a[3].shape[0] * 64)
             else:
                 desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
             rec[name].append((e0, e1, desc))
@@ -146,14 +159,17 @@ def kernel_roofline(model, batch, B, dump=None):
         def arm():
             for k in rec:
                 rec[k].clear()
-            ops.gemm_conv, ops.attention, ops.xattn_block = wrap("gemm_conv"), wrap("attention"), wrap("xattn_block")
+            for n_ in rec:
+                setattr(ops, n_, wrap(n_))
         for _ in range(2):
-            ops.gemm_conv, ops.attention, ops.xattn_block = orig["gemm_conv"], orig["attention"], orig["xattn_block"]
+            for n_ in rec:
+                setattr(ops, n_, orig[n_])
             with torch.no_grad():
                 eager_unet_step(unet, x, t, ctx, hook=arm)
             torch.cuda.synchronize()
     finally:
-        ops.gemm_conv, ops.attention, ops.xattn_block = orig["gemm_conv"], orig["attention"], orig["xattn_block"]
+        for n_ in rec:
+            setattr(ops, n_, orig[n_])
         unet.use_hip_graph = True
     fl = unet_flops(unet, x.shape[2], x.shape[3])
     n = 2 * B
@@ -166,7 +182,8 @@ def kernel_roofline(model, batch, B, dump=None):
     out = {}
     # the fused cross-attention block runs two of the UNet's pointwise linears and a 77-key attention: its flops leave the
     # numerators of the GEMM / attention families (which only count what those kernels still execute)
-    moved = {"gemm": sum(4.0 * d["M"] * d["C"] * d["C"] for _, _, d in rec["xattn_block"]),
+    ffn_fl = lambda d: 6.0 * d["M"] * d["C"] * d["H"]      # [M, C] x [C, 2H] + [M, H] x [H, C]
+    moved = {"gemm": sum(4.0 * d["M"] * d["C"] * d["C"] for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"]),
              "attn": sum(4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
@@ -174,8 +191,13 @@ def kernel_roofline(model, batch, B, dump=None):
                      "tflops": (n * fl[key] - moved[key]) / (ms * 1e-3) / 1e12}
     if rec["xattn_block"]:
         ms = sum(a.elapsed_time(b) for a, b, _ in rec["xattn_block"])
+        fl_x = sum(4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])
         out["xattn_block"] = {"launches": len(rec["xattn_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["xattn_block"]),
-                              "tflops": (moved["gemm"] + moved["attn"]) / (ms * 1e-3) / 1e12}
+                              "tflops": fl_x / (ms * 1e-3) / 1e12}
+    if rec["ffn_block"]:
+        ms = sum(a.elapsed_time(b) for a, b, _ in rec["ffn_block"])
+        out["ffn_block"] = {"launches": len(rec["ffn_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["ffn_block"]),
+                            "tflops": sum(ffn_fl(d) for _, _, d in rec["ffn_block"]) / (ms * 1e-3) / 1e12}
     out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
     out["gemm_conv"]["algorithmic_gflop"] = (n * fl["gemm"] - moved["gemm"]) / 1e9
     # per-shape table of this instrumented step (what tools/kernel_table.py prints from --dump-kernels)
@@ -189,6 +211,9 @@ def kernel_roofline(model, batch, B, dump=None):
             elif name == "xattn_block":
                 key = f'xattn {d["M"]}x{d["C"]} keys{d["Lc"]} (ln + to_q + attention + to_out + resid)'
                 fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
+            elif name == "ffn_block":
+                key = f'ffn {d["M"]}x{d["C"]} hidden{d["H"]} (ln + geglu proj + gate + linear + resid)'
+                fl_ = 6.0 * d["M"] * d["C"] * d["H"]
             else:
                 key = f'attn B{d["B"]} h{d["heads"]} {d["Nq"]}x{d["Nkv"]}'
                 fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
@@ -205,6 +230,8 @@ def kernel_roofline(model, batch, B, dump=None):
                     fl_ = 2.0 * d["M"] * d["N"] * d["K"]
                 elif name == "xattn_block":
                     fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
+                elif name == "ffn_block":
+                    fl_ = 6.0 * d["M"] * d["C"] * d["H"]
                 else:
                     fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
                 rows.append(dict(kernel=name, us=us, tflops=fl_ / us / 1e6, **d))
@@ -278,7 +305,8 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     from leftrefill_amd import dist as lrd
     Bt, h, w = 16, 32, 64
     steps = steps or a.steps
-    model = (model or build_model(device, "single")).train()
+    task = getattr(a, "task", "nvs")
+    model = (model or build_model(device, "nvs" if task == "nvs" else "single")).train()
     bf16 = getattr(a, "dtype", "f16") == "bf16"
     unet = model.model.diffusion_model
     prev_dtype = unet.compute_dtype
@@ -289,7 +317,20 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     g0 = torch.Generator(device=device).manual_seed(99)            # parameters: the SAME initial tokens on every rank
     tokens = torch.nn.Parameter(0.02 * torch.randn(73, 1024, device=device, generator=g0))
     g = torch.Generator(device=device).manual_seed(1099 + rank)     # data: rank-dependent
-    opt = torch.optim.AdamW([tokens], lr=1e-4)
+    trainable = [tokens]
+    pose_mlp = rel_pos = None
+    if task == "nvs":
+        # the NVS prompt encoder's pose token (ldm/modules/encoders/NVS_modules.py:92-106, 219-224): RelPosModel(4 -> 512 -> 1024) of the
+        # relative camera pose, trained with the prompt tokens (NVS_ldm.py:326-329); here it is added at its token slot of the context
+        # (the CLIP tower between the token embeddings and the context needs the absent open_clip weights)
+        import leftrefill_amd.dropin as dropin
+        dropin.install()
+        from ldm.modules.encoders.NVS_modules import RelPosModel
+        torch.manual_seed(7)                                        # same initial pose MLP on every rank
+        pose_mlp = RelPosModel(input_ch=4, out_ch=1024).to(device)
+        rel_pos = torch.randn(Bt, 4, device=device, generator=g)
+        trainable += list(pose_mlp.parameters())
+    opt = torch.optim.AdamW(trainable, lr=1e-4)
     base_ctx = torch.randn(Bt, 77, 1024, device=device, generator=g)
     c_concat = torch.randn(Bt, 5, h, w, device=device, generator=g)
     x_start = torch.randn(Bt, 4, h, w, device=device, generator=g)
@@ -308,15 +349,18 @@ def train_bench(a, rank, world, device, model=None, steps=None):
 
     def body():
         ctx = torch.cat([base_ctx[:, :1], base_ctx[:, 1:74] + tokens, base_ctx[:, 74:]], dim=1)
+        if pose_mlp is not None:
+            ctx = torch.cat([ctx[:, :74], ctx[:, 74:75] + pose_mlp(rel_pos)[:, None], ctx[:, 75:]], dim=1)
         loss, _ = model.p_losses(x_start, {"c_concat": [c_concat], "c_crossattn": [ctx]}, t_buf, noise=noise_buf)
         (loss * scaler["scale"]).backward()
-        lrd.allreduce_mean_grads([tokens])           # after the reduction every rank sees the same gradient -> same decision
-        if not torch.cuda.is_current_stream_capturing() and not bool(torch.isfinite(tokens.grad).all()):
+        lrd.allreduce_mean_grads(trainable)          # after the reduction every rank sees the same gradient -> same decision
+        if not torch.cuda.is_current_stream_capturing() and not all(bool(torch.isfinite(p_.grad).all()) for p_ in trainable):
             scaler["scale"] *= 0.5
             scaler["good"] = 0
             scaler["skipped"] += 1
             return loss
-        tokens.grad /= scaler["scale"]
+        for p_ in trainable:
+            p_.grad /= scaler["scale"]
         opt.step()
         scaler["good"] += 1
         if scaler["good"] % 200 == 0 and not bf16:
@@ -327,7 +371,7 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     if getattr(a, "train_graph", False):
         # whole step (forward, HIP backward, token all-reduce, AdamW) captured into ONE hipGraph; t / noise are refreshed
         # in place before every replay
-        opt = torch.optim.AdamW([tokens], lr=1e-4, capturable=True)
+        opt = torch.optim.AdamW(trainable, lr=1e-4, capturable=True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -387,11 +431,13 @@ def train_bench(a, rank, world, device, model=None, steps=None):
     return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f16", "data": "synthetic",
-            "config": {"workload": "configs[4]: canvas 256x512 (latent 32x64), per-GPU batch 16, "
+            "config": {"workload": ("configs[4] (NVS task model: NVSLDM.p_losses, prompt tokens + pose MLP trainable): " if task == "nvs"
+                                    else "configs[4]-like (RefInpaintLDM): ") + "canvas 256x512 (latent 32x64), per-GPU batch 16, "
                                    + ("bf16 (no loss scale), " if bf16 else "fp16 + dynamic loss scale, ") +
                                    
-                                   "p_losses + backward + AdamW on 73x1024 prompt tokens", "global_batch": world * Bt,
-                       "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the 73x1024 token gradient only)"},
+                                   "p_losses + backward + AdamW on 73x1024 prompt tokens" + (" + RelPosModel (4-512-1024)" if task == "nvs" else ""),
+                       "global_batch": world * Bt, "task": task,
+                       "per_gpu_batch": Bt, "parallelism": f"dp{world} (all-reduce of the trainable token / pose-MLP gradients only)"},
             "forward_only_ms": fwd_ms, "final_loss": float(loss.detach()), "peak_memory_gib": peak_gb,
             "recompute_in_backward": bool(getattr(a, "recompute", False)), "hip_graph": graph is not None,
             "loss_scale": scaler["scale"], "skipped_steps": scaler["skipped"]}
@@ -526,6 +572,8 @@ def main():
                     help="single workload with B < #GPUs: the unconditional / conditional UNet passes of the same samples on rank "
                          "pairs (2 j, 2 j + 1), one all-gather of the eps halves per DDIM step")
     ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="DDIM steps per sampling (the metric is quoted at 50)")
+    ap.add_argument("--task", default="nvs", choices=["nvs", "refill"],
+                    help="train workload: nvs = BASELINE configs[4] as stated (NVSLDM, prompt tokens + pose MLP); refill = RefInpaintLDM tokens only")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -685,7 +733,7 @@ def main():
                            "algorithmic_gflop_per_unet_step": g["algorithmic_gflop"]}
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
         res["kernel_table"] = kern.get("table", [])[:48]
-        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"),
+        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"),
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline and a.workload == "single":

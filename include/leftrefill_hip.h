@@ -184,7 +184,8 @@ int lr_transpose_v_f16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B,
  *      (f < 4, i < 8) holds channel 32 p + 16 (i >> 2) + 4 f + (i & 3) -- project the context with the same permutation
  *      of to_k.weight's rows;
  *   vt [B][5][2][64][64]: lr_xattn_pack_vt_f16 of the V projection (transposed, key slots in the same order);
- *   wo [320][320] = to_out[0].weight with the in-head COLUMNS in that order, bo [320] = to_out[0].bias (fp32);
+ *   wo [5][320][64] = to_out[0].weight as per-head pieces (piece h = columns 64 h .. 64 h + 63, 40 KB contiguous) with the columns of
+ *      every piece in that order, bo [320] = to_out[0].bias (fp32);
  *   stats_out (optional) [M][2]: per-row (sum, sumsq) of the rounded output (lr_gemm_args.ln_stats of the next GEMM, ln_parts = 1).
  * Anything else (other widths, Lc > 96, ragged M): LR_E_UNSUPPORTED -- callers keep the three-kernel path for those. */
 typedef struct lr_xattn_args {
@@ -199,6 +200,27 @@ typedef struct lr_xattn_args {
 } lr_xattn_args;
 int lr_xattn_block_f16(const lr_xattn_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_f16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
+
+/* ---- fused feed-forward block (C = 320: level 0 of the SD2 UNet) ------------------------------------------------------
+ * replaces: `x = self.ff(self.norm3(x)) + x` (attention.py:282) = norm3 (LayerNorm), GEGLU.proj + `x * F.gelu(gate)` (attention.py:51-58),
+ *           FeedForward.net[2] Linear + bias (attention.py:74-78) and the residual add, in ONE launch: the [M][H] hidden activation
+ *           (168 MB at M = 65536, H = 1280) is never written (instead of LayerNorm-folded GEGLU GEMM -> Linear GEMM).
+ *   x, out [M][320], M % 128 == 0;
+ *   w1 [2H][320] = GEGLU.proj.weight * gamma (LayerNorm folded along K) with its rows interleaved in 16-row groups [u16 | g16 | ...]
+ *      (the layout of lr_gemm_args.geglu == 1), b1 [2H] = proj.weight @ beta + proj.bias in the same row order (fp32);
+ *   w2 [H / 64][320][64] = net[2].weight as 64-column pieces (each 40 KB contiguous) in the k-slot order of lr_xattn_args.wo (inside a
+ *      piece: position 32 p + 8 f + i holds column 32 p + 16 (i >> 2) + 4 f + (i & 3)), b2 [320] = net[2].bias (fp32);  H % 64 == 0, H <= 2048;
+ *   stats_out (optional) [M][2]: per-row (sum, sumsq) of the rounded output.
+ * Other widths / ragged M: LR_E_UNSUPPORTED -- callers keep the two-GEMM path. */
+typedef struct lr_ffn_args {
+  const lr_half* x; lr_half* out;
+  const lr_half* w1; const float* b1;
+  const lr_half* w2; const float* b2;
+  float* stats_out;
+  int32_t M, C, H;
+  float ln_eps;
+} lr_ffn_args;
+int lr_ffn_block_f16(const lr_ffn_args* args, lr_stream_t s);
 
 /* ---- row softmax of materialised logits (VAE AttnBlock: single head, d_head = C = 512) ---------------------------
  * replaces: `w_ = w_ * (int(c)**(-0.5)); w_ = softmax(w_, dim=2)` (ldm/modules/diffusionmodules/model.py:186-187) between
@@ -307,6 +329,7 @@ int lr_attention_vt_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, c
 int lr_transpose_v_bf16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B, int heads, int Nkv, lr_stream_t s);
 int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s);
 int lr_xattn_block_bf16(const lr_xattn_args* args, lr_stream_t s);
+int lr_ffn_block_bf16(const lr_ffn_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_bf16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
 
 #ifdef __cplusplus

@@ -1,0 +1,41 @@
+// Helpers shared by the register-chained fused blocks (xattn_block.hip, ffn_block.hip): each wave owns 16 rows and hands the
+// accumulators of one 16x16x32 MFMA product on as the B operand of the next.
+#pragma once
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void xa_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// reductions over the four lanes (fr, fq = 0..3) that share a row
+__device__ __forceinline__ float xa_row4_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+  const unsigned u2 = __builtin_bit_cast(unsigned, v);
+  const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  v = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+#endif
+  return v;
+}
+__device__ __forceinline__ float xa_row4_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+  const unsigned u2 = __builtin_bit_cast(unsigned, v);
+  const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  v = fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+#endif
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ vec8<T> xa_pack(const f32x4& a, const f32x4& b) {
+  vec8<T> r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = (T)a[i]; r[4 + i] = (T)b[i]; }
+  return r;
+}
+

@@ -1,0 +1,281 @@
+// Fused feed-forward block of BasicTransformerBlock (reference ldm/modules/attention.py:51-78 + 282):
+//
+//     out = x + W2 ( u * gelu_erf(g) ) + b2,      [u | g] = LayerNorm(x) W1^T + b1          (FeedForward with GEGLU, glu=True)
+//
+// as ONE kernel for C = 320 (level 0 of the SD2 UNet, hidden width H = 1280): the [M, 4C] hidden activation never exists in
+// memory.  Unfused, the GEGLU projection writes 168 MB and the second Linear reads them back at M = 65536 -- both GEMMs have
+// K-loops of 5 / 20 steps under epilogues as long as their main loops.
+//
+// Same register-chained structure as xattn_block.hip: block = 8 waves = 128 rows, each wave owns 16 rows; 16x16x32 MFMAs in
+// the swapped form (weights = A operand from LDS, the wave's rows = B operand from registers):
+//     [u | g]^T [64 x 16] = W1_c [64 x 320] . xn^T      chunk c = 32 hidden units, rows interleaved [u16 | g16 | u16 | g16]
+//                                                        (packing.pack_geglu: value and gate land in the same lane)
+//     h^T       [32 x 16] = (u + bu) * gelu(g + bg)      in the accumulator registers, packed to fp16
+//     out^T   [320 x 16] += W2[:, chunk] . h^T           B = the h accumulators: k-slot (fq, i) holds hidden unit
+//                                                        32 c + 16 (i >> 2) + 4 fq + (i & 3)  (W2's columns are stored in that order)
+// Weight ring: 3 LDS slots of 40 KB, one piece per step, loads two steps ahead, counted vmcnt + one barrier per step; per 64
+// hidden units:  W1 chunk 2j (5 sub-tiles [64 x 64])  ->  W1 chunk 2j + 1  ->  W2[:, 64 j .. + 63] ([320 x 64]).  W2 is stored piece by
+// piece ([H / 64][320][64]) so that every piece is 40 KB of consecutive addresses like the W1 pieces: with the Linear's own [320][H]
+// layout the 128-byte rows of a piece sit 2 H bytes apart and all CUs of an XCD hammer half of its L2 channels at the same time.
+// LayerNorm: gamma / beta folded into W1 / b1 (packing.fold_layernorm), rows normalised in registers (two-pass).
+// Epilogue as in xattn_block.hip: + bias -> fp16 -> wave-private LDS rows -> 16-byte pieces: + x, store, optional row statistics.
+#include "chain_common.h"
+
+#define FF_C 320
+#define FF_ROWS 128
+#define FF_THREADS 512
+#define FF_SLOT 40960
+#define FF_PITCH 656
+#define FF_MAX_H 2048          // hidden units whose bias rows fit the LDS region behind the ring
+
+struct FfnParams {
+  const void* x; const void* w1; const float* b1; const void* w2; const float* b2; void* out; float* st_out;
+  int M, H, nblocks;
+  float eps;
+#ifdef LR_FFN_TRACE
+  unsigned long long* trace;   // developer build only: shader-clock stamps [block][8 waves][16] (tools/trace_ffn.py)
+#endif
+};
+
+#ifdef LR_FFN_TRACE
+#define FF_STAMP(k) do { if (P.trace && lane == 0) P.trace[((size_t)blockIdx.x * 8 + w) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+static unsigned long long* g_ff_trace = nullptr;
+extern "C" void lr_ffn_set_trace(void* p) { g_ff_trace = (unsigned long long*)p; }
+#else
+#define FF_STAMP(k) do { } while (0)
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = FF_C, NT = C / 16, KL = C / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* par = reinterpret_cast<float*>(smem + 3 * FF_SLOT);      // [2 H] b1 (interleaved like W1's rows) | [C] b2
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  int bid = blockIdx.x;
+  {
+    const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m_w0 = bid * FF_ROWS + w * 16;
+  const int H2 = 2 * P.H;
+  FF_STAMP(0);
+
+  // ---- this wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 16 fq + 8 u .. + 7]
+  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 16 * fq;
+  vec8<T> xf[KL][2];
+#pragma unroll
+  for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 8 * u);
+  for (int i = t; i < (H2 + C) / 4; i += FF_THREADS) {      // biases -> LDS (no register loads inside the loop below)
+    const float* src = i < H2 / 4 ? P.b1 + 4 * i : P.b2 + 4 * (i - H2 / 4);
+    *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(src);
+  }
+
+  // ---- weight ring
+  const __amdgpu_buffer_rsrc_t rs1 = uniform_rsrc(P.w1, (size_t)H2 * C * 2);
+  const __amdgpu_buffer_rsrc_t rs2 = uniform_rsrc(P.w2, (size_t)C * P.H * 2);
+  const int lrow = w * 8 + (lane >> 3);
+  const int lchunk = (lane & 7) ^ ((lrow >> 1) & 7);
+  auto issue_w1 = [&](int slot, int c, int i) __attribute__((always_inline)) {   // rows 64 c .. + 63 of W1 as 5 sub-tiles [64 x 64 k]
+    const unsigned v0 = (unsigned)(((c * 64 + lrow) * C + lchunk * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(smem + slot * FF_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 128, 0, 0);
+  };
+  auto issue_w2 = [&](int slot, int j, int i) __attribute__((always_inline)) {   // piece j of W2 ([H / 64][320][64]: 40 KB contiguous); rows 64 i + 8 w ..
+    const unsigned v0 = (unsigned)(((j * C + lrow) * 64 + lchunk * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(smem + slot * FF_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 64 * 128, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < KL; ++i) issue_w1(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < KL; ++i) issue_w1(1, 1, i);
+
+  // ---- LayerNorm of the rows in registers (two-pass); gamma / beta live in W1 / b1
+  float s = 0.f;
+#pragma unroll
+  for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (float)xf[t5][u][i];
+  const float mean = xa_row4_sum(s) * (1.0f / C);
+  float q2 = 0.f;
+#pragma unroll
+  for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = (float)xf[t5][u][i] - mean; q2 = fmaf(d, d, q2); }
+  const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
+  const float nmr = -mean * rstd;
+#pragma unroll
+  for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xf[t5][u][i] = (T)fmaf((float)xf[t5][u][i], rstd, nmr);
+
+  FF_STAMP(1);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int sw = (fr >> 1) & 7;
+  auto frag = [&](const char* base, int row, int chunk) -> vec8<T> {
+    return *reinterpret_cast<const vec8<T>*>(base + row * 128 + ((chunk ^ sw) << 4));
+  };
+#define FF_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // [u | g] of chunk c from the W1 piece in `slot`, gated: h (32 hidden units of the wave's 16 rows) as one B operand.
+  // `issue(i)`: the i-th LDS-DMA instruction of the piece this step prefetches, placed between the MFMA groups.
+  auto proj_chunk = [&](int slot, int c, auto&& issue) __attribute__((always_inline)) -> vec8<T> {
+    const char* Ws = smem + slot * FF_SLOT;
+    f32x4 pa[4] = {z4, z4, z4, z4};
+    vec8<T> fa[2][4];
+    auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 2 * fq + (ks & 1));
+    };
+    rd(0, fa[0]);
+#pragma unroll
+    for (int ks = 0; ks < 2 * KL; ++ks) {
+      if (ks + 1 < 2 * KL) rd(ks + 1, fa[(ks + 1) & 1]);
+      FF_FENCE();
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) pa[jd] = lr_mfma16(fa[ks & 1][jd], xf[ks >> 1][ks & 1], pa[jd]);
+      if (ks < KL) issue(ks);
+      FF_FENCE();
+    }
+    // tiles: 0 = u (units 0..15 of the chunk), 1 = their gates, 2 = u (16..31), 3 = gates
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) pa[jd] += *reinterpret_cast<const f32x4*>(par + c * 64 + jd * 16 + 4 * fq);
+    f32x4 h0, h1;
+    {
+      const f32x2_t a = lr_gelu_erf2((f32x2_t){pa[1][0], pa[1][1]}), b = lr_gelu_erf2((f32x2_t){pa[1][2], pa[1][3]});
+      h0 = (f32x4){pa[0][0] * a[0], pa[0][1] * a[1], pa[0][2] * b[0], pa[0][3] * b[1]};
+      const f32x2_t c2 = lr_gelu_erf2((f32x2_t){pa[3][0], pa[3][1]}), d2 = lr_gelu_erf2((f32x2_t){pa[3][2], pa[3][3]});
+      h1 = (f32x4){pa[2][0] * c2[0], pa[2][1] * c2[1], pa[2][2] * d2[0], pa[2][3] * d2[1]};
+    }
+    return xa_pack<T>(h0, h1);
+  };
+
+  const int nsuper = P.H / 64;
+#pragma unroll 1
+  for (int j = 0; j < nsuper; ++j) {
+    const bool more = j + 1 < nsuper;
+    // ---- step A1: chunk 2j (slot 0); W2 columns 64 j .. go to slot 2
+    xa_wait_vmcnt<5>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j < 3) FF_STAMP(2 + 4 * j);
+    const vec8<T> hb0 = proj_chunk(0, 2 * j, [&](int i) __attribute__((always_inline)) { issue_w2(2, j, i); });
+    // ---- step A2: chunk 2j + 1 (slot 1); the next super-chunk's first W1 piece goes to slot 0
+    if (j < 3) FF_STAMP(3 + 4 * j);
+    xa_wait_vmcnt<5>();
+    __builtin_amdgcn_s_barrier();
+    if (j < 3) FF_STAMP(4 + 4 * j);
+    const vec8<T> hb1 = proj_chunk(1, 2 * j + 1, [&](int i) __attribute__((always_inline)) { if (more) issue_w1(0, 2 * j + 2, i); });
+    // ---- step C: out^T += W2[:, 64 j ..] h^T (slot 2); the next super-chunk's second W1 piece goes to slot 1
+    if (more) xa_wait_vmcnt<5>(); else xa_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (j < 3) FF_STAMP(5 + 4 * j);
+    {
+      const char* Os = smem + 2 * FF_SLOT;
+      vec8<T> fa[2][4];
+      auto rd = [&](int g, vec8<T> (&f)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = frag(Os, (4 * (g % 5) + q) * 16 + fr, 4 * (g / 5) + fq);
+      };
+      rd(0, fa[0]);
+#pragma unroll
+      for (int g = 0; g < 10; ++g) {
+        if (g + 1 < 10) rd(g + 1, fa[(g + 1) & 1]);
+        FF_FENCE();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * (g % 5) + q] = lr_mfma16(fa[g & 1][q], g < 5 ? hb0 : hb1, acc[4 * (g % 5) + q]);
+        if (more && g < KL) issue_w1(1, 2 * j + 3, g);
+        FF_FENCE();
+      }
+    }
+  }
+#undef FF_FENCE
+
+  // ---- epilogue: (acc + b2) -> fp16 -> this wave's 16 LDS rows -> 16-byte pieces: + x, store, row statistics
+  FF_STAMP(14);
+  __syncthreads();
+  char* stg = smem + w * (16 * FF_PITCH);
+  const float* pb2 = par + H2;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const f32x4 v = acc[j] + *reinterpret_cast<const f32x4*>(pb2 + j * 16 + 4 * fq);
+    vec4<T> hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
+    *reinterpret_cast<vec4<T>*>(stg + fr * FF_PITCH + (j * 16 + 4 * fq) * 2) = hv;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int row = lane >> 2, sub = lane & 3;
+  const T* xr = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + row) * C;
+  T* orow = reinterpret_cast<T*>(P.out) + (size_t)(m_w0 + row) * C;
+  float s1 = 0.f, s2 = 0.f;
+  constexpr int NP = C / 32;
+  uint4 rx[NP];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) rx[it] = *reinterpret_cast<const uint4*>(xr + (sub + 4 * it) * 8);
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    const int piece = sub + 4 * it;
+    float a[8], e[8];
+    lr_unpack8<T>(*reinterpret_cast<const uint4*>(stg + row * FF_PITCH + piece * 16), a);
+    lr_unpack8<T>(rx[it], e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += e[i];
+    const uint4 pk = lr_pack8<T>(a);
+    *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
+    lr_unpack8<T>(pk, a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1 += a[i]; s2 = fmaf(a[i], a[i], s2); }
+  }
+  if (P.st_out) {
+    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (sub == 0) {
+      float2 o; o.x = s1; o.y = s2;
+      *reinterpret_cast<float2*>(P.st_out + (size_t)(m_w0 + row) * 2) = o;
+    }
+  }
+#ifdef LR_FFN_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FF_STAMP(15);
+#endif
+#endif
+}
+
+template <typename T>
+static int ffn_block_t(const lr_ffn_args* a, lr_stream_t s) {
+  if (!a || !a->x || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->out) return LR_E_ARG;
+  if (a->M <= 0 || a->H <= 0) return LR_E_ARG;
+  if (a->C != FF_C || a->H % 64 || a->H > FF_MAX_H || a->M % FF_ROWS) return LR_E_UNSUPPORTED;
+  if (((uintptr_t)a->x | (uintptr_t)a->w1 | (uintptr_t)a->b1 | (uintptr_t)a->w2 | (uintptr_t)a->b2 | (uintptr_t)a->out) & 15) return LR_E_ALIGN;
+  if (a->stats_out && ((uintptr_t)a->stats_out & 7)) return LR_E_ALIGN;
+  FfnParams P;
+  P.x = a->x; P.w1 = a->w1; P.b1 = a->b1; P.w2 = a->w2; P.b2 = a->b2; P.out = a->out; P.st_out = a->stats_out;
+  P.M = a->M; P.H = a->H; P.nblocks = a->M / FF_ROWS; P.eps = a->ln_eps;
+#ifdef LR_FFN_TRACE
+  P.trace = g_ff_trace;
+#endif
+  const size_t smem = 3 * FF_SLOT + (size_t)(2 * a->H + FF_C) * sizeof(float);
+  static int attr_smem = 0;
+  if ((int)smem > attr_smem) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_smem = (int)smem;
+  }
+  hipLaunchKernelGGL((ffn_block_kernel<T>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
+  return lr_launch_status();
+}
+
+extern "C" int lr_ffn_block_f16(const lr_ffn_args* a, lr_stream_t s) { return ffn_block_t<f16>(a, s); }
+extern "C" int lr_ffn_block_bf16(const lr_ffn_args* a, lr_stream_t s) { return ffn_block_t<bf16>(a, s); }

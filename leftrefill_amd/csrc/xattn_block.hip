@@ -25,10 +25,7 @@
 // in registers with a two-pass mean / variance (no producer statistics needed).
 // Epilogue: out^T + bias -> fp16 -> wave-private LDS rows -> whole 16-byte pieces: + residual (x, L2-hot), store, and the
 // per-row (sum, sumsq) of the rounded output for the LayerNorm folded into the GEGLU projection that follows.
-#include "common.h"
-
-typedef __attribute__((address_space(3))) void* lptr_t;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "chain_common.h"
 
 #define XA_C 320
 #define XA_HEADS 5
@@ -59,40 +56,6 @@ extern "C" void lr_xattn_set_trace(void* p) { g_xa_trace = (unsigned long long*)
 #else
 #define XA_STAMP(k) do { } while (0)
 #endif
-
-template <int N> __device__ __forceinline__ void xa_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// reductions over the four lanes (fr, fq = 0..3) that share a row
-__device__ __forceinline__ float xa_row4_sum(float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
-  const unsigned u2 = __builtin_bit_cast(unsigned, v);
-  const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-  v = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
-#endif
-  return v;
-}
-__device__ __forceinline__ float xa_row4_max(float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
-  const unsigned u2 = __builtin_bit_cast(unsigned, v);
-  const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-  v = fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
-#endif
-  return v;
-}
-
-template <typename T>
-__device__ __forceinline__ vec8<T> xa_pack(const f32x4& a, const f32x4& b) {
-  vec8<T> r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { r[i] = (T)a[i]; r[4 + i] = (T)b[i]; }
-  return r;
-}
 
 // NKT = 16-key tiles of the context (5: Lc <= 80, 6: Lc <= 96)
 template <typename T, int NKT>
@@ -141,9 +104,9 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
     const unsigned v0 = (unsigned)(((h * 64 + lrow) * C + lchunk * 8) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + slot * XA_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 128, 0, 0);
   };
-  auto issue_wo = [&](int slot, int h, int i) __attribute__((always_inline)) {   // [320 n x 64 k]; wave w: rows 64 i + 8 w .. + 7
-    const unsigned v0 = (unsigned)((lrow * C + h * 64 + lchunk * 8) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + slot * XA_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 64 * C * 2, 0, 0);
+  auto issue_wo = [&](int slot, int h, int i) __attribute__((always_inline)) {   // piece h of Wo ([heads][320 n][64 k], 40 KB contiguous); rows 64 i + 8 w ..
+    const unsigned v0 = (unsigned)(((h * C + lrow) * 64 + lchunk * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lptr_t)(smem + slot * XA_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 64 * 128, 0, 0);
   };
   auto issue_kv = [&](int slot, int h, int i) __attribute__((always_inline)) {   // K [128 keys x 64 d] | V^T 2 x [64 d x 64 key slots]
     if (i < 2) {

@@ -162,6 +162,10 @@ class PackedTBlock:
         perm = packing.geglu_perm(proj.weight.shape[0] // 2, proj.weight.device)
         self.geglu_wf, self.geglu_bf, self.geglu_cs = wf[perm].contiguous(), bf[perm].contiguous(), cs[perm].contiguous()
         self.ff2 = PackedLinear(blk.ff.net[2])
+        self.ff2_x = None
+        if self.ff2.w.shape[0] == ops.FFN_C and self.ff2.w.shape[1] % 64 == 0:
+            # second Linear with its columns in the k-slot order of the fused feed-forward block (lr_ffn_block_f16)
+            self.ff2_x = packing.pack_pieces(blk.ff.net[2].weight.detach(), compute_dtype())
         # multi-view attributes (None for the single-view block)
         self.kv_slot = None   # index into the per-context K/V projection cache (set by UNetModel.prepare)
         self.view_num = getattr(blk, "view_num", None)
@@ -330,6 +334,11 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     ws = fold_ok(x)
     x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
     x, st = x if ws else (x, None)
+    if FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(x.shape[0], x.shape[1], pt.ff2_x.shape[0] * 64):
+        # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
+        ws = want_stats and fold_ok(x)
+        y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, want_stats=ws)
+        return y if ws else (y, None)
     if st is not None:
         g = ops.gemm_conv(x, pt.geglu_wf, B=1, H=1, W=x.shape[0], taps=1, bias=pt.geglu_bf, geglu=True,
                           ln=(st, pt.n3.eps, pt.geglu_cs))
@@ -344,6 +353,8 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
 # Fused cross-attention block for the C = 320 level (needs the per-context K / V^T pack of UNetModel._context_kv);
 # LEFTREFILL_XATTN=0 keeps the to_q -> attention -> to_out launches.
 XATTN = __import__("os").environ.get("LEFTREFILL_XATTN", "1") != "0"
+# Fused feed-forward block for the C = 320 level; LEFTREFILL_FFN_FUSED=0 keeps the GEGLU GEMM -> Linear GEMM launches.
+FFN_FUSED = __import__("os").environ.get("LEFTREFILL_FFN_FUSED", "1") != "0"
 
 # LayerNorm folded into the consuming GEMM (inference path); LEFTREFILL_LN_FOLD=0 runs the stand-alone LayerNorm kernel.
 LN_FOLD = __import__("os").environ.get("LEFTREFILL_LN_FOLD", "1") != "0"

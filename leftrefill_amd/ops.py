@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, XattnArgs
+from ._lib import FfnArgs, GemmArgs, XattnArgs
 
 GN_CHUNKS = 256
 
@@ -429,14 +429,14 @@ def xattn_pack_vt(v, B, heads, Lc, out=None):
 
 def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_stats=False, out=None):
     """x + to_out(attention(LayerNorm(x) Wq, K, V)) in one launch (lr_xattn_block_f16).  wq / bq: LayerNorm-folded to_q;
-    k [B*Lc, ld] = context projection with packing.pack_xattn's row order; vt = xattn_pack_vt(V); wo: column-permuted.
+    k [B*Lc, ld] = context projection with packing.pack_xattn's row order; vt = xattn_pack_vt(V); wo: packing.pack_pieces(to_out).
     Returns out [M, C] (, stats [M, 1, 2] for the LayerNorm fold of the next GEMM)."""
     lib = _lib.load()
     _chk16(x, "x")
     M, C = x.shape
     assert xattn_ok(M, HW, C, heads, Lc), (M, HW, C, heads, Lc)
-    for t_ in (wq, wo):
-        assert t_.dtype == x.dtype and t_.is_contiguous() and t_.shape == (C, C)
+    assert wq.dtype == x.dtype and wq.is_contiguous() and wq.shape == (C, C)
+    assert wo.dtype == x.dtype and wo.is_contiguous() and wo.shape == (heads, C, 64)
     assert bq.dtype == torch.float32 and bo.dtype == torch.float32 and bq.numel() == C and bo.numel() == C
     assert k.dtype == x.dtype and k.stride(1) == 1 and k.shape[0] == (M // HW) * Lc and vt.dtype == x.dtype and vt.is_contiguous()
     if out is None:
@@ -447,6 +447,36 @@ def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_sta
     a.stats_out = _p(stats)
     a.M, a.HW, a.C, a.heads, a.Lc, a.ln_eps, a.scale = M, HW, C, heads, Lc, float(eps), float(scale)
     _lib.check(_fn(lib, "lr_xattn_block_f16", x.dtype)(a, _stream()), "xattn_block")
+    return (out, stats) if want_stats else out
+
+
+FFN_C, FFN_ROWS, FFN_MAX_H = 320, 128, 2048
+
+
+def ffn_ok(M, C, H):
+    """Shapes lr_ffn_block_f16 takes (everything else keeps the GEGLU GEMM -> Linear GEMM path)."""
+    return C == FFN_C and M % FFN_ROWS == 0 and H % 64 == 0 and 0 < H <= FFN_MAX_H
+
+
+def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None):
+    """x + W2 (u * gelu(g)) + b2 with [u | g] = LayerNorm(x) W1^T + b1, in one launch (lr_ffn_block_f16).
+    w1 / b1: LayerNorm-folded GEGLU projection in the interleaved [u16 | g16] row order (packing.pack_geglu / fold_layernorm);
+    w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  Returns out [M, C] (, stats [M, 1, 2])."""
+    lib = _lib.load()
+    _chk16(x, "x")
+    M, C = x.shape
+    H = w2.shape[0] * 64
+    assert ffn_ok(M, C, H), (M, C, H)
+    assert w1.dtype == x.dtype and w1.is_contiguous() and w1.shape == (2 * H, C)
+    assert w2.dtype == x.dtype and w2.is_contiguous() and w2.shape == (H // 64, C, 64)
+    assert b1.dtype == torch.float32 and b1.numel() == 2 * H and b2.dtype == torch.float32 and b2.numel() == C
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(M, 1, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    a = FfnArgs()
+    a.x, a.out, a.w1, a.b1, a.w2, a.b2, a.stats_out = _p(x), _p(out), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats)
+    a.M, a.C, a.H, a.ln_eps = M, C, H, float(eps)
+    _lib.check(_fn(lib, "lr_ffn_block_f16", x.dtype)(a, _stream()), "ffn_block")
     return (out, stats) if want_stats else out
 
 

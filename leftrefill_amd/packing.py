@@ -71,7 +71,15 @@ def xattn_perm(n, device=None):
     return h * 64 + 32 * p + 16 * (i // 4) + 4 * f + (i % 4)
 
 
+def pack_pieces(w, dtype=torch.float16):
+    """[N, K] with K % 64 == 0 -> [K / 64, N, 64]: the 64-column pieces the fused blocks stream through LDS, each piece consecutive
+    in memory, the columns inside every piece in k-slot order (xattn_perm)."""
+    n, k = w.shape
+    perm = xattn_perm(k, w.device)
+    return w[:, perm].to(dtype).reshape(n, k // 64, 64).permute(1, 0, 2).contiguous()
+
+
 def pack_xattn(wk, wo, dtype=torch.float16):
-    """(to_k.weight with its ROWS in k-slot order, to_out[0].weight with its COLUMNS in k-slot order)."""
+    """(to_k.weight with its ROWS in k-slot order, to_out[0].weight as per-head pieces [heads, C, 64] with k-slot column order)."""
     perm = xattn_perm(wk.shape[0], wk.device)
-    return wk[perm].to(dtype).contiguous(), wo[:, perm].to(dtype).contiguous()
+    return wk[perm].to(dtype).contiguous(), pack_pieces(wo, dtype)

@@ -367,6 +367,12 @@ def xattn_block(*a, **k):
     return ops.xattn_block(*a, **k)
 
 
+def ffn_block(*a, **k):
+    """Fused feed-forward block: inference only, looked up on `ops` at call time (see xattn_block)."""
+    assert not _needs_grad(a[0])
+    return ops.ffn_block(*a, **k)
+
+
 def mv_gather(x, b, v, s):
     return _MvGather.apply(x, b, v, s) if _needs_grad(x) else ops.mv_gather(x, b, v, s)
 

@@ -1,0 +1,101 @@
+"""GPU parity of the fused feed-forward block (lr_ffn_block_f16) against the CPU oracle.
+
+Reference semantics: `x = self.ff(self.norm3(x)) + x` (ldm/modules/attention.py:282), FeedForward with GEGLU (attention.py:51-78);
+oracle: unet_ref.layer_norm + unet_ref.feed_forward.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_spec as G, unet_ref, weights  # noqa: E402
+from tests.test_gpu_ops import dev, h16, report  # noqa: E402
+
+C = 320
+
+
+def _params(tag, H):
+    sd = {"f.net.0.proj.weight": h16(torch.from_numpy(weights.fill_like(f"ffb.{tag}.proj.weight", (2 * H, C)))),
+          "f.net.0.proj.bias": torch.from_numpy(weights.fill_like(f"ffb.{tag}.proj.bias", (2 * H,))),
+          "f.net.2.weight": h16(torch.from_numpy(weights.fill_like(f"ffb.{tag}.net2.weight", (C, H)))),
+          "f.net.2.bias": torch.from_numpy(weights.fill_like(f"ffb.{tag}.net2.bias", (C,)))}
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like(f"ffb.{tag}.norm.weight", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like(f"ffb.{tag}.norm.bias", (C,), kind="unit"))
+    return sd, gamma, beta
+
+
+def _oracle(sd, gamma, beta, x):
+    return x + unet_ref.feed_forward(sd, "f", unet_ref.layer_norm(x, gamma, beta), unet_ref._Mode("fp32"))
+
+
+def _run_fused(sd, gamma, beta, x, want_stats=True):
+    from leftrefill_amd import ops, packing
+    d = dev()
+    H = sd["f.net.2.weight"].shape[1]
+    wf, bf, _cs = packing.fold_layernorm(sd["f.net.0.proj.weight"], sd["f.net.0.proj.bias"], gamma, beta)
+    perm = packing.geglu_perm(H)
+    w1, b1 = wf[perm].contiguous().to(d), bf[perm].contiguous().to(d)
+    w2 = packing.pack_pieces(sd["f.net.2.weight"]).to(d)
+    return ops.ffn_block(x.reshape(-1, C).half().to(d), w1, b1, w2, sd["f.net.2.bias"].to(d), eps=1e-5, want_stats=want_stats)
+
+
+@pytest.mark.parametrize("M,H", [(128, 1280), (384, 1280), (256, 64), (128, 2048), (256, 192)])
+def test_ffn_block_vs_oracle(M, H):
+    sd, gamma, beta = _params(f"p{H}", H)
+    x = h16(G.T(f"ffb.{M}.{H}.x", (M, C)) * 1.3 + 0.2)
+    ref = _oracle(sd, gamma, beta, x)
+    out, st = _run_fused(sd, gamma, beta, x)
+    # two chained products with an fp16 hand-off of the gated hidden activation, LayerNorm folded into fp16 weights
+    report(f"ffn M{M} H{H}", out, ref, rtol=3e-3, atol=3e-3)
+    o32 = out.float()
+    torch.testing.assert_close(st[:, 0, 0], o32.sum(1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[:, 0, 1], (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
+
+
+def test_ffn_block_hot_shape_and_reruns():
+    """configs[1] shape of the level-0 blocks: M = 8 x 8192 rows, H = 1280 (sampled rows against the oracle), bit-identical reruns."""
+    M, H = 65536, 1280
+    sd, gamma, beta = _params("hot", H)
+    g = torch.Generator().manual_seed(11)
+    x = h16(torch.randn(M, C, generator=g))
+    out = _run_fused(sd, gamma, beta, x, want_stats=False)
+    out2 = _run_fused(sd, gamma, beta, x, want_stats=False)
+    assert torch.equal(out, out2)
+    rows = torch.arange(0, M, 61)
+    report("ffn hot", out[rows], _oracle(sd, gamma, beta, x[rows]), rtol=3e-3, atol=3e-3)
+
+
+def test_ffn_unsupported_shapes_are_reported():
+    from leftrefill_amd import ops
+    assert not ops.ffn_ok(100, 320, 1280) and not ops.ffn_ok(256, 640, 2560) and not ops.ffn_ok(256, 320, 2112)
+    assert ops.ffn_ok(65536, 320, 1280)
+
+
+def test_engine_transformer_block_fused_ffn_equals_unfused():
+    """Drop-in BasicTransformerBlock at C = 320 through the engine with the fused feed-forward block on / off."""
+    import importlib
+    from leftrefill_amd import engine
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(0)
+    d = dev()
+    blk = att.BasicTransformerBlock(320, 5, 64, context_dim=1024).to(d).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        for n_ in (blk.norm1, blk.norm2, blk.norm3):
+            n_.weight.add_(1.0)
+    x = torch.randn(2, 256, 320, device=d)
+    ctx = torch.randn(2, 77, 1024, device=d)
+    outs = []
+    for flag in (True, False):
+        engine.FFN_FUSED = flag
+        try:
+            with torch.no_grad():
+                outs.append(blk(x, context=ctx).float().cpu())
+        finally:
+            engine.FFN_FUSED = True
+    err = (outs[0] - outs[1]).abs().max().item()
+    print(f"[fused vs unfused feed-forward in BasicTransformerBlock] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
+    assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())

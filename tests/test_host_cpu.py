@@ -106,7 +106,8 @@ def test_xattn_k_slot_permutation():
                 assert got == want
     wk, wo = torch.arange(128.0)[:, None].repeat(1, 8), torch.arange(128.0)[None, :].repeat(4, 1)
     xk, xwo = packing.pack_xattn(wk, wo, torch.float32)
-    assert torch.equal(xk[:, 0], perm.float()) and torch.equal(xwo[0], perm.float())
+    assert torch.equal(xk[:, 0], perm.float())
+    assert xwo.shape == (2, 4, 64) and torch.equal(xwo[0, 0], perm[:64].float()) and torch.equal(xwo[1, 3], perm[64:].float())
 
 
 def test_gemm_plan_is_a_pure_function_of_the_shape():
