@@ -210,7 +210,7 @@ int lr_xattn_pack_vt_f16(const lr_half* v, int ldv, lr_half* vt, int B, int head
  *      (the layout of lr_gemm_args.geglu == 1), b1 [2H] = proj.weight @ beta + proj.bias in the same row order (fp32);
  *   w2 [H / 64][320][64] = net[2].weight as 64-column pieces (each 40 KB contiguous) in the k-slot order of lr_xattn_args.wo (inside a
  *      piece: position 32 p + 8 f + i holds column 32 p + 16 (i >> 2) + 4 f + (i & 3)), b2 [320] = net[2].bias (fp32);  H % 64 == 0, H <= 2048;
- *   stats_out (optional) [M][2]: per-row (sum, sumsq) of the rounded output.
+ *   stats_out (optional) [M][2][2]: per-row (sum, sumsq) of the rounded output, one partial per column half (ln_parts = 2).
  * Other widths / ragged M: LR_E_UNSUPPORTED -- callers keep the two-GEMM path. */
 typedef struct lr_ffn_args {
   const lr_half* x; lr_half* out;

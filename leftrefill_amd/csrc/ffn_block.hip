@@ -6,8 +6,11 @@
 // memory.  Unfused, the GEGLU projection writes 168 MB and the second Linear reads them back at M = 65536 -- both GEMMs have
 // K-loops of 5 / 20 steps under epilogues as long as their main loops.
 //
-// Same register-chained structure as xattn_block.hip: block = 8 waves = 128 rows, each wave owns 16 rows; 16x16x32 MFMAs in
-// the swapped form (weights = A operand from LDS, the wave's rows = B operand from registers):
+// Register-chained like xattn_block.hip (16x16x32 MFMAs in the swapped form: weights = A operand from LDS, rows = B operand from
+// registers), but two waves share 32 rows: block = 8 waves = 4 pairs = 128 rows; a wave computes half of every hidden chunk and owns
+// half of the output columns FOR BOTH 16-row tiles, so each weight fragment read from LDS feeds two MFMAs (the kernel is bound by
+// the LDS -> register fragment stream: with one row tile per wave it ran 23 % slower); the halves of the gated hidden chunk cross
+// between the two waves through a 4 KB LDS hand-off area (8 bytes per lane and row tile), under the step barrier that exists anyway:
 //     [u | g]^T [64 x 16] = W1_c [64 x 320] . xn^T      chunk c = 32 hidden units, rows interleaved [u16 | g16 | u16 | g16]
 //                                                        (packing.pack_geglu: value and gate land in the same lane)
 //     h^T       [32 x 16] = (u + bu) * gelu(g + bg)      in the accumulator registers, packed to fp16
@@ -25,7 +28,11 @@
 #define FF_ROWS 128
 #define FF_THREADS 512
 #define FF_SLOT 40960
-#define FF_PITCH 656
+#define FF_PITCH 336          // bytes per staged row of a wave's 160 output columns (320 + 16: rows start in distinct banks)
+#define FF_PAR_BYTES ((2 * FF_MAX_H + FF_C) * 4)      // bias rows behind the ring
+#ifndef FF_DEPTH
+#define FF_DEPTH 2
+#endif
 #define FF_MAX_H 2048          // hidden units whose bias rows fit the LDS region behind the ring
 
 struct FfnParams {
@@ -48,29 +55,36 @@ extern "C" void lr_ffn_set_trace(void* p) { g_ff_trace = (unsigned long long*)p;
 template <typename T>
 __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int C = FF_C, NT = C / 16, KL = C / 64;
+  constexpr int C = FF_C, KL = C / 64;
+  constexpr int NTW = C / 32;          // output tiles (16 columns) per wave: half of the row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* par = reinterpret_cast<float*>(smem + 3 * FF_SLOT);      // [2 H] b1 (interleaved like W1's rows) | [C] b2
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int pr = w >> 1, role = w & 1;   // wave pair (32 rows) and which half of the work this wave does for it
   const int fr = lane & 15, fq = lane >> 4;
   int bid = blockIdx.x;
   {
     const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m_w0 = bid * FF_ROWS + w * 16;
+  const int m_p0 = bid * FF_ROWS + pr * 32;      // first row of the pair
   const int H2 = 2 * P.H;
+  char* xch = smem + 3 * FF_SLOT + FF_PAR_BYTES + pr * 4096;      // the pair's hand-off area [chunk 2][row tile 2][lane 64][16 B]
   FF_STAMP(0);
 
-  // ---- this wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 16 fq + 8 u .. + 7]
-  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 16 * fq;
-  vec8<T> xf[KL][2];
+  // ---- the pair's 32 rows in B-operand form (both waves hold them): lane (fr, fq), row tile rt holds
+  //      x[m_p0 + 16 rt + fr][64 t5 + 16 fq + 8 u .. + 7]
+  vec8<T> xf[2][KL][2];
 #pragma unroll
-  for (int t5 = 0; t5 < KL; ++t5)
+  for (int rt = 0; rt < 2; ++rt) {
+    const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + 16 * rt + fr) * C + 16 * fq;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 8 * u);
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) xf[rt][t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 8 * u);
+  }
   for (int i = t; i < (H2 + C) / 4; i += FF_THREADS) {      // biases -> LDS (no register loads inside the loop below)
     const float* src = i < H2 / 4 ? P.b1 + 4 * i : P.b2 + 4 * (i - H2 / 4);
     *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(src);
@@ -95,156 +109,181 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
   for (int i = 0; i < KL; ++i) issue_w1(1, 1, i);
 
   // ---- LayerNorm of the rows in registers (two-pass); gamma / beta live in W1 / b1
-  float s = 0.f;
 #pragma unroll
-  for (int t5 = 0; t5 < KL; ++t5)
+  for (int rt = 0; rt < 2; ++rt) {
+    __builtin_amdgcn_sched_barrier(0);      // one row tile at a time (register pressure)
+    float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += (float)xf[t5][u][i];
-  const float mean = xa_row4_sum(s) * (1.0f / C);
-  float q2 = 0.f;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-  for (int t5 = 0; t5 < KL; ++t5)
+        for (int i = 0; i < 8; ++i) s += (float)xf[rt][t5][u][i];
+    const float mean = xa_row4_sum(s) * (1.0f / C);
+    float q2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d = (float)xf[t5][u][i] - mean; q2 = fmaf(d, d, q2); }
-  const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
-  const float nmr = -mean * rstd;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-  for (int t5 = 0; t5 < KL; ++t5)
+        for (int i = 0; i < 8; ++i) { const float d = (float)xf[rt][t5][u][i] - mean; q2 = fmaf(d, d, q2); }
+    const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
+    const float nmr = -mean * rstd;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xf[t5][u][i] = (T)fmaf((float)xf[t5][u][i], rstd, nmr);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[rt][t5][u][i] = (T)fmaf((float)xf[rt][t5][u][i], rstd, nmr);
+  }
 
   FF_STAMP(1);
-  f32x4 acc[NT];
+  f32x4 acc[NTW][2];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NTW; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; }
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const int sw = (fr >> 1) & 7;
   auto frag = [&](const char* base, int row, int chunk) -> vec8<T> {
     return *reinterpret_cast<const vec8<T>*>(base + row * 128 + ((chunk ^ sw) << 4));
   };
 #define FF_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // [u | g] of chunk c from the W1 piece in `slot`, gated: h (32 hidden units of the wave's 16 rows) as one B operand.
-  // `issue(i)`: the i-th LDS-DMA instruction of the piece this step prefetches, placed between the MFMA groups.
-  auto proj_chunk = [&](int slot, int c, auto&& issue) __attribute__((always_inline)) -> vec8<T> {
+  // This wave's half of chunk c (32 hidden units): tiles (u, g) of units 16 role .. 16 role + 15 for both row tiles -- every W1
+  // fragment read from LDS feeds TWO MFMAs.  The gated result goes to the pair's hand-off area as 4 halves per lane and row tile;
+  // the 16 units of the partner come from there in step C.  `issue(i)`: the i-th LDS-DMA instruction of the piece this step prefetches.
+  auto proj_chunk = [&](int slot, int c, int cb, auto&& issue) __attribute__((always_inline)) {
     const char* Ws = smem + slot * FF_SLOT;
-    f32x4 pa[4] = {z4, z4, z4, z4};
-    vec8<T> fa[2][4];
-    auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {
+    f32x4 pa[2][2] = {{z4, z4}, {z4, z4}};      // [u | g][row tile]
+    vec8<T> fa[FF_DEPTH + 1][2];              // fragment reads run FF_DEPTH MFMA groups ahead of their use
+    auto rd = [&](int ks, vec8<T> (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 2 * fq + (ks & 1));
+      for (int ug = 0; ug < 2; ++ug) f[ug] = frag(Ws + (ks >> 1) * 64 * 128, (2 * role + ug) * 16 + fr, 2 * fq + (ks & 1));
     };
-    rd(0, fa[0]);
+#pragma unroll
+    for (int d = 0; d < FF_DEPTH; ++d) rd(d, fa[d]);
 #pragma unroll
     for (int ks = 0; ks < 2 * KL; ++ks) {
-      if (ks + 1 < 2 * KL) rd(ks + 1, fa[(ks + 1) & 1]);
+      if (ks + FF_DEPTH < 2 * KL) rd(ks + FF_DEPTH, fa[(ks + FF_DEPTH) % (FF_DEPTH + 1)]);
       FF_FENCE();
 #pragma unroll
-      for (int jd = 0; jd < 4; ++jd) pa[jd] = lr_mfma16(fa[ks & 1][jd], xf[ks >> 1][ks & 1], pa[jd]);
+      for (int ug = 0; ug < 2; ++ug)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) pa[ug][rt] = lr_mfma16(fa[ks % (FF_DEPTH + 1)][ug], xf[rt][ks >> 1][ks & 1], pa[ug][rt]);
       if (ks < KL) issue(ks);
       FF_FENCE();
     }
-    // tiles: 0 = u (units 0..15 of the chunk), 1 = their gates, 2 = u (16..31), 3 = gates
+    const f32x4 bu = *reinterpret_cast<const f32x4*>(par + c * 64 + (2 * role) * 16 + 4 * fq);
+    const f32x4 bg = *reinterpret_cast<const f32x4*>(par + c * 64 + (2 * role + 1) * 16 + 4 * fq);
 #pragma unroll
-    for (int jd = 0; jd < 4; ++jd) pa[jd] += *reinterpret_cast<const f32x4*>(par + c * 64 + jd * 16 + 4 * fq);
-    f32x4 h0, h1;
-    {
-      const f32x2_t a = lr_gelu_erf2((f32x2_t){pa[1][0], pa[1][1]}), b = lr_gelu_erf2((f32x2_t){pa[1][2], pa[1][3]});
-      h0 = (f32x4){pa[0][0] * a[0], pa[0][1] * a[1], pa[0][2] * b[0], pa[0][3] * b[1]};
-      const f32x2_t c2 = lr_gelu_erf2((f32x2_t){pa[3][0], pa[3][1]}), d2 = lr_gelu_erf2((f32x2_t){pa[3][2], pa[3][3]});
-      h1 = (f32x4){pa[2][0] * c2[0], pa[2][1] * c2[1], pa[2][2] * d2[0], pa[2][3] * d2[1]};
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 u = pa[0][rt] + bu, g = pa[1][rt] + bg;
+      const f32x2_t a = lr_gelu_erf2((f32x2_t){g[0], g[1]}), b = lr_gelu_erf2((f32x2_t){g[2], g[3]});
+      vec4<T> hv = {(T)(u[0] * a[0]), (T)(u[1] * a[1]), (T)(u[2] * b[0]), (T)(u[3] * b[1])};
+      *reinterpret_cast<vec4<T>*>(xch + ((cb * 2 + rt) * 64 + lane) * 16 + role * 8) = hv;
     }
-    return xa_pack<T>(h0, h1);
   };
 
   const int nsuper = P.H / 64;
 #pragma unroll 1
   for (int j = 0; j < nsuper; ++j) {
     const bool more = j + 1 < nsuper;
-    // ---- step A1: chunk 2j (slot 0); W2 columns 64 j .. go to slot 2
+    // ---- step A1: chunk 2j (slot 0); W2 piece j goes to slot 2
     xa_wait_vmcnt<5>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (j < 3) FF_STAMP(2 + 4 * j);
-    const vec8<T> hb0 = proj_chunk(0, 2 * j, [&](int i) __attribute__((always_inline)) { issue_w2(2, j, i); });
+    proj_chunk(0, 2 * j, 0, [&](int i) __attribute__((always_inline)) { issue_w2(2, j, i); });
     // ---- step A2: chunk 2j + 1 (slot 1); the next super-chunk's first W1 piece goes to slot 0
     if (j < 3) FF_STAMP(3 + 4 * j);
     xa_wait_vmcnt<5>();
     __builtin_amdgcn_s_barrier();
     if (j < 3) FF_STAMP(4 + 4 * j);
-    const vec8<T> hb1 = proj_chunk(1, 2 * j + 1, [&](int i) __attribute__((always_inline)) { if (more) issue_w1(0, 2 * j + 2, i); });
-    // ---- step C: out^T += W2[:, 64 j ..] h^T (slot 2); the next super-chunk's second W1 piece goes to slot 1
+    proj_chunk(1, 2 * j + 1, 1, [&](int i) __attribute__((always_inline)) { if (more) issue_w1(0, 2 * j + 2, i); });
+    // ---- step C: out^T += W2[own 160 columns, 64 j ..] h^T (slot 2); the next super-chunk's second W1 piece goes to slot 1
     if (more) xa_wait_vmcnt<5>(); else xa_wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's halves of h are in the hand-off area
     __builtin_amdgcn_s_barrier();
     if (j < 3) FF_STAMP(5 + 4 * j);
     {
       const char* Os = smem + 2 * FF_SLOT;
-      vec8<T> fa[2][4];
-      auto rd = [&](int g, vec8<T> (&f)[4]) __attribute__((always_inline)) {
+      vec8<T> hb[2];                        // [row tile] of the current chunk: k-slots 0-3 = role 0's units, 4-7 = role 1's (W2's column order)
+      auto rd_h = [&](int cb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = frag(Os, (4 * (g % 5) + q) * 16 + fr, 4 * (g / 5) + fq);
+        for (int rt = 0; rt < 2; ++rt) hb[rt] = *reinterpret_cast<const vec8<T>*>(xch + ((cb * 2 + rt) * 64 + lane) * 16);
       };
-      rd(0, fa[0]);
+      rd_h(0);
+      vec8<T> fa[FF_DEPTH + 1][2];
+      // group g: k-step (chunk) g / 5, output tiles 2 (g % 5), + 1 of this wave's 10
+      auto rd = [&](int g, vec8<T> (&f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) f[q] = frag(Os, (role * NTW + 2 * (g % 5) + q) * 16 + fr, 4 * (g / 5) + fq);
+      };
+#pragma unroll
+      for (int d = 0; d < FF_DEPTH; ++d) rd(d, fa[d]);
 #pragma unroll
       for (int g = 0; g < 10; ++g) {
-        if (g + 1 < 10) rd(g + 1, fa[(g + 1) & 1]);
+        if (g + FF_DEPTH < 10) rd(g + FF_DEPTH, fa[(g + FF_DEPTH) % (FF_DEPTH + 1)]);
         FF_FENCE();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[4 * (g % 5) + q] = lr_mfma16(fa[g & 1][q], g < 5 ? hb0 : hb1, acc[4 * (g % 5) + q]);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[2 * (g % 5) + q][rt] = lr_mfma16(fa[g % (FF_DEPTH + 1)][q], hb[rt], acc[2 * (g % 5) + q][rt]);
         if (more && g < KL) issue_w1(1, 2 * j + 3, g);
+        if (g == 4) rd_h(1);
         FF_FENCE();
       }
     }
   }
 #undef FF_FENCE
 
-  // ---- epilogue: (acc + b2) -> fp16 -> this wave's 16 LDS rows -> 16-byte pieces: + x, store, row statistics
+  // ---- epilogue: (acc + b2) -> fp16 -> this wave's LDS area [32 rows][160 columns] -> 16-byte pieces: + x, store, row statistics
   FF_STAMP(14);
   __syncthreads();
-  char* stg = smem + w * (16 * FF_PITCH);
-  const float* pb2 = par + H2;
+  char* stg = smem + w * (32 * FF_PITCH);
+  const float* pb2 = par + H2 + role * (C / 2);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const f32x4 v = acc[j] + *reinterpret_cast<const f32x4*>(pb2 + j * 16 + 4 * fq);
-    vec4<T> hv;
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
-    *reinterpret_cast<vec4<T>*>(stg + fr * FF_PITCH + (j * 16 + 4 * fq) * 2) = hv;
-  }
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 v = acc[j][rt] + *reinterpret_cast<const f32x4*>(pb2 + j * 16 + 4 * fq);
+      vec4<T> hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
+      *reinterpret_cast<vec4<T>*>(stg + (16 * rt + fr) * FF_PITCH + (j * 16 + 4 * fq) * 2) = hv;
+    }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int row = lane >> 2, sub = lane & 3;
-  const T* xr = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + row) * C;
-  T* orow = reinterpret_cast<T*>(P.out) + (size_t)(m_w0 + row) * C;
-  float s1 = 0.f, s2 = 0.f;
-  constexpr int NP = C / 32;
-  uint4 rx[NP];
+  const int sub = lane & 3;
+  constexpr int NP = C / 64;                  // 16-byte pieces per lane and row (4 lanes per row, 20 pieces of the wave's 160 columns)
 #pragma unroll
-  for (int it = 0; it < NP; ++it) rx[it] = *reinterpret_cast<const uint4*>(xr + (sub + 4 * it) * 8);
+  for (int rh = 0; rh < 2; ++rh) {
+    const int row = 16 * rh + (lane >> 2);
+    const T* xr = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + row) * C + role * (C / 2);
+    T* orow = reinterpret_cast<T*>(P.out) + (size_t)(m_p0 + row) * C + role * (C / 2);
+    float s1 = 0.f, s2 = 0.f;
+    uint4 rx[NP];
 #pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const int piece = sub + 4 * it;
-    float a[8], e[8];
-    lr_unpack8<T>(*reinterpret_cast<const uint4*>(stg + row * FF_PITCH + piece * 16), a);
-    lr_unpack8<T>(rx[it], e);
+    for (int it = 0; it < NP; ++it) rx[it] = *reinterpret_cast<const uint4*>(xr + (sub + 4 * it) * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] += e[i];
-    const uint4 pk = lr_pack8<T>(a);
-    *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
-    lr_unpack8<T>(pk, a);
+    for (int it = 0; it < NP; ++it) {
+      const int piece = sub + 4 * it;
+      float a[8], e[8];
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(stg + row * FF_PITCH + piece * 16), a);
+      lr_unpack8<T>(rx[it], e);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1 += a[i]; s2 = fmaf(a[i], a[i], s2); }
-  }
-  if (P.st_out) {
-    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-    if (sub == 0) {
-      float2 o; o.x = s1; o.y = s2;
-      *reinterpret_cast<float2*>(P.st_out + (size_t)(m_w0 + row) * 2) = o;
+      for (int i = 0; i < 8; ++i) a[i] += e[i];
+      const uint4 pk = lr_pack8<T>(a);
+      *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
+      lr_unpack8<T>(pk, a);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1 += a[i]; s2 = fmaf(a[i], a[i], s2); }
+    }
+    if (P.st_out) {      // one partial per wave of the pair: [M][2][2]
+      s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+      if (sub == 0) {
+        float2 o; o.x = s1; o.y = s2;
+        *reinterpret_cast<float2*>(P.st_out + ((size_t)(m_p0 + row) * 2 + role) * 2) = o;
+      }
     }
   }
 #ifdef LR_FFN_TRACE
@@ -267,11 +306,11 @@ static int ffn_block_t(const lr_ffn_args* a, lr_stream_t s) {
 #ifdef LR_FFN_TRACE
   P.trace = g_ff_trace;
 #endif
-  const size_t smem = 3 * FF_SLOT + (size_t)(2 * a->H + FF_C) * sizeof(float);
-  static int attr_smem = 0;
-  if ((int)smem > attr_smem) {
+  const size_t smem = 3 * FF_SLOT + FF_PAR_BYTES + 4 * 4096;      // ring | bias rows | hand-off areas of the four wave pairs
+  static bool attr_done = false;
+  if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_smem = (int)smem;
+    attr_done = true;
   }
   hipLaunchKernelGGL((ffn_block_kernel<T>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
   return lr_launch_status();

@@ -461,7 +461,7 @@ def ffn_ok(M, C, H):
 def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None):
     """x + W2 (u * gelu(g)) + b2 with [u | g] = LayerNorm(x) W1^T + b1, in one launch (lr_ffn_block_f16).
     w1 / b1: LayerNorm-folded GEGLU projection in the interleaved [u16 | g16] row order (packing.pack_geglu / fold_layernorm);
-    w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  Returns out [M, C] (, stats [M, 1, 2])."""
+    w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  Returns out [M, C] (, stats [M, 2, 2])."""
     lib = _lib.load()
     _chk16(x, "x")
     M, C = x.shape
@@ -472,7 +472,7 @@ def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None):
     assert b1.dtype == torch.float32 and b1.numel() == 2 * H and b2.dtype == torch.float32 and b2.numel() == C
     if out is None:
         out = torch.empty_like(x)
-    stats = torch.empty(M, 1, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    stats = torch.empty(M, 2, 2, device=x.device, dtype=torch.float32) if want_stats else None      # one partial per wave of a pair
     a = FfnArgs()
     a.x, a.out, a.w1, a.b1, a.w2, a.b2, a.stats_out = _p(x), _p(out), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats)
     a.M, a.C, a.H, a.ln_eps = M, C, H, float(eps)

@@ -48,8 +48,9 @@ def test_ffn_block_vs_oracle(M, H):
     # two chained products with an fp16 hand-off of the gated hidden activation, LayerNorm folded into fp16 weights
     report(f"ffn M{M} H{H}", out, ref, rtol=3e-3, atol=3e-3)
     o32 = out.float()
-    torch.testing.assert_close(st[:, 0, 0], o32.sum(1), rtol=1e-5, atol=1e-3)
-    torch.testing.assert_close(st[:, 0, 1], (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
+    assert st.shape == (M, 2, 2)          # (sum, sumsq) partials of the two column halves
+    torch.testing.assert_close(st[:, :, 0].sum(1), o32.sum(1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[:, :, 1].sum(1), (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
 
 
 def test_ffn_block_hot_shape_and_reruns():
