@@ -889,7 +889,10 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
 #define RED_GROUPS 16     // 8-channel groups per block: 128 channels x 32 rows = 512 threads; 1024 x 1280 outputs -> 320 blocks
 template <typename T>
 __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(const GemmParams P) {
-  __shared__ float red[RED_ROWS][RED_GROUPS][17];     // 17: conflict-free column reads
+  // [value j of 16][row][group] with 16 floats of padding per j: the writes of a half-wave (16 groups x 2 rows) and the column
+  // reads of a half-wave (16 groups x 2 values) both touch 32 distinct banks (the round-2 [row][group][17] layout put two of the
+  // four channel groups a wave reads on the same banks: 33 % conflict cycles, profiles/r02_pmc_util.txt)
+  __shared__ float red[16][RED_ROWS * RED_GROUPS + 16];
   const int tx = threadIdx.x % RED_GROUPS, ty = threadIdx.x / RED_GROUPS;
   const int n = (blockIdx.x * RED_GROUPS + tx) * 8;
   const int m = blockIdx.y * RED_ROWS + ty;
@@ -946,15 +949,15 @@ __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(co
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float x = ok ? v[i] : 0.f;
-      red[ty][tx][2 * i] = x; red[ty][tx][2 * i + 1] = x * x;
+      red[2 * i][ty * RED_GROUPS + tx] = x; red[2 * i + 1][ty * RED_GROUPS + tx] = x * x;
     }
     __syncthreads();
     // RED_GROUPS channel groups x 16 values, summed over the 32 rows in a fixed order by the first 16 RED_GROUPS threads
     if (threadIdx.x < 16 * RED_GROUPS) {
-      const int cg = threadIdx.x >> 4, pr = threadIdx.x & 15;
+      const int pr = threadIdx.x >> 4, cg = threadIdx.x & 15;
       float s = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < RED_ROWS; ++k) s += red[k][cg][pr];
+      for (int k = 0; k < RED_ROWS; ++k) s += red[pr][k * RED_GROUPS + cg];
       const int nn = (blockIdx.x * RED_GROUPS + cg) * 8;
       if (nn < P.N) P.gs_out[((size_t)blockIdx.y * P.N + nn) * 2 + pr] = s;      // [row block][N][2], (sum, sumsq) interleaved
     }
