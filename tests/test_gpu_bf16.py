@@ -202,6 +202,44 @@ def test_attention_bf16(B, heads, Nq, Nkv):
     report(f"attention(V^T) {Nq}x{Nkv}", o2.reshape(B, Nq, C), ref, atol=1.6e-2)
 
 
+def test_fused_blocks_bf16():
+    """bf16 instances of the register-chained kernels of the C = 320 level (lr_xattn_block_bf16, lr_ffn_block_bf16) vs the
+    oracle on bf16-rounded operands."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    C, H, heads, B, L, Lc = 320, 1280, 5, 2, 128, 77
+    m = unet_ref._Mode("fp32")
+    sd = {f"a.{k}.weight": b16(torch.from_numpy(weights.fill_like(f"fb16.{k}", (C, C if k == "to_q" else 1024)))) for k in ("to_q", "to_k", "to_v")}
+    sd["a.to_out.0.weight"] = b16(torch.from_numpy(weights.fill_like("fb16.to_out", (C, C))))
+    sd["a.to_out.0.bias"] = torch.from_numpy(weights.fill_like("fb16.to_out.b", (C,)))
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like("fb16.g", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like("fb16.b", (C,), kind="unit"))
+    x = b16(G.T("fb16.x", (B, L, C)))
+    ctx = b16(G.T("fb16.ctx", (B, Lc, 1024)))
+    ref = x + unet_ref.cross_attention(sd, "a", unet_ref.layer_norm(x, gamma, beta), ctx, heads, m)
+    wq, bq, _ = packing.fold_layernorm(sd["a.to_q.weight"], None, gamma, beta, BF)
+    xk_w, xwo = packing.pack_xattn(sd["a.to_k.weight"], sd["a.to_out.0.weight"], BF)
+    ctx_t = ctx.reshape(B * Lc, -1).to(BF).to(d)
+    k = ops.gemm_conv(ctx_t, xk_w.to(d), B=1, H=1, W=B * Lc, taps=1)
+    v = ops.gemm_conv(ctx_t, sd["a.to_v.weight"].to(BF).to(d), B=1, H=1, W=B * Lc, taps=1)
+    out = ops.xattn_block(x.reshape(B * L, C).to(BF).to(d), wq.to(d), bq.to(d), k, ops.xattn_pack_vt(v, B, heads, Lc), xwo.to(d),
+                          sd["a.to_out.0.bias"].to(d), HW=L, heads=heads, Lc=Lc, eps=1e-5, scale=0.125)
+    assert out.dtype == BF
+    report("fused cross-attention block", out.reshape(B, L, C), ref, atol=2e-2)
+    fd = {"f.net.0.proj.weight": b16(torch.from_numpy(weights.fill_like("fb16.proj", (2 * H, C)))),
+          "f.net.0.proj.bias": torch.from_numpy(weights.fill_like("fb16.proj.b", (2 * H,))),
+          "f.net.2.weight": b16(torch.from_numpy(weights.fill_like("fb16.ff2", (C, H)))),
+          "f.net.2.bias": torch.from_numpy(weights.fill_like("fb16.ff2.b", (C,)))}
+    xf = x.reshape(B * L, C)
+    ref2 = xf + unet_ref.feed_forward(fd, "f", unet_ref.layer_norm(xf, gamma, beta), m)
+    wf, bf, _ = packing.fold_layernorm(fd["f.net.0.proj.weight"], fd["f.net.0.proj.bias"], gamma, beta, BF)
+    perm = packing.geglu_perm(H)
+    out2 = ops.ffn_block(xf.to(BF).to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d),
+                         packing.pack_pieces(fd["f.net.2.weight"], BF).to(d), fd["f.net.2.bias"].to(d), eps=1e-5)
+    assert out2.dtype == BF
+    report("fused feed-forward block", out2, ref2, atol=2e-2)
+
+
 def test_mv_gather_scatter_bf16():
     from leftrefill_amd import ops
     b, V, s, C = 2, 5, 4, 64
