@@ -75,15 +75,16 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
   FF_STAMP(0);
 
   // ---- the pair's 32 rows in B-operand form (both waves hold them): lane (fr, fq), row tile rt holds
-  //      x[m_p0 + 16 rt + fr][64 t5 + 16 fq + 8 u .. + 7]
+  //      x[m_p0 + 16 rt + fr][64 t5 + 32 u + 8 fq .. + 7]  (weight fragment of lane group fq = chunk 4 u + fq: conflict-free reads,
+  //      see xattn_block.hip)
   vec8<T> xf[2][KL][2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + 16 * rt + fr) * C + 16 * fq;
+    const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + 16 * rt + fr) * C + 8 * fq;
 #pragma unroll
     for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) xf[rt][t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 8 * u);
+      for (int u = 0; u < 2; ++u) xf[rt][t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
   }
   for (int i = t; i < (H2 + C) / 4; i += FF_THREADS) {      // biases -> LDS (no register loads inside the loop below)
     const float* src = i < H2 / 4 ? P.b1 + 4 * i : P.b2 + 4 * (i - H2 / 4);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
     vec8<T> fa[FF_DEPTH + 1][2];              // fragment reads run FF_DEPTH MFMA groups ahead of their use
     auto rd = [&](int ks, vec8<T> (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ug = 0; ug < 2; ++ug) f[ug] = frag(Ws + (ks >> 1) * 64 * 128, (2 * role + ug) * 16 + fr, 2 * fq + (ks & 1));
+      for (int ug = 0; ug < 2; ++ug) f[ug] = frag(Ws + (ks >> 1) * 64 * 128, (2 * role + ug) * 16 + fr, 4 * (ks & 1) + fq);
     };
 #pragma unroll
     for (int d = 0; d < FF_DEPTH; ++d) rd(d, fa[d]);

@@ -78,13 +78,16 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
   const int m_w0 = m0 + w * 16;
   XA_STAMP(0);
 
-  // ---- this wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 16 fq + 8 u .. + 7]
-  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 16 * fq;
+  // ---- this wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 32 u + 8 fq .. + 7] (the four fq lanes of a
+  //      row read 64 consecutive bytes; the matching weight fragment of lane group fq is chunk 4 u + fq of sub-tile t5 -- consecutive
+  //      chunks across fq like the GEMM's fragments, which is what keeps the ds_read_b128 conflict-free: with 16 fq + 8 u, i.e. chunk
+  //      2 fq + u, every fragment read of the q projection took two LDS passes)
+  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 8 * fq;
   vec8<T> xf[KL][2];
 #pragma unroll
   for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 8 * u);
+    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
   if (t < 2 * (C / 4)) {      // biases -> LDS (the loop below issues no register loads: they would drain the LDS-DMA queue)
     const float* src = t < C / 4 ? P.bq + 4 * t : P.bo + 4 * (t - C / 4);
     *reinterpret_cast<f32x4*>(par + 4 * t) = *reinterpret_cast<const f32x4*>(src);
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
       vec8<T> fa[2][4];
       auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 2 * fq + (ks & 1));
+        for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq);
       };
       rd(0, fa[0]);
 #pragma unroll

@@ -274,13 +274,22 @@ def dup2(t):
     return torch.cat([t, t], dim=0)
 
 
+def xattn_fused(x, pa: PackedAttn, B, L, Lc, kv):
+    """Will cross_attention take the one-launch path (lr_xattn_block_f16)?  It normalises its rows itself: the producer of x then
+    does not need to emit row statistics."""
+    return (XATTN and kv is not None and len(kv) > 2 and fold_ok(x) and ops.xattn_ok(B * L, L, x.shape[1], pa.heads, Lc))
+
+
+def ffn_fused(x, pt):
+    return FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(x.shape[0], x.shape[1], pt.ff2_x.shape[0] * 64)
+
+
 def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False, dup=False):
     """x + to_out(attention(LayerNorm(x) Wq, ctx Wk, ctx Wv)).  kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T,
     V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv.
     dup: x holds only the first B / 2 samples (the two CFG halves are identical up to here): the query projection runs
     once, then x and q are duplicated for the B contexts."""
-    if (XATTN and kv is not None and len(kv) > 2 and fold_ok(x)
-            and ops.xattn_ok(B * L, L, x.shape[1], pa.heads, Lc)):
+    if xattn_fused(x, pa, B, L, Lc, kv):
         # one launch: LayerNorm + to_q + attention + to_out + residual (+ the row statistics of the next LayerNorm)
         if dup:
             x = dup2(x)
@@ -306,7 +315,8 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
     dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
     self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix)."""
-    ws = fold_ok(x)       # ask the residual GEMMs for the row statistics the next LayerNorm needs
+    # ask the residual GEMMs for the row statistics the next LayerNorm fold needs (the fused blocks normalise their rows themselves)
+    ws = fold_ok(x) and not xattn_fused(x, pt.attn2, N, L, Lc, kv)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
             x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
@@ -331,10 +341,11 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         assert b * v == N
         x = self_attention(x, st, pt.n1, pt.attn1, b, v * L, want_stats=ws)
     x, st = x if ws else (x, None)
-    ws = fold_ok(x)
+    n_rows = N * L          # rows of the block's output (x may still hold half of a CFG batch here: `dup`)
+    ws = fold_ok(x) and not (FFN_FUSED and pt.ff2_x is not None and ops.ffn_ok(n_rows, x.shape[1], pt.ff2_x.shape[0] * 64))
     x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
     x, st = x if ws else (x, None)
-    if FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(x.shape[0], x.shape[1], pt.ff2_x.shape[0] * 64):
+    if ffn_fused(x, pt):
         # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
         ws = want_stats and fold_ok(x)
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, want_stats=ws)

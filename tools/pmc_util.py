@@ -25,7 +25,8 @@ def family(name):
                            ("gemm_conv_pipe_kernelILi128", "gemm_conv_pipe_kernel<128,4,*,2,4> (4-stage)")):
         if mangled in name:
             return label
-    for key in ("gemm_conv_pipe_kernel", "gemm_conv_kernel", "gn_apply", "gn_stats", "gn_finalize", "layernorm", "splitk_reduce", "transpose_v"):
+    for key in ("gemm_conv_pipe_kernel", "gemm_conv_kernel", "xattn_block_kernel", "ffn_block_kernel", "gn_apply", "gn_stats", "gn_finalize", "layernorm",
+                "splitk_reduce", "transpose_v"):
         if key in name:
             return key
     if "attention_kernel" in name:      # attention_kernel<T, VT, CAUSAL>
