@@ -145,7 +145,7 @@ def kernel_roofline(model, batch, B, dump=None):
                             stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
                             cat=k.get("x2") is not None, resid=k.get("resid") is not None)
             elif name == "xattn_block":      # fused LayerNorm + to_q + 77-key attention + to_out + residual (level 0)
-                desc = dict(M=a[0].shape[0], C=a[0].shape[1], Lc=k["Lc"], heads=k["heads"])
+                desc = dict(M=a[0].shape[0], C=a[0].shape[1], Lc=k["Lc"], heads=k["heads"], pre=int(k.get("pre") is not None))
             elif name == "ffn_block":        # fused LayerNorm + GEGLU projection + gate + second Linear + residual (level 0)
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], H=a[3].shape[0] * 64)
             else:
@@ -183,7 +183,8 @@ def kernel_roofline(model, batch, B, dump=None):
     # the fused cross-attention block runs two of the UNet's pointwise linears and a 77-key attention: its flops leave the
     # numerators of the GEMM / attention families (which only count what those kernels still execute)
     ffn_fl = lambda d: 6.0 * d["M"] * d["C"] * d["H"]      # [M, C] x [C, 2H] + [M, H] x [H, C]
-    moved = {"gemm": sum(4.0 * d["M"] * d["C"] * d["C"] for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"]),
+    xl_fl = lambda d: (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"]      # to_q + to_out (+ the self-attention's out-projection)
+    moved = {"gemm": sum(xl_fl(d) for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"]),
              "attn": sum(4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
@@ -191,7 +192,7 @@ def kernel_roofline(model, batch, B, dump=None):
                      "tflops": (n * fl[key] - moved[key]) / (ms * 1e-3) / 1e12}
     if rec["xattn_block"]:
         ms = sum(a.elapsed_time(b) for a, b, _ in rec["xattn_block"])
-        fl_x = sum(4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])
+        fl_x = sum(xl_fl(d) + 4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])
         out["xattn_block"] = {"launches": len(rec["xattn_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["xattn_block"]),
                               "tflops": fl_x / (ms * 1e-3) / 1e12}
     if rec["ffn_block"]:
@@ -209,8 +210,8 @@ def kernel_roofline(model, batch, B, dump=None):
                 key = f'gemm {d["M"]}x{d["N"]}x{d["K"]} taps{d["taps"]} s{d["stride"]} up{d["up"]}' + (" geglu" if d["geglu"] else "") + (" cat" if d["cat"] else "")
                 fl_ = 2.0 * d["M"] * d["N"] * d["K"]
             elif name == "xattn_block":
-                key = f'xattn {d["M"]}x{d["C"]} keys{d["Lc"]} (ln + to_q + attention + to_out + resid)'
-                fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
+                key = f'xattn {d["M"]}x{d["C"]} keys{d["Lc"]} (' + ("attn1.to_out + resid + " if d["pre"] else "") + 'ln + to_q + attention + to_out + resid)'
+                fl_ = (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
             elif name == "ffn_block":
                 key = f'ffn {d["M"]}x{d["C"]} hidden{d["H"]} (ln + geglu proj + gate + linear + resid)'
                 fl_ = 6.0 * d["M"] * d["C"] * d["H"]
@@ -229,7 +230,7 @@ def kernel_roofline(model, batch, B, dump=None):
                 if name == "gemm_conv":
                     fl_ = 2.0 * d["M"] * d["N"] * d["K"]
                 elif name == "xattn_block":
-                    fl_ = 4.0 * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
+                    fl_ = (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
                 elif name == "ffn_block":
                     fl_ = 6.0 * d["M"] * d["C"] * d["H"]
                 else:

@@ -197,6 +197,12 @@ typedef struct lr_xattn_args {
   float* stats_out;
   int32_t M, HW, C, heads, Lc;
   float ln_eps, scale;
+  /* pre_a != NULL: the out-projection of the preceding self-attention runs in front, in the same launch
+   * (`x = self.attn1(self.norm1(x)) + x`, attention.py:280):  x1 = pre_a pre_w^T + pre_b + x;  out = x1 + to_out(attention(LayerNorm(x1) ...)).
+   * pre_a [M][320] = the self-attention output, pre_w [320][320] = attn1.to_out[0].weight (natural layout), pre_b [320] its bias (fp32);
+   * wq must then have its COLUMNS in the k-slot order (inside every 64 columns: position 32 p + 8 f + i holds column
+   * 32 p + 16 (i >> 2) + 4 f + (i & 3)): the normalised x1 reaches the q projection in accumulator order, never through memory. */
+  const lr_half* pre_a; const lr_half* pre_w; const float* pre_b;
 } lr_xattn_args;
 int lr_xattn_block_f16(const lr_xattn_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_f16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);

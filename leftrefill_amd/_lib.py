@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -54,7 +54,8 @@ class XattnArgs(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("wq", c_void_p), ("bq", c_void_p), ("k", c_void_p), ("ldk", ctypes.c_int32),
                 ("vt", c_void_p), ("wo", c_void_p), ("bo", c_void_p), ("stats_out", c_void_p),
                 ("M", ctypes.c_int32), ("HW", ctypes.c_int32), ("C", ctypes.c_int32), ("heads", ctypes.c_int32),
-                ("Lc", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("scale", ctypes.c_float)]
+                ("Lc", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("scale", ctypes.c_float),
+                ("pre_a", c_void_p), ("pre_w", c_void_p), ("pre_b", c_void_p)]
 
 
 class FfnArgs(ctypes.Structure):

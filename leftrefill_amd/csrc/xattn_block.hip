@@ -41,6 +41,7 @@
 struct XattnParams {
   const void* x; const void* wq; const float* bq; const void* k; const void* vt; const void* wo; const float* bo;
   void* out; float* st_out;
+  const void* pre_a; const void* pre_w; const float* pre_b;      // PRE: x1 = pre_a pre_w^T + pre_b + x runs in front (see below)
   int M, HW, Lc, ldk, nblocks;
   float eps, c;               // c = scale * log2(e)
   unsigned k_bytes, vt_bytes;
@@ -58,12 +59,18 @@ extern "C" void lr_xattn_set_trace(void* p) { g_xa_trace = (unsigned long long*)
 #endif
 
 // NKT = 16-key tiles of the context (5: Lc <= 80, 6: Lc <= 96)
-template <typename T, int NKT>
+// PRE: the out-projection of the preceding self-attention runs in front, in the same registers (reference attention.py:280-281):
+//     x1 = a Wo1^T + bo1 + x          (a = pre_a: the self-attention output, Wo1 = pre_w in its natural [320][320] layout)
+//     out = x1 + to_out(attention(LayerNorm(x1) Wq, K, V))
+// five more ring steps (Wo1 as five 64-row pieces) in front of the head loop; x1 never goes to memory: its fp32 accumulators are
+// rounded to fp16 (what the unfused path stores), normalised, and handed to the q projection as B operands in accumulator order
+// (Wq's columns are stored in the order pi for this variant), and the rounded x1 stays in 40 registers as the final residual.
+template <typename T, int NKT, bool PRE>
 __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = XA_C, NT = C / 16, KL = C / 64;   // 20 output tiles, 5 lines of 128 B per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* par = reinterpret_cast<float*>(smem + 3 * XA_SLOT);      // [2][C]: bq | bo
+  float* par = reinterpret_cast<float*>(smem + 3 * XA_SLOT);      // [3][C]: bq | bo | bo1 (PRE)
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -82,14 +89,21 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
   //      row read 64 consecutive bytes; the matching weight fragment of lane group fq is chunk 4 u + fq of sub-tile t5 -- consecutive
   //      chunks across fq like the GEMM's fragments, which is what keeps the ds_read_b128 conflict-free: with 16 fq + 8 u, i.e. chunk
   //      2 fq + u, every fragment read of the q projection took two LDS passes)
-  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 8 * fq;
+  const T* xrow = reinterpret_cast<const T*>(PRE ? P.pre_a : P.x) + (size_t)(m_w0 + fr) * C + 8 * fq;
   vec8<T> xf[KL][2];
 #pragma unroll
   for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
     for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
-  if (t < 2 * (C / 4)) {      // biases -> LDS (the loop below issues no register loads: they would drain the LDS-DMA queue)
-    const float* src = t < C / 4 ? P.bq + 4 * t : P.bo + 4 * (t - C / 4);
+  // PRE: the residual x in ACCUMULATOR layout (lane (fr, fq), tile j: x[m_w0 + fr][16 j + 4 fq .. + 3]); later the rounded x1
+  vec4<T> xres[PRE ? NT : 1];
+  if constexpr (PRE) {
+    const T* xd = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 4 * fq;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xres[j] = *reinterpret_cast<const vec4<T>*>(xd + 16 * j);
+  }
+  if (t < (PRE ? 3 : 2) * (C / 4)) {      // biases -> LDS (the loop below issues no register loads: they would drain the LDS-DMA queue)
+    const float* src = t < C / 4 ? P.bq + 4 * t : t < C / 2 ? P.bo + 4 * (t - C / 4) : P.pre_b + 4 * (t - C / 2);
     *reinterpret_cast<f32x4*>(par + 4 * t) = *reinterpret_cast<const f32x4*>(src);
   }
 
@@ -122,12 +136,25 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
                                                (i - 2) * 64 * 128, 0, 0);
     }
   };
+  const __amdgpu_buffer_rsrc_t rsP = uniform_rsrc(PRE ? P.pre_w : P.wq, (size_t)C * C * 2);
+  auto issue_pre = [&](int slot, int p, int i) __attribute__((always_inline)) {   // rows 64 p .. + 63 of Wo1 as 5 sub-tiles [64 x 64 k]
+    const unsigned v0 = (unsigned)(((p * 64 + lrow) * C + lchunk * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lptr_t)(smem + slot * XA_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 128, 0, 0);
+  };
+  if constexpr (PRE) {      // pieces 0, 1 of Wo1 -> slots 1, 2 (the five pre steps use slots 1, 2, 0, 1, 2: the head loop then finds its own)
 #pragma unroll
-  for (int i = 0; i < KL; ++i) issue_wq(0, 0, i);
+    for (int i = 0; i < KL; ++i) issue_pre(1, 0, i);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue_kv(1, 0, i);
+    for (int i = 0; i < KL; ++i) issue_pre(2, 1, i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < KL; ++i) issue_wq(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_kv(1, 0, i);
+  }
 
   // ---- LayerNorm of the rows in registers (two-pass), gamma / beta live in Wq / bq
+  if constexpr (!PRE) {
   float s = 0.f;
 #pragma unroll
   for (int t5 = 0; t5 < KL; ++t5)
@@ -151,6 +178,7 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int i = 0; i < 8; ++i) xf[t5][u][i] = (T)fmaf((float)xf[t5][u][i], rstd, nmr);
+  }
 
   XA_STAMP(1);                                // rows loaded and normalised
   f32x4 acc[NT];
@@ -161,12 +189,72 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
   auto frag = [&](const char* base, int row, int chunk) -> vec8<T> {
     return *reinterpret_cast<const vec8<T>*>(base + row * 128 + ((chunk ^ sw) << 4));
   };
+#define XA_FENCE() __builtin_amdgcn_sched_barrier(0)
+  if constexpr (PRE) {
+    // ================= pre steps: x1^T = Wo1 a^T, 64 output channels (4 tiles) per step ==============================
+#pragma unroll
+    for (int p = 0; p < KL; ++p) {
+      const int slot = (p + 1) % 3;
+      xa_wait_vmcnt<5>();                     // piece p landed (the next one may be in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* Ws = smem + slot * XA_SLOT;
+      vec8<T> fa[2][4];
+      auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq);
+      };
+      rd(0, fa[0]);
+#pragma unroll
+      for (int ks = 0; ks < 2 * KL; ++ks) {
+        if (ks + 1 < 2 * KL) rd(ks + 1, fa[(ks + 1) & 1]);
+        XA_FENCE();
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) acc[4 * p + jd] = lr_mfma16(fa[ks & 1][jd], xf[ks >> 1][ks & 1], acc[4 * p + jd]);
+        if (ks < KL) {                        // two steps ahead: Wo1 pieces 2 .. 4, then the first head's Wq / K|V pieces
+          if (p + 2 < KL) issue_pre((p + 3) % 3, p + 2, ks);
+          else if (p + 2 == KL) issue_wq(0, 0, ks);
+          else if (ks < 4) issue_kv(1, 0, ks);
+        }
+        XA_FENCE();
+      }
+    }
+    // x1 = acc + bo1 + x, rounded to fp16 (what the unfused path stores); LayerNorm of the rounded rows; B operands in accumulator order
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4 bj = *reinterpret_cast<const f32x4*>(par + 2 * C + j * 16 + 4 * fq);
+      vec4<T> r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { r16[r] = (T)(acc[j][r] + bj[r] + (float)xres[j][r]); s += (float)r16[r]; }
+      xres[j] = r16;
+    }
+    const float mean = xa_row4_sum(s) * (1.0f / C);
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = (float)xres[j][r] - mean; q2 = fmaf(d, d, q2); }
+    const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int pp = 0; pp < NT / 2; ++pp) {
+      f32x4 n0, n1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        n0[r] = fmaf((float)xres[2 * pp][r], rstd, nmr);
+        n1[r] = fmaf((float)xres[2 * pp + 1][r], rstd, nmr);
+      }
+      xf[pp >> 1][pp & 1] = xa_pack<T>(n0, n1);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   // Fragment reads run one MFMA group ahead of their use (two register sets), and `sched_barrier(0)` pins
   //   [ds_reads of group g + 1] -> [MFMAs of group g (independent accumulators)] -> [one LDS-DMA issue]:
   // left to itself hipcc orders each product as one dependent accumulator chain with the read of every fragment issued one MFMA
   // before its use (~100 cycles per MFMA instead of ~17).
-#define XA_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
   for (int h = 0; h < XA_HEADS; ++h) {
     const bool more = h + 1 < XA_HEADS;
@@ -310,7 +398,10 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
     const f32x4 v = acc[j] + *reinterpret_cast<const f32x4*>(par + C + j * 16 + 4 * fq);
     vec4<T> hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
+    for (int r = 0; r < 4; ++r) {
+      hv[r] = (T)v[r];
+      if constexpr (PRE) hv[r] = (T)((float)hv[r] + (float)xres[j][r]);      // + x1 (same two roundings as the unfused kernels)
+    }
     *reinterpret_cast<vec4<T>*>(stg + fr * XA_PITCH + (j * 16 + 4 * fq) * 2) = hv;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -320,17 +411,22 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_block_kernel(const XattnPara
   float s1 = 0.f, s2 = 0.f;
   constexpr int NP = C / 32;                  // 16-byte pieces per lane (4 lanes per row)
   uint4 rx[NP];
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int it = 0; it < NP; ++it) rx[it] = *reinterpret_cast<const uint4*>(xr + (sub + 4 * it) * 8);
+    for (int it = 0; it < NP; ++it) rx[it] = *reinterpret_cast<const uint4*>(xr + (sub + 4 * it) * 8);
+  }
 #pragma unroll
   for (int it = 0; it < NP; ++it) {
     const int piece = sub + 4 * it;
     float a[8], e[8];
-    lr_unpack8<T>(*reinterpret_cast<const uint4*>(stg + row * XA_PITCH + piece * 16), a);
-    lr_unpack8<T>(rx[it], e);
+    uint4 pk = *reinterpret_cast<const uint4*>(stg + row * XA_PITCH + piece * 16);
+    lr_unpack8<T>(pk, a);
+    if constexpr (!PRE) {
+      lr_unpack8<T>(rx[it], e);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] += e[i];
-    const uint4 pk = lr_pack8<T>(a);
+      for (int i = 0; i < 8; ++i) a[i] += e[i];
+      pk = lr_pack8<T>(a);
+    }
     *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
     lr_unpack8<T>(pk, a);
 #pragma unroll
@@ -412,16 +508,26 @@ static int xattn_block_t(const lr_xattn_args* a, lr_stream_t s) {
 #ifdef LR_XATTN_TRACE
   P.trace = g_xa_trace;
 #endif
-  const size_t smem = 3 * XA_SLOT + 2 * XA_C * sizeof(float);
-  const bool six = a->Lc > 80;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[six]) {
-    const void* f = six ? reinterpret_cast<const void*>(xattn_block_kernel<T, 6>) : reinterpret_cast<const void*>(xattn_block_kernel<T, 5>);
-    hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done[six] = true;
+  const size_t smem = 3 * XA_SLOT + 3 * XA_C * sizeof(float);
+  const bool six = a->Lc > 80, pre = a->pre_a != nullptr;
+  if (pre) {
+    if (!a->pre_w || !a->pre_b) return LR_E_ARG;
+    if (((uintptr_t)a->pre_a | (uintptr_t)a->pre_w | (uintptr_t)a->pre_b) & 15) return LR_E_ALIGN;
   }
-  if (six) hipLaunchKernelGGL((xattn_block_kernel<T, 6>), dim3(P.nblocks), dim3(XA_THREADS), smem, (hipStream_t)s, P);
-  else hipLaunchKernelGGL((xattn_block_kernel<T, 5>), dim3(P.nblocks), dim3(XA_THREADS), smem, (hipStream_t)s, P);
+  P.pre_a = a->pre_a; P.pre_w = a->pre_w; P.pre_b = a->pre_b;
+  const void* fns[4] = {reinterpret_cast<const void*>(xattn_block_kernel<T, 5, false>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, false>),
+                        reinterpret_cast<const void*>(xattn_block_kernel<T, 5, true>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, true>)};
+  static bool attr_done[4] = {false, false, false, false};
+  const int v = (pre ? 2 : 0) + (six ? 1 : 0);
+  if (!attr_done[v]) {
+    hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done[v] = true;
+  }
+  const dim3 grid(P.nblocks), block(XA_THREADS);
+  if (v == 0) hipLaunchKernelGGL((xattn_block_kernel<T, 5, false>), grid, block, smem, (hipStream_t)s, P);
+  else if (v == 1) hipLaunchKernelGGL((xattn_block_kernel<T, 6, false>), grid, block, smem, (hipStream_t)s, P);
+  else if (v == 2) hipLaunchKernelGGL((xattn_block_kernel<T, 5, true>), grid, block, smem, (hipStream_t)s, P);
+  else hipLaunchKernelGGL((xattn_block_kernel<T, 6, true>), grid, block, smem, (hipStream_t)s, P);
   return lr_launch_status();
 }
 

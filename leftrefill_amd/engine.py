@@ -142,6 +142,9 @@ class PackedAttn:
         if not is_self and norm is not None and attn.to_q.weight.shape[0] == ops.XATTN_C:
             # operands of the fused cross-attention block (lr_xattn_block_f16): to_k rows / to_out columns in its k-slot order
             self.xk, self.xwo = packing.pack_xattn(attn.to_k.weight.detach(), attn.to_out[0].weight.detach(), compute_dtype())
+            # LayerNorm-folded to_q with its columns in k-slot order: the variant that also runs the self-attention's out-projection
+            # hands the normalised rows to the q projection in accumulator order
+            self.xq_pi = self.q.wf[:, packing.xattn_perm(self.q.wf.shape[1], self.q.wf.device)].contiguous()
         self.dim_head = attn.to_q.weight.shape[0] // attn.heads
         if self.dim_head != 64:
             raise RuntimeError(f"attention kernel is specialised for d_head=64 (got {self.dim_head})")
@@ -284,6 +287,27 @@ def ffn_fused(x, pt):
     return FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(x.shape[0], x.shape[1], pt.ff2_x.shape[0] * 64)
 
 
+XATTN_PRE = __import__("os").environ.get("LEFTREFILL_XATTN_PRE", "1") != "0"
+
+
+def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False):
+    """attn1 and attn2 of a plain (single-view) block with the self-attention's out-projection fused into the cross-attention launch:
+    LayerNorm-folded QKV GEMM -> flash attention -> ONE kernel for  x1 = a Wo1 + b + x;  x2 = x1 + to_out(attention(LN(x1) Wq, K, V)).
+    dup: x holds the first N / 2 samples of a CFG batch whose halves are still identical: projection and self-attention run on them
+    once (planned like the full batch), then a and x are duplicated for the N contexts."""
+    pa1, pa2 = pt.attn1, pt.attn2
+    if dup:
+        with plan_batch_scale(2):
+            qkv = ln_linear(x, st, pt.n1, pa1.qkv)
+        a = dup2(ops.attention_qkv(qkv, N // 2, pa1.heads, L, pa1.dim_head ** -0.5))
+        x = dup2(x)
+    else:
+        qkv = ln_linear(x, st, pt.n1, pa1.qkv)
+        a = ops.attention_qkv(qkv, N, pa1.heads, L, pa1.dim_head ** -0.5)
+    return ops.xattn_block(x, pa2.xq_pi, pa2.q.bf, kv[2], kv[3], pa2.xwo, pa2.out.b, HW=L, heads=pa2.heads, Lc=Lc, eps=pa2.q.eps,
+                           scale=pa2.dim_head ** -0.5, want_stats=want_stats, pre=(a, pa1.out.w, pa1.out.b))
+
+
 def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False, dup=False):
     """x + to_out(attention(LayerNorm(x) Wq, ctx Wk, ctx Wv)).  kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T,
     V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv.
@@ -317,6 +341,13 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix)."""
     # ask the residual GEMMs for the row statistics the next LayerNorm fold needs (the fused blocks normalise their rows themselves)
     ws = fold_ok(x) and not xattn_fused(x, pt.attn2, N, L, Lc, kv)
+    n_rows = N * L          # rows of the block's output (x may still hold half of a CFG batch here: `dup`)
+    ffn_f = FFN_FUSED and pt.ff2_x is not None and ops.ffn_ok(n_rows, x.shape[1], pt.ff2_x.shape[0] * 64)
+    if pt.view_num is None and XATTN_PRE and xattn_fused(x, pt.attn2, N, L, Lc, kv) and pt.attn1.out.b is not None:
+        ws = fold_ok(x) and not ffn_f
+        x = self_then_cross_attention(x, st, pt, N, L, Lc, kv, ws, dup=dup)
+        x, st = x if ws else (x, None)
+        return _ffn(x, st, pt, want_stats)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
             x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
@@ -341,10 +372,14 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         assert b * v == N
         x = self_attention(x, st, pt.n1, pt.attn1, b, v * L, want_stats=ws)
     x, st = x if ws else (x, None)
-    n_rows = N * L          # rows of the block's output (x may still hold half of a CFG batch here: `dup`)
-    ws = fold_ok(x) and not (FFN_FUSED and pt.ff2_x is not None and ops.ffn_ok(n_rows, x.shape[1], pt.ff2_x.shape[0] * 64))
+    ws = fold_ok(x) and not ffn_f
     x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
     x, st = x if ws else (x, None)
+    return _ffn(x, st, pt, want_stats)
+
+
+def _ffn(x, st, pt: PackedTBlock, want_stats):
+    """x + ff(LayerNorm(x)) (attention.py:282); st: row statistics of x (or None); returns (y, statistics of y | None)."""
     if ffn_fused(x, pt):
         # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
         ws = want_stats and fold_ok(x)

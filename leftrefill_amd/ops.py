@@ -427,9 +427,10 @@ def xattn_pack_vt(v, B, heads, Lc, out=None):
     return vt
 
 
-def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_stats=False, out=None):
+def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_stats=False, out=None, pre=None):
     """x + to_out(attention(LayerNorm(x) Wq, K, V)) in one launch (lr_xattn_block_f16).  wq / bq: LayerNorm-folded to_q;
     k [B*Lc, ld] = context projection with packing.pack_xattn's row order; vt = xattn_pack_vt(V); wo: packing.pack_pieces(to_out).
+    pre = (a, Wo1, bo1): also fuses the preceding self-attention's out-projection, x1 = a Wo1^T + bo1 + x (wq: xattn_perm columns).
     Returns out [M, C] (, stats [M, 1, 2] for the LayerNorm fold of the next GEMM)."""
     lib = _lib.load()
     _chk16(x, "x")
@@ -446,6 +447,14 @@ def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_sta
     a.x, a.out, a.wq, a.bq, a.k, a.ldk, a.vt, a.wo, a.bo = _p(x), _p(out), _p(wq), _p(bq), _p(k), k.stride(0), _p(vt), _p(wo), _p(bo)
     a.stats_out = _p(stats)
     a.M, a.HW, a.C, a.heads, a.Lc, a.ln_eps, a.scale = M, HW, C, heads, Lc, float(eps), float(scale)
+    a.pre_a = a.pre_w = a.pre_b = 0
+    if pre is not None:
+        # (a_self, Wo1, bo1): x1 = a_self Wo1^T + bo1 + x runs in front, in the same launch; wq then has pi-ordered COLUMNS
+        pa_, pw_, pb_ = pre
+        _chk16(pa_, "pre_a")
+        assert pa_.shape == (M, C) and pw_.dtype == x.dtype and pw_.is_contiguous() and pw_.shape == (C, C)
+        assert pb_.dtype == torch.float32 and pb_.numel() == C
+        a.pre_a, a.pre_w, a.pre_b = _p(pa_), _p(pw_), _p(pb_)
     _lib.check(_fn(lib, "lr_xattn_block_f16", x.dtype)(a, _stream()), "xattn_block")
     return (out, stats) if want_stats else out
 

@@ -64,6 +64,35 @@ def test_xattn_block_vs_oracle(B, L, Lc):
     torch.testing.assert_close(st[:, 0, 1], (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,L,Lc", [(1, 128, 77), (2, 256, 96), (1, 256, 40)])
+def test_xattn_block_with_fused_self_attention_out_projection(B, L, Lc):
+    """PRE variant: x1 = a Wo1^T + bo1 + x (attn1's out-projection + residual, attention.py:280) runs in front of the
+    cross-attention block in the same launch; oracle = the two reference lines evaluated in fp32."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    sd, gamma, beta = _params("pre")
+    wo1 = h16(torch.from_numpy(weights.fill_like("xa.pre.attn1.to_out.weight", (C, C))))
+    bo1 = torch.from_numpy(weights.fill_like("xa.pre.attn1.to_out.bias", (C,)))
+    x = h16(G.T(f"xa.pre.{L}.{Lc}.x", (B, L, C)) * 1.3 + 0.2)
+    a = h16(G.T(f"xa.pre.{L}.{Lc}.a", (B, L, C)))
+    ctx = h16(G.T(f"xa.pre.{L}.{Lc}.ctx", (B, Lc, 1024)))
+    x1 = x + torch.nn.functional.linear(a, wo1, bo1)
+    ref = _oracle(sd, gamma, beta, x1, ctx)
+    wq, bq, _cs = packing.fold_layernorm(sd["a.to_q.weight"], None, gamma, beta)
+    wq_pi = wq[:, packing.xattn_perm(C)].contiguous()
+    xk_w, xwo = packing.pack_xattn(sd["a.to_k.weight"], sd["a.to_out.0.weight"])
+    ctx_t = ctx.reshape(B * Lc, -1).half().to(d)
+    k = ops.gemm_conv(ctx_t, xk_w.to(d), B=1, H=1, W=B * Lc, taps=1)
+    v = ops.gemm_conv(ctx_t, sd["a.to_v.weight"].half().to(d), B=1, H=1, W=B * Lc, taps=1)
+    out, st = ops.xattn_block(x.reshape(B * L, C).half().to(d), wq_pi.to(d), bq.to(d), k, ops.xattn_pack_vt(v, B, HEADS, Lc), xwo.to(d),
+                              sd["a.to_out.0.bias"].to(d), HW=L, heads=HEADS, Lc=Lc, eps=1e-5, scale=64 ** -0.5, want_stats=True,
+                              pre=(a.reshape(B * L, C).half().to(d), wo1.half().to(d), bo1.to(d)))
+    # one more fp16 hand-off than the plain block (x1 is rounded like the unfused path stores it)
+    report(f"xattn+pre B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, rtol=3e-3, atol=4e-3)
+    o32 = out.float()
+    torch.testing.assert_close(st[:, 0, 0], o32.sum(1), rtol=1e-5, atol=1e-3)
+
+
 def test_xattn_block_hot_shape_and_reruns():
     """configs[1] shape of the level-0 blocks: M = 8 x 8192 rows (sampled rows against the oracle), bit-identical reruns."""
     B, L, Lc = 8, 8192, 77
@@ -120,3 +149,38 @@ def test_engine_cross_attention_fused_equals_unfused_path():
     print(f"[fused vs unfused cross-attention] max abs diff {err:.3e} at |out| {plain.float().abs().max().item():.2f}")
     assert err <= 8e-3 * max(1.0, plain.float().abs().max().item())
     torch.testing.assert_close(st.sum(1)[:, 0], st2.sum(1)[:, 0], rtol=1e-3, atol=2e-1)
+
+
+def test_transformer_block_pre_fused_equals_separate_launches():
+    """engine.transformer_block at C = 320 with the self-attention's out-projection fused into the cross-attention launch vs the
+    separate out-projection GEMM: same block output to fp16 noise."""
+    import importlib
+    from leftrefill_amd import engine, ops
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(1)
+    d = dev()
+    blk = att.BasicTransformerBlock(320, 5, 64, context_dim=1024).to(d).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        for n_ in (blk.norm1, blk.norm2, blk.norm3):
+            n_.weight.add_(1.0)
+    pt = engine.PackedTBlock(blk)
+    B, L, Lc = 2, 256, 77
+    x = torch.randn(B * L, 320, device=d).half()
+    ctx = torch.randn(B * Lc, 1024, device=d).half()
+    kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=B * Lc, taps=1)
+    ent = (kv, None, ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, 320:], B, 5, Lc))
+    outs = []
+    for flag in (True, False):
+        engine.XATTN_PRE = flag
+        try:
+            with torch.no_grad():
+                outs.append(engine.transformer_block(x, ctx, pt, B, L, Lc, kv=ent)[0].float().cpu())
+        finally:
+            engine.XATTN_PRE = True
+    err = (outs[0] - outs[1]).abs().max().item()
+    print(f"[pre-fused vs separate out-projection] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
+    assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())

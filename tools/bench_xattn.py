@@ -67,8 +67,23 @@ def main():
         o = ops.attention_q_kv(q, kv, B, heads, L, Lc, 0.125)
         return ops.gemm_conv(o, wo_d, B=1, H=1, W=M, taps=1, bias=bo, resid=xs[i], want_stats=True, out=outs[i])
 
+    wo1 = (torch.randn(C, C, generator=g) / C ** 0.5).half().to(d)
+    bo1 = torch.randn(C, generator=g).to(d)
+    wq_pi = wqf[:, packing.xattn_perm(C).to(d)].contiguous()
+    a_s = [torch.randn(M, C, device=d).half() for _ in range(nsets)]
+
+    def fused_pre(i):      # attn1's out-projection + residual in front, same launch
+        return ops.xattn_block(xs[i], wq_pi, bqf, kx, vt, xwo, bo, HW=L, heads=heads, Lc=Lc, eps=1e-5, scale=0.125, want_stats=True,
+                               out=outs[i], pre=(a_s[i], wo1, bo1))
+
+    def plain_pre(i):
+        x1, st1 = ops.gemm_conv(a_s[i], wo1, B=1, H=1, W=M, taps=1, bias=bo1, resid=xs[i], want_stats=True)
+        q = ops.gemm_conv(x1, wqf, B=1, H=1, W=M, taps=1, bias=bqf, ln=(st1, 1e-5, cs))
+        o = ops.attention_q_kv(q, kv, B, heads, L, Lc, 0.125)
+        return ops.gemm_conv(o, wo_d, B=1, H=1, W=M, taps=1, bias=bo, resid=x1, want_stats=True, out=outs[i])
+
     res = {}
-    for name, fn in (("fused", fused), ("three launches", plain)):
+    for name, fn in (("fused", fused), ("three launches", plain), ("fused + pre", fused_pre), ("four launches", plain_pre)):
         fn(0)
         torch.cuda.synchronize()
         cold = min(time_seq(lambda i: fn(i % nsets), nsets * 2) for _ in range(3))
