@@ -225,6 +225,12 @@ typedef struct lr_ffn_args {
   float* stats_out;
   int32_t M, C, H;
   float ln_eps;
+  /* post_w != NULL: the Linear after the block runs in the same launch (SpatialTransformer.proj_out + `x + x_in`, attention.py:412-419):
+   *   x3 = x + ff(LayerNorm(x));  out = x3 post_w^T + post_b + post_resid.
+   * post_w [5][320][64] = proj_out.weight as 64-column pieces in k-slot order (like w2), post_b [320] fp32, post_resid [M][320];
+   * gn_stats_out (optional) [M / 128][320][2] = per-channel (sum, sumsq) of the rounded output over each block of 128 rows, for the
+   * GroupNorm that consumes `out` (lr_groupnorm_finalize with R = 128); stats_out is then the row statistics of `out`. */
+  const lr_half* post_w; const float* post_b; const lr_half* post_resid; float* gn_stats_out;
 } lr_ffn_args;
 int lr_ffn_block_f16(const lr_ffn_args* args, lr_stream_t s);
 

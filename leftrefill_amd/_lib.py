@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -61,7 +61,8 @@ class XattnArgs(ctypes.Structure):
 class FfnArgs(ctypes.Structure):
     """struct lr_ffn_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
-                ("stats_out", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("ln_eps", ctypes.c_float)]
+                ("stats_out", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("ln_eps", ctypes.c_float),
+                ("post_w", c_void_p), ("post_b", c_void_p), ("post_resid", c_void_p), ("gn_stats_out", c_void_p)]
 
 
 # symbol -> argtypes; every function returns int

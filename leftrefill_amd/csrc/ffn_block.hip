@@ -29,7 +29,7 @@
 #define FF_THREADS 512
 #define FF_SLOT 40960
 #define FF_PITCH 336          // bytes per staged row of a wave's 160 output columns (320 + 16: rows start in distinct banks)
-#define FF_PAR_BYTES ((2 * FF_MAX_H + FF_C) * 4)      // bias rows behind the ring
+#define FF_PAR_BYTES ((2 * FF_MAX_H + 2 * FF_C) * 4)      // bias rows behind the ring
 #ifndef FF_DEPTH
 #define FF_DEPTH 2
 #endif
@@ -37,6 +37,7 @@
 
 struct FfnParams {
   const void* x; const void* w1; const float* b1; const void* w2; const float* b2; void* out; float* st_out;
+  const void* post_w; const float* post_b; const void* post_resid; float* gs_out;      // POST (see the kernel)
   int M, H, nblocks;
   float eps;
 #ifdef LR_FFN_TRACE
@@ -52,7 +53,12 @@ extern "C" void lr_ffn_set_trace(void* p) { g_ff_trace = (unsigned long long*)p;
 #define FF_STAMP(k) do { } while (0)
 #endif
 
-template <typename T>
+// POST: the Linear that follows the block (SpatialTransformer.proj_out, attention.py:412-419) runs behind it in the same launch:
+//     x3 = x + ff(LayerNorm(x));   out = x3 Wp^T + bp + x_in        (Wp = post_w as 64-column pieces in k-slot order, x_in = post_resid)
+// x3 never goes to memory: rounded to fp16 like the unfused path stores it, each wave's half of the columns becomes five B operands
+// per row tile, the two halves of a pair cross through LDS once, then five more ring steps.  With gs_out the block also emits the
+// per-channel (sum, sumsq) of its 128 output rows -- the statistics of the GroupNorm that consumes `out` (lr_groupnorm_finalize, R = 128).
+template <typename T, bool POST>
 __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = FF_C, KL = C / 64;
@@ -86,8 +92,8 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
 #pragma unroll
       for (int u = 0; u < 2; ++u) xf[rt][t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
   }
-  for (int i = t; i < (H2 + C) / 4; i += FF_THREADS) {      // biases -> LDS (no register loads inside the loop below)
-    const float* src = i < H2 / 4 ? P.b1 + 4 * i : P.b2 + 4 * (i - H2 / 4);
+  for (int i = t; i < (H2 + (POST ? 2 : 1) * C) / 4; i += FF_THREADS) {      // biases -> LDS (no register loads inside the loop below)
+    const float* src = i < H2 / 4 ? P.b1 + 4 * i : i < (H2 + C) / 4 ? P.b2 + 4 * (i - H2 / 4) : P.post_b + 4 * (i - (H2 + C) / 4);
     *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(src);
   }
 
@@ -235,13 +241,91 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
       }
     }
   }
+  if constexpr (POST) {
+    // ================= post: x3 = acc + b2 + x (fp16), out^T = Wp x3^T ==============================================
+    const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.post_w, (size_t)C * C * 2);
+    auto issue_wp = [&](int slot, int pc, int i) __attribute__((always_inline)) {   // piece pc of Wp ([5][320][64]); rows 64 i + 8 w ..
+      const unsigned v0 = (unsigned)(((pc * C + lrow) * 64 + lchunk * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(smem + slot * FF_SLOT + (i * 64 + w * 8) * 128), 16, v0, i * 64 * 128, 0, 0);
+    };
+    // the residual x of this wave's tiles in accumulator layout (its registers were the B operands of the projection until here)
+    vec4<T> xd[NTW][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const T* xr = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + 16 * rt + fr) * C + role * (C / 2) + 4 * fq;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) xd[j][rt] = *reinterpret_cast<const vec4<T>*>(xr + 16 * j);
+    }
+    __syncthreads();                          // every wave is done with the ring
+#pragma unroll
+    for (int i = 0; i < KL; ++i) issue_wp(0, 0, i);
+    // own half of x3 as B operands: k-step q of this wave = its tiles (2 q, 2 q + 1) = global k-step 5 role + q
+    char* xo = smem + FF_SLOT + w * 10240;
+    const float* pb = par + H2 + role * (C / 2);
+    vec8<T> ball[2 * (NTW / 2)][2];           // all ten k-steps of the pair's rows (this wave's five, the partner's five)
+#pragma unroll
+    for (int q = 0; q < NTW / 2; ++q)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x4 v0 = acc[2 * q][rt] + *reinterpret_cast<const f32x4*>(pb + (2 * q) * 16 + 4 * fq);
+        f32x4 v1 = acc[2 * q + 1][rt] + *reinterpret_cast<const f32x4*>(pb + (2 * q + 1) * 16 + 4 * fq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {         // the unfused kernels round ff's output, then x + that
+          v0[r] = (float)(T)v0[r] + (float)xd[2 * q][rt][r];
+          v1[r] = (float)(T)v1[r] + (float)xd[2 * q + 1][rt][r];
+        }
+        const vec8<T> bq_ = xa_pack<T>(v0, v1);
+        *reinterpret_cast<vec8<T>*>(xo + ((q * 2 + rt) * 64 + lane) * 16) = bq_;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int p = 0; p < 2 * (NTW / 2); ++p)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int ow = (w & ~1) | (p / (NTW / 2));          // the wave of the pair that owns global k-step p
+        ball[p][rt] = *reinterpret_cast<const vec8<T>*>(smem + FF_SLOT + ow * 10240 + (((p % (NTW / 2)) * 2 + rt) * 64 + lane) * 16);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // everyone has its operands: slots 1, 2 are free again
+#pragma unroll
+    for (int i = 0; i < KL; ++i) issue_wp(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < KL; ++i) issue_wp(2, 2, i);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; }
+#pragma unroll
+    for (int pc = 0; pc < KL; ++pc) {
+      if (pc == 0) xa_wait_vmcnt<10>(); else if (pc + 1 < KL) xa_wait_vmcnt<5>(); else xa_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const char* Os = smem + (pc % 3) * FF_SLOT;
+      vec8<T> fa[2][2];
+      auto rd = [&](int g, vec8<T> (&f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) f[q] = frag(Os, (role * NTW + 2 * (g % 5) + q) * 16 + fr, 4 * (g / 5) + fq);
+      };
+      rd(0, fa[0]);
+#pragma unroll
+      for (int g = 0; g < 10; ++g) {
+        if (g + 1 < 10) rd(g + 1, fa[(g + 1) & 1]);
+        FF_FENCE();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[2 * (g % 5) + q][rt] = lr_mfma16(fa[g & 1][q], ball[2 * pc + g / 5][rt], acc[2 * (g % 5) + q][rt]);
+        if (pc >= 1 && pc + 2 < KL && g < KL) issue_wp((pc + 2) % 3, pc + 2, g);
+        FF_FENCE();
+      }
+    }
+  }
 #undef FF_FENCE
 
-  // ---- epilogue: (acc + b2) -> fp16 -> this wave's LDS area [32 rows][160 columns] -> 16-byte pieces: + x, store, row statistics
+  // ---- epilogue: (acc + bias) -> fp16 -> this wave's LDS area [32 rows][160 columns] -> 16-byte pieces: + residual, store, statistics
   FF_STAMP(14);
   __syncthreads();
   char* stg = smem + w * (32 * FF_PITCH);
-  const float* pb2 = par + H2 + role * (C / 2);
+  const float* pb2 = par + H2 + (POST ? C : 0) + role * (C / 2);
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -258,7 +342,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh) {
     const int row = 16 * rh + (lane >> 2);
-    const T* xr = reinterpret_cast<const T*>(P.x) + (size_t)(m_p0 + row) * C + role * (C / 2);
+    const T* xr = reinterpret_cast<const T*>(POST ? P.post_resid : P.x) + (size_t)(m_p0 + row) * C + role * (C / 2);
     T* orow = reinterpret_cast<T*>(P.out) + (size_t)(m_p0 + row) * C + role * (C / 2);
     float s1 = 0.f, s2 = 0.f;
     uint4 rx[NP];
@@ -274,6 +358,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
       for (int i = 0; i < 8; ++i) a[i] += e[i];
       const uint4 pk = lr_pack8<T>(a);
       *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
+      if constexpr (POST) { if (P.gs_out) *reinterpret_cast<uint4*>(stg + row * FF_PITCH + piece * 16) = pk; }      // final values for the column sums
       lr_unpack8<T>(pk, a);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s1 += a[i]; s2 = fmaf(a[i], a[i], s2); }
@@ -284,6 +369,31 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
       if (sub == 0) {
         float2 o; o.x = s1; o.y = s2;
         *reinterpret_cast<float2*>(P.st_out + ((size_t)(m_p0 + row) * 2 + role) * 2) = o;
+      }
+    }
+  }
+  if constexpr (POST) {
+    if (P.gs_out) {      // per-channel (sum, sumsq) over the block's 128 rows, fixed order: wave -> its 32 rows, then the four pairs
+      float* cs = reinterpret_cast<float*>(smem + 8 * 32 * FF_PITCH);      // [8 waves][160][2]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int c = lane; c < C / 2; c += 64) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+          const float v = (float)*reinterpret_cast<const T*>(stg + r * FF_PITCH + c * 2);
+          a1 += v; a2 = fmaf(v, v, a2);
+        }
+        cs[(w * (C / 2) + c) * 2] = a1;
+        cs[(w * (C / 2) + c) * 2 + 1] = a2;
+      }
+      __syncthreads();
+      if (t < C) {
+        const int rl = t / (C / 2), cc = t % (C / 2);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) { a1 += cs[((2 * p4 + rl) * (C / 2) + cc) * 2]; a2 += cs[((2 * p4 + rl) * (C / 2) + cc) * 2 + 1]; }
+        float2 o; o.x = a1; o.y = a2;
+        *reinterpret_cast<float2*>(P.gs_out + ((size_t)bid * C + t) * 2) = o;
       }
     }
   }
@@ -308,12 +418,20 @@ static int ffn_block_t(const lr_ffn_args* a, lr_stream_t s) {
   P.trace = g_ff_trace;
 #endif
   const size_t smem = 3 * FF_SLOT + FF_PAR_BYTES + 4 * 4096;      // ring | bias rows | hand-off areas of the four wave pairs
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
+  const bool post = a->post_w != nullptr;
+  if (post) {
+    if (!a->post_b || !a->post_resid) return LR_E_ARG;
+    if (((uintptr_t)a->post_w | (uintptr_t)a->post_b | (uintptr_t)a->post_resid | (uintptr_t)a->gn_stats_out) & 15) return LR_E_ALIGN;
+  } else if (a->gn_stats_out) return LR_E_ARG;
+  P.post_w = a->post_w; P.post_b = a->post_b; P.post_resid = a->post_resid; P.gs_out = a->gn_stats_out;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[post]) {
+    hipFuncSetAttribute(post ? reinterpret_cast<const void*>(ffn_block_kernel<T, true>) : reinterpret_cast<const void*>(ffn_block_kernel<T, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done[post] = true;
   }
-  hipLaunchKernelGGL((ffn_block_kernel<T>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
+  if (post) hipLaunchKernelGGL((ffn_block_kernel<T, true>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
+  else hipLaunchKernelGGL((ffn_block_kernel<T, false>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
   return lr_launch_status();
 }
 

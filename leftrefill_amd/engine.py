@@ -182,6 +182,10 @@ class PackedST:
         self.proj_in = PackedLinear(st.proj_in)
         self.blocks = [PackedTBlock(b) for b in st.transformer_blocks]
         self.proj_out = PackedLinear(st.proj_out)
+        self.proj_out_x = None
+        if self.proj_out.w.shape == (ops.FFN_C, ops.FFN_C) and self.proj_out.b is not None:
+            w_ = st.proj_out.weight.detach()
+            self.proj_out_x = packing.pack_pieces(w_.reshape(w_.shape[0], w_.shape[1]), compute_dtype())      # fused behind the last block's feed-forward
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -334,7 +338,7 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False):
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False, post=None):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468.
     st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
     dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
@@ -347,7 +351,7 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         ws = fold_ok(x) and not ffn_f
         x = self_then_cross_attention(x, st, pt, N, L, Lc, kv, ws, dup=dup)
         x, st = x if ws else (x, None)
-        return _ffn(x, st, pt, want_stats)
+        return _ffn(x, st, pt, want_stats, post)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
             x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
@@ -375,11 +379,20 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     ws = fold_ok(x) and not ffn_f
     x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
     x, st = x if ws else (x, None)
-    return _ffn(x, st, pt, want_stats)
+    return _ffn(x, st, pt, want_stats, post)
 
 
-def _ffn(x, st, pt: PackedTBlock, want_stats):
-    """x + ff(LayerNorm(x)) (attention.py:282); st: row statistics of x (or None); returns (y, statistics of y | None)."""
+FFN_POST = __import__("os").environ.get("LEFTREFILL_FFN_POST", "1") != "0"
+
+
+def _ffn(x, st, pt: PackedTBlock, want_stats, post=None):
+    """x + ff(LayerNorm(x)) (attention.py:282); st: row statistics of x (or None); returns (y, statistics of y | None).
+    post = (proj_out pieces, bias, x_in, want_gn): when the fused kernel runs, SpatialTransformer.proj_out (+ x_in) rides behind it in
+    the same launch and the result is ("post", out, GroupNorm statistics | None) instead."""
+    if post is not None and FFN_POST and ffn_fused(x, pt):
+        pw, pb, x_in, want_gn = post
+        y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, post=(pw, pb, x_in), want_gn_stats=want_gn)
+        return ("post",) + (y if want_gn else (y, None))
     if ffn_fused(x, pt):
         # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
         ws = want_stats and fold_ok(x)
@@ -453,11 +466,15 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
         assert st_dup_ok(ps)
         x_in = dup2(x_in)
         act = Act(x_in, 2 * act.N, act.H, act.W)
+    want = gn_fuse_ok(h)
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
-        h, st = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=i + 1 < len(ps.blocks),
-                                  dup=dup and i == 0)
-    want = gn_fuse_ok(h)
+        last = i + 1 == len(ps.blocks)
+        post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0) if last and ps.proj_out_x is not None else None
+        r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post)
+        if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
+            return Act(r[1], act.N, act.H, act.W, gs=r[2])
+        h, st = r
     y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want)
     y, gs = y if want else (y, None)
     return Act(y, act.N, act.H, act.W, gs=gs)

@@ -467,7 +467,7 @@ def ffn_ok(M, C, H):
     return C == FFN_C and M % FFN_ROWS == 0 and H % 64 == 0 and 0 < H <= FFN_MAX_H
 
 
-def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None):
+def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, want_gn_stats=False):
     """x + W2 (u * gelu(g)) + b2 with [u | g] = LayerNorm(x) W1^T + b1, in one launch (lr_ffn_block_f16).
     w1 / b1: LayerNorm-folded GEGLU projection in the interleaved [u16 | g16] row order (packing.pack_geglu / fold_layernorm);
     w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  Returns out [M, C] (, stats [M, 2, 2])."""
@@ -485,7 +485,23 @@ def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None):
     a = FfnArgs()
     a.x, a.out, a.w1, a.b1, a.w2, a.b2, a.stats_out = _p(x), _p(out), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats)
     a.M, a.C, a.H, a.ln_eps = M, C, H, float(eps)
+    a.post_w = a.post_b = a.post_resid = a.gn_stats_out = 0
+    gstats = None
+    if post is not None:
+        # (Wp pieces [5, C, 64], bp, x_in): out = (x + ff(LN x)) Wp^T + bp + x_in in the same launch (SpatialTransformer.proj_out)
+        pw_, pb_, pr_ = post
+        _chk16(pr_, "post_resid")
+        assert pw_.dtype == x.dtype and pw_.is_contiguous() and pw_.shape == (C // 64, C, 64) and pr_.shape == (M, C)
+        assert pb_.dtype == torch.float32 and pb_.numel() == C
+        a.post_w, a.post_b, a.post_resid = _p(pw_), _p(pb_), _p(pr_)
+        if want_gn_stats:
+            gstats = (torch.empty(M // FFN_ROWS, C, 2, device=x.device, dtype=torch.float32), FFN_ROWS)
+            a.gn_stats_out = _p(gstats[0])
+    else:
+        assert not want_gn_stats
     _lib.check(_fn(lib, "lr_ffn_block_f16", x.dtype)(a, _stream()), "ffn_block")
+    if want_gn_stats:
+        return out, gstats
     return (out, stats) if want_stats else out
 
 

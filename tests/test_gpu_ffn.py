@@ -100,3 +100,75 @@ def test_engine_transformer_block_fused_ffn_equals_unfused():
     err = (outs[0] - outs[1]).abs().max().item()
     print(f"[fused vs unfused feed-forward in BasicTransformerBlock] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
     assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())
+
+
+@pytest.mark.parametrize("M", [128, 512])
+def test_ffn_block_with_fused_proj_out(M):
+    """POST variant: out = (x + ff(LN x)) Wp^T + bp + x_in (SpatialTransformer.proj_out + residual, attention.py:412-419) in the same
+    launch, plus the per-channel GroupNorm statistics of the output over blocks of 128 rows."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    H = 1280
+    sd, gamma, beta = _params("post", H)
+    wp = h16(torch.from_numpy(weights.fill_like("ffb.post.proj_out.weight", (C, C))))
+    bp = torch.from_numpy(weights.fill_like("ffb.post.proj_out.bias", (C,)))
+    x = h16(G.T(f"ffb.post.{M}.x", (M, C)) * 1.3 + 0.2)
+    x_in = h16(G.T(f"ffb.post.{M}.xin", (M, C)))
+    x3 = _oracle(sd, gamma, beta, x)
+    ref = x_in + torch.nn.functional.linear(x3, wp, bp)
+    wf, bf, _cs = packing.fold_layernorm(sd["f.net.0.proj.weight"], sd["f.net.0.proj.bias"], gamma, beta)
+    perm = packing.geglu_perm(H)
+    out, (gs, rows) = ops.ffn_block(x.half().to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d),
+                                    packing.pack_pieces(sd["f.net.2.weight"]).to(d), sd["f.net.2.bias"].to(d), eps=1e-5,
+                                    post=(packing.pack_pieces(wp).to(d), bp.to(d), x_in.half().to(d)), want_gn_stats=True)
+    report(f"ffn+proj_out M{M}", out, ref, rtol=3e-3, atol=5e-3)
+    assert rows == 128 and gs.shape == (M // 128, C, 2)
+    o32 = out.float().reshape(M // 128, 128, C)
+    torch.testing.assert_close(gs[:, :, 0], o32.sum(1), rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(gs[:, :, 1], (o32 * o32).sum(1), rtol=1e-5, atol=2e-3)
+    out2 = ops.ffn_block(x.half().to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d),
+                         packing.pack_pieces(sd["f.net.2.weight"]).to(d), sd["f.net.2.bias"].to(d), eps=1e-5,
+                         post=(packing.pack_pieces(wp).to(d), bp.to(d), x_in.half().to(d)))
+    assert torch.equal(out, out2)
+
+
+def test_spatial_transformer_post_fused_equals_separate_proj_out():
+    """Drop-in SpatialTransformer at C = 320 through engine.spatial_transformer (with the per-context K / V operands) with proj_out
+    fused behind the feed-forward vs the separate GEMM."""
+    import importlib
+    from leftrefill_amd import engine, ops
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(2)
+    d = dev()
+    st = att.SpatialTransformer(320, 5, 64, depth=1, context_dim=1024, use_linear=True).to(d).eval()
+    with torch.no_grad():
+        for p_ in st.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        st.norm.weight.add_(1.0)
+        for blk in st.transformer_blocks:
+            for n_ in (blk.norm1, blk.norm2, blk.norm3):
+                n_.weight.add_(1.0)
+    ps = engine.PackedST(st)
+    ps.blocks[0].kv_slot = 0
+    N, H_, W_, Lc = 2, 16, 16, 77
+    tok = torch.randn(N * H_ * W_, 320, device=d).half()
+    ctx = torch.randn(N * Lc, 1024, device=d).half()
+    pa = ps.blocks[0].attn2
+    kv = ops.gemm_conv(ctx, pa.kv.w, B=1, H=1, W=N * Lc, taps=1)
+    cache = [(kv, None, ops.gemm_conv(ctx, pa.xk, B=1, H=1, W=N * Lc, taps=1), ops.xattn_pack_vt(kv[:, 320:], N, 5, Lc))]
+    outs, gss = [], []
+    for flag in (True, False):
+        engine.FFN_POST = flag
+        try:
+            with torch.no_grad():
+                a_ = engine.spatial_transformer(engine.Act(tok, N, H_, W_), ctx, Lc, ps, cache)
+            outs.append(a_.tok.float().cpu())
+            gss.append(a_.gs)
+        finally:
+            engine.FFN_POST = True
+    err = (outs[0] - outs[1]).abs().max().item()
+    print(f"[proj_out fused behind the feed-forward vs separate GEMM] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
+    assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())
+    assert gss[0] is not None and gss[0][1] == 128      # GroupNorm statistics ride along (128-row blocks)

@@ -39,8 +39,20 @@ def main():
         h = ops.gemm_conv(xs[i], w1p, B=1, H=1, W=M, taps=1, bias=b1p, geglu=True, ln=(sts[i], 1e-5, csp))
         return ops.gemm_conv(h, w2h, B=1, H=1, W=M, taps=1, bias=b2, resid=xs[i], out=outs[i])
 
+    wp = (torch.randn(C, C, generator=g) / C ** 0.5)
+    wp_h, wp_x = wp.half().to(d), packing.pack_pieces(wp).to(d)
+    bp = (0.1 * torch.randn(C, generator=g)).to(d)
+    xins = [torch.randn(M, C, device=d).half() for _ in range(nsets)]
+
+    def fused_post(i):      # proj_out + x_in behind the block, same launch, with the GroupNorm statistics of the output
+        return ops.ffn_block(xs[i], w1p, b1p, w2x, b2, eps=1e-5, out=outs[i], post=(wp_x, bp, xins[i]), want_gn_stats=True)
+
+    def fused_then_gemm(i):
+        y = ops.ffn_block(xs[i], w1p, b1p, w2x, b2, eps=1e-5)
+        return ops.gemm_conv(y, wp_h, B=1, H=1, W=M, taps=1, bias=bp, resid=xins[i], out=outs[i], want_gn_stats=True)
+
     res = {}
-    for name, fn in (("fused", fused), ("two GEMMs", plain)):
+    for name, fn in (("fused", fused), ("two GEMMs", plain), ("fused + post", fused_post), ("fused, proj_out", fused_then_gemm)):
         fn(0)
         torch.cuda.synchronize()
         cold = min(time_seq(lambda i: fn(i % nsets), nsets * 2) for _ in range(3))
