@@ -2,8 +2,9 @@
 pixels, keep the right (target) half of a stitched canvas, optional area down-sampling, PSNR on [0, 1].
 
 Pure torch on whatever device the tensors live on.  SSIM restates `skimage.metrics.structural_similarity` of the pinned
-scikit_image==0.18.1 with the defaults the reference call uses (test_inpainting.py:160-162); LPIPS needs the pretrained AlexNet
-of the `lpips` package (no weights without network) and is not reproduced."""
+scikit_image==0.18.1 with the defaults the reference call uses (test_inpainting.py:160-162); `LPIPSAlex` restates the published
+LPIPS(alex) computation (test_inpainting.py:159) and takes the pretrained weights from the user (none ship without network;
+parity-unpinned: the `lpips` package is absent here)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -59,3 +60,81 @@ def ssim_gray(pred_gray, origin_gray):
     s = ((2 * ua * ub + c1) * (2 * vab + c2)) / ((ua * ua + ub * ub + c1) * (va + vb + c2))
     pad = (win - 1) // 2
     return float(s[pad:-pad, pad:-pad].mean())
+
+
+class LPIPSAlex(torch.nn.Module):
+    """Learned perceptual distance of the harness (`model.loss_fn_alex = lpips.LPIPS(net='alex')`, test_inpainting.py:159).
+
+    The `lpips` package (requirements: lpips==0.1.4) is a third-party dependency that is absent from the reference tree and
+    from this image, together with its weights; this class restates the PUBLISHED algorithm (Zhang et al., CVPR 2018, v0.1
+    linear calibration) and is **parity-unpinned**: inputs in [-1, 1] -> fixed per-channel shift / scale -> the five ReLU stages of
+    torchvision's AlexNet `features` -> each stage's activations normalised to unit length over channels (eps 1e-10 added to the
+    norm) -> squared difference -> non-negative 1x1 `lin` weights -> spatial mean -> sum over the five stages.  Output [N, 1, 1, 1].
+
+    No weights ship with this repo (no network); `load_weights` takes the two files a user of the reference already has --
+    torchvision's `alexnet-owt-*.pth` (`features.{0,3,6,8,10}.{weight,bias}`) and lpips' `weights/v0.1/alex.pth`
+    (`lin{0..4}.model.1.weight`) -- or one state dict saved from `lpips.LPIPS(net='alex')` (`net.slice{1..5}.{0,3,6,8,10}.*`,
+    `lin{k}.model.1.weight`).  Without weights `forward` raises: the harness then reports LPIPS as not computed."""
+
+    SHIFT = (-0.030, -0.088, -0.188)
+    SCALE = (0.458, 0.448, 0.450)
+    CONVS = ((3, 64, 11, 4, 2), (64, 192, 5, 1, 2), (192, 384, 3, 1, 1), (384, 256, 3, 1, 1), (256, 256, 3, 1, 1))   # cin, cout, k, stride, pad
+    FEATURE_INDEX = (0, 3, 6, 8, 10)          # positions of the convolutions in torchvision's alexnet.features
+    POOL_BEFORE = (False, True, True, False, False)   # MaxPool2d(3, 2) in front of conv2 and conv3
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor(self.SHIFT).view(1, 3, 1, 1))
+        self.register_buffer("scale", torch.tensor(self.SCALE).view(1, 3, 1, 1))
+        self.convs = torch.nn.ModuleList(torch.nn.Conv2d(ci, co, k, s, p) for ci, co, k, s, p in self.CONVS)
+        self.lins = torch.nn.ParameterList(torch.nn.Parameter(torch.zeros(1, co, 1, 1), requires_grad=False) for _, co, *_ in self.CONVS)
+        self.loaded = False
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def load_weights(self, *state_dicts):
+        """Accepts any mix of the key spellings in the class docstring; raises KeyError naming what is still missing."""
+        sd = {}
+        for s in state_dicts:
+            sd.update(s)
+        missing = []
+        for i, fi in enumerate(self.FEATURE_INDEX):
+            for leaf in ("weight", "bias"):
+                for key in (f"features.{fi}.{leaf}", f"net.slice{i + 1}.{fi}.{leaf}"):
+                    if key in sd:
+                        getattr(self.convs[i], leaf).copy_(sd[key])
+                        break
+                else:
+                    missing.append(f"features.{fi}.{leaf}")
+            for key in (f"lin{i}.model.1.weight", f"lins.{i}.model.1.weight"):
+                if key in sd:
+                    self.lins[i].copy_(sd[key].reshape(1, -1, 1, 1))
+                    break
+            else:
+                missing.append(f"lin{i}.model.1.weight")
+        if missing:
+            raise KeyError("LPIPS(alex) weights missing: " + ", ".join(missing))
+        self.loaded = True
+        return self
+
+    def features(self, x):
+        outs = []
+        h = (x - self.shift) / self.scale
+        for conv, pool in zip(self.convs, self.POOL_BEFORE):
+            if pool:
+                h = F.max_pool2d(h, 3, 2)
+            h = F.relu(conv(h))
+            outs.append(h)
+        return outs
+
+    @torch.no_grad()
+    def forward(self, a, b):
+        if not self.loaded:
+            raise RuntimeError("LPIPSAlex has no weights: call load_weights(alexnet_state_dict, lpips_alex_state_dict) first")
+        a, b = a.float(), b.float()
+        total = 0
+        for fa, fb, lin in zip(self.features(a), self.features(b), self.lins):
+            na = fa / (fa.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            nb = fb / (fb.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            total = total + ((na - nb) ** 2 * lin).sum(1, keepdim=True).mean((2, 3), keepdim=True)
+        return total

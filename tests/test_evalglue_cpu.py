@@ -135,3 +135,53 @@ def test_harness_composition_hand_derived_fixture():
     assert abs(mse - fx["expected_mse01"]) < 1e-9
     assert abs(evalglue.psnr01(p, o).item() - fx["expected_psnr_db"]) < 1e-4
     assert torch.allclose(evalglue.rgb_to_gray01(p[0])[0], torch.tensor(fx["expected_gray_pred_metric_row"]), atol=1e-6)
+
+
+def test_lpips_alex_restatement_structure_and_properties():
+    """LPIPS(alex) of the harness (test_inpainting.py:159): `evalglue.LPIPSAlex` against a sequential restatement written with the
+    lpips package's own state-dict key spelling (`net.slice{k}.{idx}.*`, `lin{k}.model.1.weight`), on random weights --
+    PARITY-UNPINNED (the lpips package and its weights are absent here): the check is that the module computes the published
+    formula from whichever key spelling it is given, is symmetric, zero on identical inputs, and refuses to run without weights."""
+    import torch.nn.functional as F
+    from leftrefill_amd.evalglue import LPIPSAlex
+    g = torch.Generator().manual_seed(3)
+    shapes = LPIPSAlex.CONVS
+    idx = LPIPSAlex.FEATURE_INDEX
+    sd_pkg, sd_tv, sd_lin = {}, {}, {}
+    for k, (ci, co, ks, st, pd) in enumerate(shapes):
+        w = torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5
+        b = 0.1 * torch.randn(co, generator=g)
+        lin = torch.rand(1, co, 1, 1, generator=g)
+        sd_pkg[f"net.slice{k + 1}.{idx[k]}.weight"], sd_pkg[f"net.slice{k + 1}.{idx[k]}.bias"], sd_pkg[f"lin{k}.model.1.weight"] = w, b, lin
+        sd_tv[f"features.{idx[k]}.weight"], sd_tv[f"features.{idx[k]}.bias"] = w, b
+        sd_lin[f"lin{k}.model.1.weight"] = lin
+    a = torch.rand(2, 3, 96, 80, generator=g) * 2 - 1
+    b_img = (a + 0.3 * torch.randn(a.shape, generator=g)).clamp(-1, 1)
+
+    def published(x0, x1):
+        shift = torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1)
+        scale = torch.tensor([.458, .448, .450]).view(1, 3, 1, 1)
+        total = torch.zeros(x0.shape[0], 1, 1, 1)
+        h0, h1 = (x0 - shift) / scale, (x1 - shift) / scale
+        for k, (ci, co, ks, st, pd) in enumerate(shapes):
+            if k in (1, 2):
+                h0, h1 = F.max_pool2d(h0, kernel_size=3, stride=2), F.max_pool2d(h1, kernel_size=3, stride=2)
+            w, bb = sd_pkg[f"net.slice{k + 1}.{idx[k]}.weight"], sd_pkg[f"net.slice{k + 1}.{idx[k]}.bias"]
+            h0, h1 = F.relu(F.conv2d(h0, w, bb, st, pd)), F.relu(F.conv2d(h1, w, bb, st, pd))
+            n0 = h0 / (torch.sqrt(torch.sum(h0 ** 2, dim=1, keepdim=True)) + 1e-10)
+            n1 = h1 / (torch.sqrt(torch.sum(h1 ** 2, dim=1, keepdim=True)) + 1e-10)
+            total = total + F.conv2d((n0 - n1) ** 2, sd_pkg[f"lin{k}.model.1.weight"]).mean([2, 3], keepdim=True)
+        return total
+
+    want = published(a, b_img)
+    m1 = LPIPSAlex().load_weights(sd_pkg)
+    m2 = LPIPSAlex().load_weights(sd_tv, sd_lin)
+    d1, d2 = m1(a, b_img), m2(a, b_img)
+    assert d1.shape == (2, 1, 1, 1)
+    assert torch.allclose(d1, want, rtol=1e-5, atol=1e-7) and torch.equal(d1, d2)
+    assert torch.allclose(m1(b_img, a), d1, rtol=1e-6) and (d1 > 0).all()
+    assert torch.equal(m1(a, a), torch.zeros(2, 1, 1, 1))
+    with pytest.raises(RuntimeError, match="no weights"):
+        LPIPSAlex()(a, b_img)
+    with pytest.raises(KeyError, match="lin4.model.1.weight"):
+        LPIPSAlex().load_weights(sd_tv, {k: v for k, v in sd_lin.items() if not k.startswith("lin4")})

@@ -7,7 +7,9 @@ Call sequence reproduced (reference line numbers): create_model(model_config.yam
 ckpts/epoch=*.ckpt, then pretrained_models/512-inpainting-ema.ckpt when `save_prompt_only` (84-97) -> .to("cuda").eval()
 (102-103) -> no_grad + autocast (126) -> model.log_images(batch, N, unconditional_guidance_scale=cfg, ddim_eta=eta) (141)
 -> pred*mask + origin*(1-mask) (146-147) -> keep the right half (148-150) -> PSNR on (x+1)/2 (158), SSIM on the luma (160-162)
--> PNG (168-190).  LPIPS needs the pretrained AlexNet of the `lpips` package (no weights without network): not computed.
+-> PNG (168-190).  LPIPS (159): `--lpips_weights alexnet-owt.pth,lpips_alex.pth` (torchvision's AlexNet + the lpips package's
+v0.1 linear layers, or one state dict of `lpips.LPIPS(net='alex')`) feeds `evalglue.LPIPSAlex`; without the files (none ship:
+no network) the metric is reported as not computed.
 
 --test_path DIR is read through `dataloaders.test_dataset.TestInpaintingDataset` (drop-in of the reference loader: pair
 directories with source / target / mask files) and torch's DataLoader, exactly like the reference (118-120).  Without it
@@ -64,6 +66,7 @@ def main():
     ap.add_argument("--fp16", action="store_true")       # idem (63)
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--pretrained", type=str, default="pretrained_models/512-inpainting-ema.ckpt")
+    ap.add_argument("--lpips_weights", type=str, default=None, help="comma-separated state-dict files for LPIPS(alex)")
     a = ap.parse_args()
 
     import leftrefill_amd.dropin as dropin
@@ -81,7 +84,10 @@ def main():
     os.makedirs(a.output_path, exist_ok=True)
     batches = dataset_batches(a.test_path, a.batch_size, a.test_size, model) if a.test_path else \
         synthetic_batches(max(1, a.synthetic), a.batch_size, a.test_size)
-    psnrs, ssims = [], []
+    lpips_fn = None
+    if a.lpips_weights:
+        lpips_fn = evalglue.LPIPSAlex().load_weights(*[torch.load(f, map_location="cpu") for f in a.lpips_weights.split(",")]).cuda()
+    psnrs, ssims, lpipss = [], [], []
     with torch.no_grad(), torch.autocast("cuda"):
         for bi, batch in enumerate(batches):
             batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -91,6 +97,9 @@ def main():
                 print(f"WARNING: {100 * bad:.2f} % of the decoded prediction is not finite (batch {bi})")
             pred, origin = evalglue.compose_prediction(out, batch["mask"], a.test_size, a.metric_size)
             psnrs.extend(evalglue.psnr01(pred, origin).tolist())
+            if lpips_fn is not None:
+                with torch.autocast("cuda", enabled=False):
+                    lpipss.extend(lpips_fn(pred.float(), origin.float()).flatten().tolist())   # LPIPS takes [-1, 1] (159)
             for j in range(pred.shape[0]):
                 ssims.append(evalglue.ssim_gray(evalglue.rgb_to_gray01(pred[j]), evalglue.rgb_to_gray01(origin[j])))
             p01 = (pred.float().clamp(-1, 1) + 1) / 2
@@ -103,9 +112,11 @@ def main():
                 pass
     print(f"PSNR: {float(np.mean(psnrs)):.3f} over {len(psnrs)} images")
     print(f"SSIM: {float(np.mean(ssims)):.4f}")
+    lp = f"{float(np.mean(lpipss)):.4f}" if lpipss else "not computed (no --lpips_weights)"
+    print(f"LPIPS: {lp}")
     os.makedirs(a.metric_output, exist_ok=True)
     with open(os.path.join(a.metric_output, os.path.basename(os.path.normpath(a.model_path)) + ".txt"), "w") as f:
-        f.write(f"PSNR: {float(np.mean(psnrs)):.4f}\nSSIM: {float(np.mean(ssims)):.4f}\n")
+        f.write(f"PSNR: {float(np.mean(psnrs)):.4f}\nSSIM: {float(np.mean(ssims)):.4f}\nLPIPS: {lp}\n")
 
 
 if __name__ == "__main__":
