@@ -30,9 +30,7 @@
 #define FF_SLOT 40960
 #define FF_PITCH 336          // bytes per staged row of a wave's 160 output columns (320 + 16: rows start in distinct banks)
 #define FF_PAR_BYTES ((2 * FF_MAX_H + 2 * FF_C) * 4)      // bias rows behind the ring
-#ifndef FF_DEPTH
-#define FF_DEPTH 2
-#endif
+#define FF_DEPTH 2            // MFMA groups a fragment read runs ahead of its use (3 measured the same)
 #define FF_MAX_H 2048          // hidden units whose bias rows fit the LDS region behind the ring
 
 struct FfnParams {

@@ -34,9 +34,6 @@
 #define XA_SLOT 40960
 #define XA_PITCH 656          // bytes per staged output row (640 + 16: the 16 rows of a wave start in distinct banks)
 #define XA_VT_OFF 16384       // V^T sub-tiles inside the K|V slot
-#ifndef XA_SPREAD
-#define XA_SPREAD 1
-#endif
 
 struct XattnParams {
   const void* x; const void* wq; const float* bq; const void* k; const void* vt; const void* wo; const float* bo;

@@ -442,6 +442,7 @@ def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_sta
     assert k.dtype == x.dtype and k.stride(1) == 1 and k.shape[0] == (M // HW) * Lc and vt.dtype == x.dtype and vt.is_contiguous()
     if out is None:
         out = torch.empty_like(x)
+    assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous() and out.device == x.device
     stats = torch.empty(M, 1, 2, device=x.device, dtype=torch.float32) if want_stats else None
     a = XattnArgs()
     a.x, a.out, a.wq, a.bq, a.k, a.ldk, a.vt, a.wo, a.bo = _p(x), _p(out), _p(wq), _p(bq), _p(k), k.stride(0), _p(vt), _p(wo), _p(bo)
@@ -470,7 +471,9 @@ def ffn_ok(M, C, H):
 def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, want_gn_stats=False):
     """x + W2 (u * gelu(g)) + b2 with [u | g] = LayerNorm(x) W1^T + b1, in one launch (lr_ffn_block_f16).
     w1 / b1: LayerNorm-folded GEGLU projection in the interleaved [u16 | g16] row order (packing.pack_geglu / fold_layernorm);
-    w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  Returns out [M, C] (, stats [M, 2, 2])."""
+    w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  post = (Wp pieces, bp, x_in): out = x3 Wp^T + bp + x_in as well
+    (SpatialTransformer.proj_out + outer residual).  Returns out [M, C]; (out, stats [M, 2, 2]) with want_stats; (out, (column sums
+    [M / 128, C, 2], 128)) with want_gn_stats (needs post; takes precedence over want_stats)."""
     lib = _lib.load()
     _chk16(x, "x")
     M, C = x.shape
@@ -481,6 +484,7 @@ def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, 
     assert b1.dtype == torch.float32 and b1.numel() == 2 * H and b2.dtype == torch.float32 and b2.numel() == C
     if out is None:
         out = torch.empty_like(x)
+    assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous() and out.device == x.device
     stats = torch.empty(M, 2, 2, device=x.device, dtype=torch.float32) if want_stats else None      # one partial per wave of a pair
     a = FfnArgs()
     a.x, a.out, a.w1, a.b1, a.w2, a.b2, a.stats_out = _p(x), _p(out), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats)
