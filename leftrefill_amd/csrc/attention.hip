@@ -18,6 +18,7 @@
 //   more than 2^8 (exp2 domain).
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 #define ATT_THREADS 256
@@ -301,6 +302,278 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   }
 }
 
+// =====================================================================================================================
+// Ping-pong variant for long key sequences (pre-transposed V, Nkv a multiple of 64): block = 8 waves = two GROUPS of four.
+//
+// Why: two co-resident 4-wave blocks of attention_kernel start together and run the same instruction stream, so the two
+// waves of a SIMD sit in their MFMA stretch (QK^T, PV) at the same time and in their softmax stretch (VALU / exp) at the same
+// time -- measured: time(MFMA + softmax) = time(MFMA) + time(softmax), a block alone on its CU runs 1.8x faster than one of a
+// pair.  Here the two waves of every SIMD (waves w and w + 4 of the block) are held in ANTI-phase by two block-wide barriers
+// per key tile: while group 0 issues the 32 MFMAs of [PV(j-1), QK^T(j)], group 1 runs the softmax of its tile j-1 on the VALU /
+// transcendental pipes, then they swap (MI355X_MICROARCH.md, "Two waves per SIMD": the matrix pipe is per SIMD, VALU issue is
+// arbitrated between the two waves -- complementary segments are what pays).
+//
+//   iteration j = 0 .. T (T key tiles)     group 0                         group 1
+//     even phase                           PV(j-1) [j >= 1], QK^T(j) [j < T]    softmax(j-1) [j >= 1]
+//     barrier (LDS-DMA stays in flight)
+//     odd phase                            softmax(j) [j < T]              PV(j-1) [j >= 1], QK^T(j) [j < T]
+//     vmcnt(0), barrier
+//
+// K / V^T tiles: 3-slot LDS ring of 16 KB stages (stage s = K tile s + V^T tile s), one 1-KB LDS-DMA of each per wave, issued at
+// the top of iteration s - 1: K_s is read in iteration s, V_s in iteration s + 1, its slot is refilled in iteration s + 2.
+// The arithmetic of a wave is instruction for instruction that of attention_kernel (same MFMA order per accumulator, same
+// softmax code), so the two kernels agree bit for bit (tests/test_gpu_ops.py).
+// NQB = 32-query blocks per wave (2: 512 queries per block; 1: 256 queries per block, for sequences too short to fill the chip
+// with 512-query blocks).
+// =====================================================================================================================
+#define PP_THREADS 512
+#define PP_STAGE_BYTES (2 * ATT_KB * 128)
+#define PP_NSTAGE 3
+
+template <typename T, int NQB>
+__global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnParams<T> P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char smem[PP_NSTAGE * PP_STAGE_BYTES];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = w >> 2;
+  int bid = blockIdx.x;
+  {
+    const int q = P.nblocks >> 3, r = P.nblocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int qt = bid % P.nqt;
+  const int bh = bid / P.nqt;
+  const int h = bh % P.heads, b = bh / P.heads;
+
+  const T* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
+  const T* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
+  const T* vp = P.v + ((size_t)b * P.heads + h) * 64 * P.ldv;
+  T* op = P.o + (size_t)b * P.Nq * P.ldo + h * 64;
+
+  const int ql = lane & 31, hi = lane >> 5;
+  int qrow[NQB];
+  vec8<T> qf[NQB][4];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    qrow[qb] = qt * (8 * 32 * NQB) + w * (32 * NQB) + qb * 32 + ql;
+    const int qc = min(qrow[qb], P.Nq - 1);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      qf[qb][s4] = *reinterpret_cast<const vec8<T>*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
+  }
+  const int T_ = P.Nkv / ATT_KB;
+
+  // stage s -> slot s % 3: wave w moves rows 8 w .. 8 w + 7 of the K tile and of the V^T tile (one 1-KB LDS-DMA each)
+  const int srow = w * 8 + (lane >> 3);
+  const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+  const T* ksrc = kp + (size_t)srow * P.ldk + schunk * 8;
+  const T* vsrc = vp + (size_t)srow * P.ldv + schunk * 8;
+  auto stage = [&](int s) {
+    char* Ks = smem + (s % PP_NSTAGE) * PP_STAGE_BYTES;
+    char* Vs = Ks + ATT_KB * 128;
+    __builtin_amdgcn_global_load_lds((gptr_t)(ksrc + (size_t)s * ATT_KB * P.ldk), (lptr_t)(Ks + w * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(vsrc + s * ATT_KB), (lptr_t)(Vs + w * 1024), 16, 0, 0);
+  };
+
+  f32x16 oacc[NQB][2];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+  float m_run[NQB], l_run[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 sacc[NQB][2];
+  vec8<T> pf[NQB][2][2];
+
+  // ---- matrix segment: O^T += V^T(jv) P^T(jv)  (steps 0-3, PV) and S^T(jk) = K(jk) Q^T  (steps 4-7, QK).  Eight steps of two
+  // fragment reads + four MFMAs (2 query blocks x 2 row blocks); the reads of step i + 1 are issued BEFORE the MFMAs of step i
+  // (two register sets, order pinned with sched_barrier) -- left alone hipcc reads each fragment pair right before its MFMAs and
+  // the matrix pipe idles through every LDS round trip.
+  // Fragment addresses: chunk c = 2 sigma + hi of row ql (sigma = step & 3), swizzled slot c ^ ((ql >> 1) & 7); the row 32 + ql
+  // has the same swizzle term, i.e. the second fragment of a step sits 4096 bytes further (an immediate offset).  The reads are
+  // inline asm with hand-counted lgkmcnt waits: hipcc waits lgkmcnt(0) before every MFMA group here, i.e. also for the pair it
+  // has just issued, and the matrix pipe would idle through an LDS round trip every other step.
+  unsigned fa_off[4];
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg) fa_off[sg] = (unsigned)(ql * 128 + (((2 * sg + hi) ^ ((ql >> 1) & 7)) << 4));
+  const unsigned lds0 = __builtin_bit_cast(unsigned, (lptr_t)smem);
+  auto frag_read = [&](const unsigned addr, vec8<T>& f0, vec8<T>& f1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(f0), "=&v"(f1) : "v"(addr));
+  };
+  // wait until at most N of this wave's LDS reads are outstanding; naming the fragments makes their consumers depend on the wait
+  auto frag_wait2 = [&](vec8<T>& f0, vec8<T>& f1) { asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f0), "+v"(f1)); };
+  auto frag_wait0 = [&](vec8<T>& f0, vec8<T>& f1) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1)); };
+  auto frag_mma = [&](const int step, const vec8<T>& f0, const vec8<T>& f1) {
+    if (step < 4) {
+      const int kb = step >> 1, tt = step & 1;
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        oacc[qb][0] = lr_mfma32(f0, pf[qb][kb][tt], oacc[qb][0]);
+        oacc[qb][1] = lr_mfma32(f1, pf[qb][kb][tt], oacc[qb][1]);
+      }
+    } else {
+      const int s4 = step - 4;
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        sacc[qb][0] = lr_mfma32(f0, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][0]);
+        sacc[qb][1] = lr_mfma32(f1, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][1]);
+      }
+    }
+  };
+  // FIRST / LAST: compile-time step range (0..7 both products, 4..7 only QK: the first tile, 0..3 only PV: the drain)
+  auto matrix_segment = [&](auto first_tag, auto last_tag, int jv, int jk) {
+    constexpr int S0 = decltype(first_tag)::value, S1 = decltype(last_tag)::value;
+    const unsigned vbase = lds0 + (unsigned)((jv % PP_NSTAGE) * PP_STAGE_BYTES + ATT_KB * 128);
+    const unsigned kbase = lds0 + (unsigned)((jk % PP_NSTAGE) * PP_STAGE_BYTES);
+    auto addr = [&](const int step) -> unsigned { return (step < 4 ? vbase : kbase) + fa_off[step & 3]; };
+    vec8<T> fa[2], fb[2];
+    frag_read(addr(S0), fa[0], fa[1]);
+#pragma unroll
+    for (int step = S0; step < S1; step += 2) {
+      frag_read(addr(step + 1), fb[0], fb[1]);
+      frag_wait2(fa[0], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(step, fa[0], fa[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + 2 < S1) {
+        frag_read(addr(step + 2), fa[0], fa[1]);
+        frag_wait2(fb[0], fb[1]);
+      } else {
+        frag_wait0(fb[0], fb[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(step + 1, fb[0], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using IC0 = std::integral_constant<int, 0>;
+  using IC4 = std::integral_constant<int, 4>;
+  using IC8 = std::integral_constant<int, 8>;
+  // ---- softmax segment: S^T(j) -> P^T(j) (fp16 / bf16, the PV B-operand), running max / sum, deferred rescale of O
+  auto softmax_segment = [&]() {
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      float mx = sacc[qb][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
+      {
+        const unsigned u = __builtin_bit_cast(unsigned, mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+      }
+      if (!__all((mx - m_run[qb]) * P.c <= 8.0f)) {
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * P.c);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+      }
+      const f32x2 c2 = {P.c, P.c};
+      const f32x2 mc2 = {m_run[qb] * P.c, m_run[qb] * P.c};
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+          const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
+          const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          ps2 += pv;
+          pf[qb][kb][r >> 3][r & 7] = (T)pv[0];
+          pf[qb][kb][r >> 3][(r & 7) + 1] = (T)pv[1];
+        }
+      l_run[qb] += ps2[0] + ps2[1];
+    }
+  };
+
+  // phase ends: `mid` keeps the LDS-DMA of the next stage in flight, `end` retires it (it is first read in the next iteration)
+  // (sched_barrier(0) on both sides: the scheduler may not move register-only work -- softmax VALU, MFMAs -- across the barrier,
+  // the whole point of which is to keep the two groups in complementary segments)
+  auto mid = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  stage(0);
+  end();
+  // The two groups run separate loops with the same barrier count (2 per iteration, T_ + 1 iterations), so in each loop only
+  // ONE of the big register arrays is carried across iterations (group 0: P^T, group 1: S^T).
+  if (grp == 0) {
+    if (T_ > 1) stage(1);
+    matrix_segment(IC4{}, IC8{}, 0, 0); mid();
+    softmax_segment(); end();
+    for (int j = 1; j < T_; ++j) {
+      if (j + 1 < T_) stage(j + 1);
+      matrix_segment(IC0{}, IC8{}, j - 1, j); mid();
+      softmax_segment(); end();
+    }
+    matrix_segment(IC0{}, IC4{}, T_ - 1, 0); mid();
+    end();
+  } else {
+    if (T_ > 1) stage(1);
+    mid();
+    matrix_segment(IC4{}, IC8{}, 0, 0); end();
+    for (int j = 1; j < T_; ++j) {
+      if (j + 1 < T_) stage(j + 1);
+      softmax_segment(); mid();
+      matrix_segment(IC0{}, IC8{}, j - 1, j); end();
+    }
+    softmax_segment(); mid();
+    matrix_segment(IC0{}, IC4{}, T_ - 1, 0); end();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    float lt = l_run[qb];
+    {
+      const unsigned u = __builtin_bit_cast(unsigned, lt);
+      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      lt = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+    }
+    const float inv = 1.0f / lt;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        vec4<T> x, y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = (T)(oacc[qb][db][g * 4 + i] * inv);
+          y[i] = (T)(oacc[qb][db][(g + 1) * 4 + i] * inv);
+        }
+        const uint2 xu = __builtin_bit_cast(uint2, x), yu = __builtin_bit_cast(uint2, y);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(xu.x, yu.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(xu.y, yu.y, false, false);
+        const uint4 o4 = make_uint4((unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]);
+        if (qrow[qb] < P.Nq)
+          *reinterpret_cast<uint4*>(op + (size_t)qrow[qb] * P.ldo + db * 32 + 8 * (g + hi)) = o4;
+      }
+  }
+#endif
+}
+
+// LR_ATTN_PP (developer A/B switch, read at every launch): 0 keeps attention_kernel for every shape, 1 (default) picks the
+// block size by the rule in launch_attention, 2 / 3 force 512- / 256-query blocks
+static int attn_pp_mode() {
+  const char* v = getenv("LR_ATTN_PP");
+  return v ? atoi(v) : 1;
+}
+
 template <typename T>
 static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                             int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt,
@@ -317,6 +590,20 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = lse;
+  const int pp = attn_pp_mode();
+  if (vt && !lse && pp && Nkv % ATT_KB == 0 && Nkv >= 4 * ATT_KB) {
+    // ping-pong kernel: 512-query blocks when they fill the chip for at least two rounds, else 256-query blocks
+    const int nb2 = ((Nq + 511) / 512) * heads * B;
+    const bool two = pp == 2 || (pp == 1 && nb2 >= 512);
+    if (two) {
+      P.nqt = (Nq + 511) / 512; P.nblocks = P.nqt * heads * B;
+      hipLaunchKernelGGL((attention_pp_kernel<T, 2>), dim3(P.nblocks), dim3(PP_THREADS), 0, (hipStream_t)s, P);
+    } else {
+      P.nqt = (Nq + 255) / 256; P.nblocks = P.nqt * heads * B;
+      hipLaunchKernelGGL((attention_pp_kernel<T, 1>), dim3(P.nblocks), dim3(PP_THREADS), 0, (hipStream_t)s, P);
+    }
+    return lr_launch_status();
+  }
   if (vt) hipLaunchKernelGGL((attention_kernel<T, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   else hipLaunchKernelGGL((attention_kernel<T, false>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();

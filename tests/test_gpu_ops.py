@@ -606,6 +606,41 @@ def test_attention_vt_rescale_and_hot_shapes():
         ops.VT_MIN_KEYS = old_min
 
 
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 512, 256), (2, 3, 1000, 1024), (1, 2, 700, 320), (1, 1, 2048, 2048), (1, 1, 130, 4096)])
+def test_attention_pingpong_kernel_matches_reference_kernel(B, heads, Nq, Nkv):
+    """attention_pp_kernel (8 waves, the two waves of a SIMD held in complementary matrix / softmax segments) runs the same
+    arithmetic per wave as attention_kernel: bit-identical outputs for 512- and 256-query blocks, query tails, every ring
+    slot phase (T = 4, 5, 16, 32, 64 key tiles), with forced running-max jumps (guide rule 26) in the first, a middle and
+    the last key tile."""
+    from leftrefill_amd import ops
+    d = dev()
+    C = heads * 64
+    q = h16(G.T(f"attpp.{Nq}.{Nkv}.q", (B, Nq, C)))
+    k = h16(G.T(f"attpp.{Nq}.{Nkv}.k", (B, Nkv, C)))
+    v = h16(G.T(f"attpp.{Nq}.{Nkv}.v", (B, Nkv, C)))
+    k[0, 3, :64] = q[0, 100, :64] * 5.0
+    k[0, Nkv // 2 + 5, :64] = q[0, 40, :64] * 5.0
+    k[0, Nkv - 2, :64] = q[0, 7, :64] * 6.0
+    qd, kd, vd = (t_.reshape(-1, C).half().to(d) for t_ in (q, k, v))
+    vt = ops.transpose_v(vd, B, heads, Nkv)
+    old = os.environ.get("LR_ATTN_PP")
+    outs = {}
+    try:
+        for mode in ("0", "2", "3", "1"):
+            os.environ["LR_ATTN_PP"] = mode
+            outs[mode] = ops.attention(qd, kd, vd, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt)
+            assert torch.equal(outs[mode], ops.attention(qd, kd, vd, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt)), f"mode {mode}: rerun differs"
+    finally:
+        if old is None:
+            os.environ.pop("LR_ATTN_PP", None)
+        else:
+            os.environ["LR_ATTN_PP"] = old
+    for mode in ("2", "3", "1"):
+        assert torch.equal(outs[mode], outs["0"]), f"LR_ATTN_PP={mode} differs from attention_kernel"
+    ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))
+    report(f"attention pp B{B} h{heads} {Nq}x{Nkv}", outs["1"].reshape(B, Nq, C), ref, atol=4e-3)
+
+
 def test_mv_gather_scatter():
     from leftrefill_amd import ops
     b, V, s, C = 2, 5, 4, 64
