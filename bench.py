@@ -514,6 +514,108 @@ def cpu_baseline():
             "s_per_unet_step_b2": dt, "config0_full_s": dt0, "config0_images_per_s": 1.0 / dt0}
 
 
+class HwSampler:
+    """Shader clock and socket power of THIS rank's GPU, sampled from the amdgpu hwmon files (freq1_input = sclk in Hz,
+    power1_input in microwatts) every `period` seconds by a background thread while the timed region runs.  The MI355X clocks to
+    its power budget, so the dense-fp16 MFMA rate a kernel can be held against moves with the clock the step sustains
+    (MI355X_MICROARCH.md, "DVFS give-back"); bench.py puts the measured mean next to the roofline fraction instead of quoting a
+    clock from cycle-stamp arithmetic.  The hwmon directory is found through the PCI address of the torch device (the node's other
+    GPUs are visible in sysfs too); fallback: one `rocm-smi --showclocks --showpower --json` poll per second."""
+
+    def __init__(self, device, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self.src = period, [], None
+        self._stop = threading.Event()
+        self._thread = None
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            cands = glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*")
+            if cands and os.path.exists(os.path.join(cands[0], "freq1_input")):
+                self.dir, self.src = cands[0], f"sysfs hwmon of {addr} (freq1_input / power1_input), {int(1 / period)} Hz"
+        except Exception:      # noqa: BLE001
+            self.dir = None
+        if self.dir is None:
+            import shutil
+            self.smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+            if os.path.exists(self.smi):
+                self.src, self.period = "rocm-smi --showclocks --showpower --json (card0), 1 Hz", 1.0
+
+    def _read(self):
+        if self.dir is not None:
+            with open(os.path.join(self.dir, "freq1_input")) as f:
+                mhz = int(f.read()) / 1e6
+            with open(os.path.join(self.dir, "power1_input")) as f:
+                w = int(f.read()) / 1e6
+            return mhz, w
+        import re
+        import subprocess
+        r = subprocess.run([self.smi, "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+        js = json.loads(r.stdout[r.stdout.index("{"):])
+        card = js[sorted(js)[0]]
+        mhz = float(re.sub(r"[^0-9.]", "", card["sclk clock speed:"]))
+        w = float([v for k, v in card.items() if "Power" in k][0])
+        return mhz, w
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:      # noqa: BLE001
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.src is None:
+            return self
+        import threading
+        self.samples = []
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=30)
+            self._thread = None
+        if not self.samples:
+            return {"sclk_mhz_mean": None, "power_w_mean": None, "hw_sampler": self.src or "no hwmon files / rocm-smi on this box"}
+        mhz = [m for m, _ in self.samples]
+        w = [p_ for _, p_ in self.samples]
+        return {"sclk_mhz_mean": sum(mhz) / len(mhz), "sclk_mhz_min": min(mhz), "sclk_mhz_max": max(mhz),
+                "power_w_mean": sum(w) / len(w), "power_w_max": max(w), "hw_samples": len(mhz), "hw_sampler": self.src}
+
+
+def sustained_mfma_peak():
+    """tools/micro/mfma_peak.hip on this GPU, now: chip-wide register-only v_mfma_f32_16x16x32_f16 loops of >= 20 ms on random
+    operands (two waves per SIMD, the GEMM's configuration) -> sustained TFLOP/s and the shader clock it ran at.  This is the
+    dense-fp16 rate the matrix cores of THIS chip deliver inside its power budget; `roofline.peak` stays the datasheet constant."""
+    import shutil
+    import subprocess
+    cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "tools", "micro", "mfma_peak.hip")
+    exe = "/tmp/lr_mfma_peak"
+    if not os.path.exists(cc) or not os.path.exists(src):
+        return {"error": "hipcc or tools/micro/mfma_peak.hip missing"}
+    subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-o", exe, src], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    res = {"lines": [ln.strip() for ln in out.splitlines() if "operands" in ln]}
+    import re
+    for ln in res["lines"]:
+        m = re.search(r"(random|zero)\s+operands\s+v_mfma_f32_(\S+)_f16\s+(\d) wave.*?([0-9.]+) TFLOP/s\s+shader clock\s+([0-9.]+) MHz", ln)
+        if m and m.group(1) == "random" and m.group(3) == "2" and m.group(2) == "16x16x32":
+            res["tflops_random_16x16x32"], res["sclk_mhz"] = float(m.group(4)), float(m.group(5))
+        if m and m.group(1) == "random" and m.group(3) == "1" and m.group(2) == "32x32x16":
+            res["tflops_random_32x32x16"] = float(m.group(4))
+        if m and m.group(1) == "zero" and m.group(3) == "2" and m.group(2) == "16x16x32":
+            res["tflops_zero_16x16x32"] = float(m.group(4))
+    return res
+
+
 def measure_traffic(launches):
     """HBM traffic of the GEMM family, measured NOW: tools/pmc_step.py (one eager UNet step at batch 8) under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains), FETCH doubled per the gfx950
@@ -669,11 +771,13 @@ def main():
     for _ in range(a.warmup):
         sample_once(model, batch, B)
     barrier()
+    hw = HwSampler(device).start() if rank == 0 else None      # shader clock / socket power over exactly the timed region
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = sample_once(model, batch, B)
     barrier()
     dt = time.perf_counter() - t0
+    hw_stats = hw.stop() if hw is not None else {}
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -732,6 +836,17 @@ def main():
                            "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
                            "launches_per_unet_step": g["launches"], "avg_launch_us": g["avg_us"],
                            "algorithmic_gflop_per_unet_step": g["algorithmic_gflop"]}
+        # what the chip gave during the timed region, and what its matrix cores sustain on random operands right now
+        res["roofline"].update({k: hw_stats.get(k) for k in ("sclk_mhz_mean", "sclk_mhz_min", "sclk_mhz_max", "power_w_mean",
+                                                              "power_w_max", "hw_samples", "hw_sampler")})
+        try:
+            pk = sustained_mfma_peak() if world == 1 else {"error": "single-GPU runs only"}
+        except Exception as e:      # noqa: BLE001
+            pk = {"error": f"{type(e).__name__}: {e}"[:300]}
+        res["roofline"]["sustained_peak_measured"] = pk.get("tflops_random_16x16x32")
+        res["roofline"]["sustained_peak_detail"] = pk
+        if pk.get("tflops_random_16x16x32"):
+            res["roofline"]["frac_of_sustained_peak"] = g["tflops"] / pk["tflops_random_16x16x32"]
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
         res["kernel_table"] = kern.get("table", [])[:48]
         res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"),

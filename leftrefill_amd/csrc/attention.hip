@@ -567,11 +567,13 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
 #endif
 }
 
-// LR_ATTN_PP (developer A/B switch, read at every launch): 0 keeps attention_kernel for every shape, 1 (default) picks the
-// block size by the rule in launch_attention, 2 / 3 force 512- / 256-query blocks
+// LR_ATTN_PP (developer A/B switch, read at every launch): 0 (default) = attention_kernel for every shape; 1 = the ping-pong
+// kernel with the block size picked by the rule in launch_attention, 2 / 3 = with 512- / 256-query blocks forced.
+// Measured on MI355X (profiles/r04_attn_pingpong.txt): 8192^2 753 us (attention_kernel) vs 860 / 797 us, 2048^2 116 vs 151 / 121,
+// 20480^2 1408 vs 1383 / 1495 -- the complementary-segment schedule does not pay at d_head = 64, so it is not the default.
 static int attn_pp_mode() {
   const char* v = getenv("LR_ATTN_PP");
-  return v ? atoi(v) : 1;
+  return v ? atoi(v) : 0;
 }
 
 template <typename T>
