@@ -66,6 +66,19 @@ int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int
  * group sums in the layout lr_groupnorm_apply_n reads with nchunks = 1: partials [N][1][32][2]. */
 int lr_groupnorm_finalize(const float* p1, int C1, int R1, const float* p2, int C2, int R2, int N, int HW, float* partials,
                           lr_stream_t s);
+
+/* ---- GroupNorm folded into the pointwise GEMM that consumes it (ABI 20) -------------------------------------------------
+ * replaces: `x = self.norm(x)` of SpatialTransformer.forward (attention.py:399-404: Normalize = GroupNorm(32, eps 1e-6, affine), no
+ *           activation) in front of proj_in (attention.py:405-408): per sample b the normalisation is a per-channel scale / shift
+ *           a[b][c] = gamma[c] rstd[b][g(c)], t[b][c] = beta[c] - mean[b][g(c)] a[b][c], so
+ *              proj_in(norm(x))[m][n] = sum_c (W[n][c] a[b][c]) x[m][c] + (bias[n] + sum_c W[n][c] t[b][c])
+ *           -- the GEMM runs on the RAW x with per-sample weights (lr_gemm_args.wt_bstride) and the normalised tensor is never written.
+ *   gpart [B][chunks][32][2]: per-group (sum, sumsq) partials of x from its producer (lr_gemm_args.gn_group_out), HW rows per sample;
+ *   w [N][C] fp16, bias [N] fp32 or NULL  ->  w_out [B][N][C] = fp16(W a_b),  bias_out [B][N] = bias + W beta - rounded(W a_b) mean_b
+ *   (the mean term uses the ROUNDED weights, so it cancels exactly what the matrix cores accumulate for a constant input).
+ *   C % 32 == 0, C % 8 == 0, C <= 2048. */
+int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
+                           const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
 /* lr_groupnorm_apply with an explicit chunk count of `partials` ([N][nchunks][32][2]) */
 int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                          int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
@@ -143,7 +156,20 @@ typedef struct lr_gemm_args {
                              * LR_PIPE_W8_DEEP (4), tile_m 128 with tile_n 128 | 160: 8 waves (4 x 2, wave tile 32 x tile_n/2), 4-stage
                              * ring, one block per CU (the 4096- / 1024-row levels).
                              * Anything else: LR_E_UNSUPPORTED */
+  /* gn_group_out != NULL (ABI 20): per-GROUP (sum, sumsq) of the fp16-rounded output for the GroupNorm(32) of a consumer that
+   * normalises THIS tensor alone (N / 32 channels per group), [samples][chunks][32][2] fp32 with chunks = lr_gemm_gn_group_chunks(args)
+   * row tiles per sample (a sample = gn_hw rows; 0 = H * W): the tile reduces its per-channel sums to the groups it covers, so
+   * lr_groupnorm_apply_n(partials = gn_group_out, nchunks = chunks) runs without lr_groupnorm_finalize.  LR_E_ARG when the plan
+   * cannot produce it (lr_gemm_gn_group_chunks == 0: tile width not a whole number of groups, tiles straddling samples).  Fixed
+   * order, no atomics; behind split-K it comes out of the reduce kernel (32-row chunks).  May be combined with gn_stats_out. */
+  float* gn_group_out; int32_t gn_hw;
+  /* wt_bstride != 0 (ABI 20): per-sample weights / bias -- rows of sample b = m / (H * W) use wt + b * wt_bstride and
+   * bias + b * bias_bstride (elements).  Pointwise calls only (taps == 1), H * W a multiple of the tile's rows, no split-K.
+   * Used for the GroupNorm of SpatialTransformer folded into proj_in (lr_gn_fold_weights_f16). */
+  int32_t wt_bstride, bias_bstride;
 } lr_gemm_args;
+/* row tiles per sample of gn_group_out for this call, 0 if the plan cannot produce per-group sums */
+int lr_gemm_gn_group_chunks(const lr_gemm_args* args);
 /* rows per block of gn_stats_out (a function of the tile that will be used) */
 int lr_gemm_gn_rows(const lr_gemm_args* args);
 /* plan[0..3] = (tile_m, tile_n, splits, pipe) the call would use: explicit requests as given, zeros resolved by the static
@@ -231,6 +257,9 @@ typedef struct lr_ffn_args {
    * gn_stats_out (optional) [M / 128][320][2] = per-channel (sum, sumsq) of the rounded output over each block of 128 rows, for the
    * GroupNorm that consumes `out` (lr_groupnorm_finalize with R = 128); stats_out is then the row statistics of `out`. */
   const lr_half* post_w; const float* post_b; const lr_half* post_resid; float* gn_stats_out;
+  /* gn_group_out (optional, with post_w; ABI 20) [M / gn_hw][gn_hw / 128][32][2]: per-GROUP (sum, sumsq) of the rounded output over each
+   * block of 128 rows (10 channels per group) -- lr_groupnorm_apply_n reads it directly (nchunks = gn_hw / 128), no finalize launch. */
+  float* gn_group_out; int32_t gn_hw;
 } lr_ffn_args;
 int lr_ffn_block_f16(const lr_ffn_args* args, lr_stream_t s);
 
@@ -330,6 +359,8 @@ int lr_geglu_bwd_bf16(const lr_half* pre, const lr_half* dy, lr_half* dpre, int 
 int lr_sumpool2x2_bf16(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
 int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st);
 int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
+int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
+                            const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
 int lr_attention_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int
     ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 int lr_attention_causal_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half*

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -39,6 +39,8 @@ class GemmArgs(ctypes.Structure):
         ("gn_stats_out", c_void_p),
         ("dtype", ctypes.c_int32),
         ("pipe", ctypes.c_int32),
+        ("gn_group_out", c_void_p), ("gn_hw", ctypes.c_int32),
+        ("wt_bstride", ctypes.c_int32), ("bias_bstride", ctypes.c_int32),
     ]
 
 
@@ -62,7 +64,8 @@ class FfnArgs(ctypes.Structure):
     """struct lr_ffn_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
                 ("stats_out", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("ln_eps", ctypes.c_float),
-                ("post_w", c_void_p), ("post_b", c_void_p), ("post_resid", c_void_p), ("gn_stats_out", c_void_p)]
+                ("post_w", c_void_p), ("post_b", c_void_p), ("post_resid", c_void_p), ("gn_stats_out", c_void_p),
+                ("gn_group_out", c_void_p), ("gn_hw", ctypes.c_int32)]
 
 
 # symbol -> argtypes; every function returns int
@@ -89,6 +92,9 @@ SIGNATURES = {
     "lr_gemm_workspace_bytes": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_stats_parts": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_gn_rows": [ctypes.POINTER(GemmArgs)],
+    "lr_gemm_gn_group_chunks": [ctypes.POINTER(GemmArgs)],
+    "lr_gn_fold_weights_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p],
     "lr_groupnorm_finalize": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "lr_groupnorm_apply_n": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float,
                              c_int, c_void_p, c_void_p],
@@ -119,7 +125,7 @@ BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n"
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
               "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",
-              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16"]
+              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_gn_fold_weights_f16"]
 
 
 def twin(name):

@@ -36,6 +36,7 @@
 struct FfnParams {
   const void* x; const void* w1; const float* b1; const void* w2; const float* b2; void* out; float* st_out;
   const void* post_w; const float* post_b; const void* post_resid; float* gs_out;      // POST (see the kernel)
+  float* gp_out; int gp_hw, gp_chunks;      // POST: per-group sums of the output, [sample][chunk = 128-row block][32][2]
   int M, H, nblocks;
   float eps;
 #ifdef LR_FFN_TRACE
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
       for (int i = 0; i < 8; ++i) a[i] += e[i];
       const uint4 pk = lr_pack8<T>(a);
       *reinterpret_cast<uint4*>(orow + piece * 8) = pk;
-      if constexpr (POST) { if (P.gs_out) *reinterpret_cast<uint4*>(stg + row * FF_PITCH + piece * 16) = pk; }      // final values for the column sums
+      if constexpr (POST) { if (P.gs_out || P.gp_out) *reinterpret_cast<uint4*>(stg + row * FF_PITCH + piece * 16) = pk; }      // final values for the column sums
       lr_unpack8<T>(pk, a);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s1 += a[i]; s2 = fmaf(a[i], a[i], s2); }
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
     }
   }
   if constexpr (POST) {
-    if (P.gs_out) {      // per-channel (sum, sumsq) over the block's 128 rows, fixed order: wave -> its 32 rows, then the four pairs
+    if (P.gs_out || P.gp_out) {      // per-channel (sum, sumsq) over the block's 128 rows, fixed order: wave -> its 32 rows, then the four pairs
       float* cs = reinterpret_cast<float*>(smem + 8 * 32 * FF_PITCH);      // [8 waves][160][2]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (int c = lane; c < C / 2; c += 64) {
@@ -385,13 +386,27 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_block_kernel(const FfnParams P
         cs[(w * (C / 2) + c) * 2 + 1] = a2;
       }
       __syncthreads();
+      float a1 = 0.f, a2 = 0.f;
       if (t < C) {
         const int rl = t / (C / 2), cc = t % (C / 2);
-        float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int p4 = 0; p4 < 4; ++p4) { a1 += cs[((2 * p4 + rl) * (C / 2) + cc) * 2]; a2 += cs[((2 * p4 + rl) * (C / 2) + cc) * 2 + 1]; }
         float2 o; o.x = a1; o.y = a2;
-        *reinterpret_cast<float2*>(P.gs_out + ((size_t)bid * C + t) * 2) = o;
+        if (P.gs_out) *reinterpret_cast<float2*>(P.gs_out + ((size_t)bid * C + t) * 2) = o;
+      }
+      if (P.gp_out) {      // the 32 groups of 10 channels (block-uniform branch)
+        __syncthreads();
+        if (t < C) { cs[t * 2] = a1; cs[t * 2 + 1] = a2; }
+        __syncthreads();
+        if (t < 32) {
+          float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < C / 32; ++c) { g1 += cs[(t * (C / 32) + c) * 2]; g2 += cs[(t * (C / 32) + c) * 2 + 1]; }
+          const int m0 = bid * FF_ROWS;
+          const int smp = m0 / P.gp_hw, chunk = (m0 - smp * P.gp_hw) / FF_ROWS;
+          float2 o; o.x = g1; o.y = g2;
+          *reinterpret_cast<float2*>(P.gp_out + (((size_t)smp * P.gp_chunks + chunk) * 32 + t) * 2) = o;
+        }
       }
     }
   }
@@ -420,8 +435,13 @@ static int ffn_block_t(const lr_ffn_args* a, lr_stream_t s) {
   if (post) {
     if (!a->post_b || !a->post_resid) return LR_E_ARG;
     if (((uintptr_t)a->post_w | (uintptr_t)a->post_b | (uintptr_t)a->post_resid | (uintptr_t)a->gn_stats_out) & 15) return LR_E_ALIGN;
-  } else if (a->gn_stats_out) return LR_E_ARG;
+  } else if (a->gn_stats_out || a->gn_group_out) return LR_E_ARG;
   P.post_w = a->post_w; P.post_b = a->post_b; P.post_resid = a->post_resid; P.gs_out = a->gn_stats_out;
+  P.gp_out = a->gn_group_out; P.gp_hw = 1; P.gp_chunks = 0;
+  if (P.gp_out) {
+    if (a->gn_hw <= 0 || a->gn_hw % FF_ROWS || a->M % a->gn_hw || ((uintptr_t)P.gp_out & 7)) return LR_E_ARG;
+    P.gp_hw = a->gn_hw; P.gp_chunks = a->gn_hw / FF_ROWS;
+  }
   static bool attr_done[2] = {false, false};
   if (!attr_done[post]) {
     hipFuncSetAttribute(post ? reinterpret_cast<const void*>(ffn_block_kernel<T, true>) : reinterpret_cast<const void*>(ffn_block_kernel<T, false>),

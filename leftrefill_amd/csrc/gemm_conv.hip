@@ -38,6 +38,13 @@ struct GemmParams {
   // per-channel (sum, sumsq) of this GEMM's fp16 output over each wave's rows: gs_out[row block][N][2], row block =
   // m / (rows per wave tile); feeds the GroupNorm of the consumer (lr_groupnorm_finalize) instead of a statistics pass
   float* gs_out;
+  // per-GROUP (sum, sumsq) of this GEMM's fp16 output over each tile's rows, for the GroupNorm(32) of a single-source consumer:
+  // gp_out[sample][gp_chunks][32][2], chunk = row tile inside the sample (gp_hw rows per sample, a multiple of the tile's rows),
+  // gp_cg = N / 32 channels per group (divides the tile width).  lr_groupnorm_apply_n reads it directly: no finalize launch.
+  float* gp_out; int gp_cg, gp_chunks, gp_hw;
+  int gs_store;   // split-K reduce: write gs_out (0 when gs_out only carries the "statistics wanted" flag for gp_out)
+  // per-sample weights / bias (GroupNorm folded into a pointwise GEMM, lr_gn_fold_weights_f16): sample = m / rows_per_batch
+  int wt_bstride, bias_bstride;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
@@ -125,7 +132,7 @@ __device__ __forceinline__ constexpr int weight_tile(const int wn, const int j) 
 template <int TM, int TN, int MODE, int PAR_LD, int WNW, typename T>
 __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)[TN][TM], const int m_w0, const int n0,
                                                const int wn, const int lane, const float* rs, const float* par,
-                                               const int part) {
+                                               const int part, float* gsl = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool GEGLU = MODE == 1;
   constexpr int TE = GEGLU ? TN / 2 : TN;
@@ -162,7 +169,9 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   // GroupNorm statistics of the consumer: per-channel sums over the wave's rows.  All units of a column group (the TM
   // units of a tile-column pair, or the TM/2 units of the odd last column) put the SAME eight channels in a lane, so the
   // lane accumulates over them and the group is reduced over the 16 row lanes (4 DPP adds per value) when it completes.
-  const bool gstat = !GEGLU && fin && P.gs_out != nullptr && P.st_out == nullptr;
+  // gsl: LDS [block columns][2] of this wave's row block -- the per-channel sums also go there when the block reduces them to
+  // per-group sums afterwards (gn_group_reduce)
+  const bool gstat = !GEGLU && fin && (P.gs_out != nullptr || P.gp_out != nullptr) && P.st_out == nullptr;
   auto row16_sum = [&](float v) -> float {   // sum over the 16 lanes of a DPP row, result in every lane
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
@@ -183,12 +192,22 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
       }
       g1(q) = a; g2(q) = b;
     }
-    if (fr == 0 && (!pair_fq || !odd) && n_lane < N_out && m_w0 < P.M) {
-      float* dst = P.gs_out + ((size_t)rb * N_out + n_lane) * 2;
+    if (fr == 0 && (!pair_fq || !odd) && n_lane < N_out) {
+      if (P.gs_out != nullptr && m_w0 < P.M) {
+        float* dst = P.gs_out + ((size_t)rb * N_out + n_lane) * 2;
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        const f32x4 o = {g1(q), g2(q), g1(q + 1), g2(q + 1)};
-        *reinterpret_cast<f32x4*>(dst + 2 * q) = o;
+        for (int q = 0; q < 8; q += 2) {
+          const f32x4 o = {g1(q), g2(q), g1(q + 1), g2(q + 1)};
+          *reinterpret_cast<f32x4*>(dst + 2 * q) = o;
+        }
+      }
+      if (P.gp_out != nullptr) {      // rows past M contributed zeros
+        float* dst = gsl + (n_lane - no0) * 2;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          const f32x4 o = {g1(q), g2(q), g1(q + 1), g2(q + 1)};
+          *reinterpret_cast<f32x4*>(dst + 2 * q) = o;
+        }
       }
     }
 #pragma unroll
@@ -353,14 +372,35 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
 #endif
 }
 
+// Per-group sums of a tile from the per-channel sums its waves left in LDS: gsl[row block][BN_][2] -> gp_out.  One thread
+// per group of the tile, fixed order (row blocks outer, channels inner).  Called by all threads after a block-wide barrier.
+template <int BN_, int NROWBLK, int BM_>
+__device__ __forceinline__ void gn_group_reduce(const GemmParams& P, const float* gsl, const int m0, const int n0, const int t) {
+  const int cg = P.gp_cg;
+  if (t < BN_ / cg && m0 < P.M) {
+    const int g = n0 / cg + t;
+    if (g < 32) {
+      float s = 0.f, q = 0.f;
+      for (int rb = 0; rb < NROWBLK; ++rb) {
+        const float2* src = reinterpret_cast<const float2*>(gsl) + rb * BN_ + t * cg;
+        for (int c = 0; c < cg; ++c) { const float2 v = src[c]; s += v.x; q += v.y; }
+      }
+      const int smp = m0 / P.gp_hw, chunk = (m0 - smp * P.gp_hw) / BM_;
+      float2 o; o.x = s; o.y = q;
+      *reinterpret_cast<float2*>(P.gp_out + (((size_t)smp * P.gp_chunks + chunk) * 32 + g) * 2) = o;
+    }
+  }
+}
+
 // Kernel prologue: bias and ln_colsum of the block's BN columns -> LDS par[2][PAR_LD] by 4-byte LDS-DMA (wave w covers
 // columns 64 w .. 64 w + 63; a missing operand or a column >= N reads as 0 through the descriptor's bounds check).
 // Issued BEFORE the first K stage, so every later counted vmcnt wait covers it.
 template <int BN, int PAR_LD>
-__device__ __forceinline__ void stage_params(const GemmParams& P, float* par, const int n0, const int w, const int lane) {
+__device__ __forceinline__ void stage_params(const GemmParams& P, float* par, const int n0, const int w, const int lane,
+                                             const int smp = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (w < (BN + 63) / 64) {
-    const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(P.bias ? (const void*)P.bias : (const void*)P.wt,
+    const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(P.bias ? (const void*)(P.bias + (size_t)smp * P.bias_bstride) : (const void*)P.wt,
                                                    (P.bias && P.splits == 1) ? (size_t)P.N * 4 : 0);
     const __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.ln_cs ? (const void*)P.ln_cs : (const void*)P.wt,
                                                    P.ln_cs ? (size_t)P.N * 4 : 0);
@@ -458,7 +498,8 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const unsigned OOB = 0x80000000u;
   const size_t a1_bytes = (size_t)P.Hs * P.Ws * P.C1 * 2 * (P.M / HW);
   const size_t a2_bytes = P.p2 ? (size_t)P.Hs * P.Ws * P.C2 * 2 * (P.M / HW) : 0;
-  const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.wt, (size_t)P.N * P.K * 2);
+  const int smp = P.wt_bstride ? m0 / P.rows_per_batch : 0;     // per-sample weights: the tile lies inside one sample
+  const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.wt + (size_t)smp * P.wt_bstride, (size_t)P.N * P.K * 2);
   unsigned wvo[BN / 32];
 #pragma unroll
   for (int i = 0; i < BN / 32; ++i) {
@@ -510,7 +551,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   constexpr int PAR_LD = ((BN + 63) / 64) * 64;
   float* rs = reinterpret_cast<float*>(smem + 2 * STAGE);
   float* par = rs + 2 * BM;
-  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
+  stage_params<BN, PAR_LD>(P, par, n0, w, lane, smp);
   if (k_begin < nk) stage(0, k_begin);
   __syncthreads();
   int cur = 0;
@@ -548,7 +589,16 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
     ln_rows_to_lds(P, rs, m0, BM, t);
     __syncthreads();
   }
-  epilogue_units<TM, TN, MODE, PAR_LD, 2, T>(P, acc, m0 + wm * 64, n0, wn, lane, rs + 2 * (wm * 64), par, tile_n * 2 + wn);
+  // (the K loop ended with a barrier: the stage buffers are free for the per-channel sums of gn_group_reduce)
+  float* gsl = reinterpret_cast<float*>(smem);
+  epilogue_units<TM, TN, MODE, PAR_LD, 2, T>(P, acc, m0 + wm * 64, n0, wn, lane, rs + 2 * (wm * 64), par, tile_n * 2 + wn,
+                                             gsl + wm * (BN * 2));
+  if constexpr (MODE == 0) {
+    if (P.gp_out != nullptr && P.splits == 1) {
+      __syncthreads();
+      gn_group_reduce<BN, 2, BM>(P, gsl, m0, n0, t);
+    }
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -620,7 +670,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   const int HW = P.H * P.W;
   const int slot = lane & 7;
   const unsigned OOB = 0x80000000u;
-  int tile_m = 0, tile_n = 0, m0 = 0, n0 = 0;
+  int tile_m = 0, tile_n = 0, m0 = 0, n0 = 0, smp = 0;
   unsigned wvo[NB_FULL + 1];      // weight rows (fixed over K): instr i covers rows (i*NW + w)*8 + lane/8
   // gather state: per-row byte offset of the current (tap, source) segment, recomputed only when the tap or the concat
   // source changes
@@ -643,7 +693,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
     }
     seg_tap = -1; seg_src = -1;
-    rsB = uniform_rsrc(P.wt, (size_t)P.N * P.K * 2);
+    smp = P.wt_bstride ? m0 / P.rows_per_batch : 0;      // per-sample weights: the tile lies inside one sample
+    rsB = uniform_rsrc(P.wt + (size_t)smp * P.wt_bstride, (size_t)P.N * P.K * 2);
   };
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
   const int cpt = (P.C1 + P.C2) >> 6;
@@ -774,7 +825,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
     }
   };
   LR_STAMP(0);
-  stage_params<BN, PAR_LD>(P, par, n0, w, lane);
+  stage_params<BN, PAR_LD>(P, par, n0, w, lane, smp);
 #pragma unroll
   for (int sidx = 0; sidx < NPRO; ++sidx) stage(sidx, k_begin + sidx);
   if constexpr (!DB) stage_prepare(NSTAGE - 1, k_begin + NSTAGE - 1);
@@ -847,8 +898,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       __syncthreads();
     }
     LR_STAMP(4);
+    float* gsl = reinterpret_cast<float*>(smem);
+    const bool gp = MODE == 0 && P.gp_out != nullptr && P.splits == 1;      // block-uniform
+    if (gp) {      // every wave has left the K loop and its (zero-length) trailing LDS-DMA has landed: the stage buffers are free
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     epilogue_units<TM, TN, MODE, PAR_LD, WNW, T>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
-                                              tile_n * WNW + wn);
+                                              tile_n * WNW + wn, gsl + wm * (BN * 2));
+    if constexpr (MODE == 0) {
+      if (gp) {
+        __syncthreads();
+        gn_group_reduce<BN, WMW, BM2>(P, gsl, m0, n0, t);
+      }
+    }
     LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -886,7 +949,8 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
 // (sum, sumsq) of its 32 rows of the ROUNDED output -- the GroupNorm statistics of the consumer -- so a split-K producer
 // no longer needs the stand-alone statistics pass.
 #define RED_ROWS 32
-#define RED_GROUPS 16     // 8-channel groups per block: 128 channels x 32 rows = 512 threads; 1024 x 1280 outputs -> 320 blocks
+#define RED_GROUPS 20     // 8-channel groups per block: 160 channels x 32 rows = 640 threads; 1024 x 1280 outputs -> 256 blocks
+                          // (160 = a whole number of GroupNorm groups for C = 320 / 640 / 1280: the block also emits per-GROUP sums)
 template <typename T>
 __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(const GemmParams P) {
   // [value j of 16][row][group] with 16 floats of padding per j: the writes of a half-wave (16 groups x 2 rows) and the column
@@ -943,9 +1007,9 @@ __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(co
     }
     const uint4 pk = lr_pack8<T>(v);
     *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = pk;
-    if (P.gs_out) lr_unpack8<T>(pk, v);       // statistics of what the consumer will read
+    if (P.gs_out || P.gp_out) lr_unpack8<T>(pk, v);       // statistics of what the consumer will read
   }
-  if (P.gs_out) {      // block-uniform
+  if (P.gs_out || P.gp_out) {      // block-uniform; gs_store: write the per-channel form too
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float x = ok ? v[i] : 0.f;
@@ -953,13 +1017,31 @@ __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(co
     }
     __syncthreads();
     // RED_GROUPS channel groups x 16 values, summed over the 32 rows in a fixed order by the first 16 RED_GROUPS threads
+    float s = 0.f;
+    const int pr = threadIdx.x / RED_GROUPS, cg = threadIdx.x % RED_GROUPS;
     if (threadIdx.x < 16 * RED_GROUPS) {
-      const int pr = threadIdx.x >> 4, cg = threadIdx.x & 15;
-      float s = 0.f;
 #pragma unroll 8
       for (int k = 0; k < RED_ROWS; ++k) s += red[pr][k * RED_GROUPS + cg];
       const int nn = (blockIdx.x * RED_GROUPS + cg) * 8;
-      if (nn < P.N) P.gs_out[((size_t)blockIdx.y * P.N + nn) * 2 + pr] = s;      // [row block][N][2], (sum, sumsq) interleaved
+      if (nn < P.N && P.gs_store) P.gs_out[((size_t)blockIdx.y * P.N + nn) * 2 + pr] = s;      // [row block][N][2], (sum, sumsq) interleaved
+    }
+    if (P.gp_out) {      // per-group sums of the block's 160 channels over its 32 rows (block-uniform)
+      __syncthreads();
+      // value pr = 2 i + j of channel group cg = (sum | sumsq)[j] of channel 8 cg + i  ->  red[j][channel]
+      if (threadIdx.x < 16 * RED_GROUPS) red[pr & 1][cg * 8 + (pr >> 1)] = s;
+      __syncthreads();
+      const int gcg = P.gp_cg, t = threadIdx.x;
+      if (t < 2 * (8 * RED_GROUPS / gcg)) {
+        const int gl = t >> 1, j = t & 1;
+        const int g = (blockIdx.x * 8 * RED_GROUPS) / gcg + gl;
+        if (g < 32) {
+          float a = 0.f;
+          for (int c = 0; c < gcg; ++c) a += red[j][gl * gcg + c];
+          const int m0 = blockIdx.y * RED_ROWS;
+          const int smp = m0 / P.gp_hw, chunk = (m0 - smp * P.gp_hw) / RED_ROWS;
+          P.gp_out[(((size_t)smp * P.gp_chunks + chunk) * 32 + g) * 2 + j] = a;
+        }
+      }
     }
   }
 }
@@ -1085,6 +1167,30 @@ extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
   return tile_wave_rows(tm, tn, a->geglu == 1, a->pipe);
 }
 
+// chunks per sample of gn_group_out for this call (0: the plan cannot produce per-group sums -- tile width not a whole number
+// of groups, tiles straddling samples, GEGLU): rows per chunk = the tile's rows (32 behind a split-K reduce)
+static int gn_group_chunks(const lr_gemm_args* a, int tm, int tn, int splits) {
+  if (a->geglu || a->N % 32) return 0;
+  const int cg = a->N / 32;
+  const int hw = a->gn_hw > 0 ? a->gn_hw : a->H * a->W;
+  const int M = a->B * a->H * a->W;
+  if (hw <= 0 || M % hw) return 0;
+  const int rows = splits > 1 ? RED_ROWS : tm;
+  const int width = splits > 1 ? 8 * RED_GROUPS : tn;
+  if (width % cg || hw % rows) return 0;
+  return hw / rows;
+}
+
+extern "C" int lr_gemm_gn_group_chunks(const lr_gemm_args* a) {
+  if (!a) return 0;
+  int tn = a->tile_n, tm = a->tile_m;
+  const int M = a->B * a->H * a->W;
+  choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
+  return gn_group_chunks(a, tm, tn, splits);
+}
+
 extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
   if (!a) return 0;
   int tn = a->tile_n, tm = a->tile_m;
@@ -1175,6 +1281,20 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (P.bf16 && P.gelu) return LR_E_UNSUPPORTED;
   P.gs_out = a->gn_stats_out;
   if (P.gs_out && (P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
+  P.gs_store = P.gs_out != nullptr;
+  P.gp_out = a->gn_group_out; P.gp_cg = 1; P.gp_chunks = 0; P.gp_hw = 1;
+  if (P.gp_out) {
+    P.gp_chunks = gn_group_chunks(a, tm, tn, splits);
+    if (P.gp_chunks <= 0 || ((uintptr_t)P.gp_out & 7) || a->stats_out) return LR_E_ARG;
+    P.gp_cg = P.N / 32;
+    P.gp_hw = a->gn_hw > 0 ? a->gn_hw : a->H * a->W;
+  }
+  // per-sample weights (GroupNorm of the SpatialTransformer folded into proj_in): pointwise, one tile = one sample, no split
+  P.wt_bstride = a->wt_bstride; P.bias_bstride = a->bias_bstride;
+  if (P.wt_bstride) {
+    if (a->taps != 1 || splits > 1 || P.rows_per_batch % tm || P.wt_bstride < 0 || P.bias_bstride < 0 || (P.wt_bstride & 7)) return LR_E_ARG;
+    if ((int64_t)a->B * P.wt_bstride * 2 >= lim) return LR_E_UNSUPPORTED;
+  }
   P.st_out = a->stats_out;
   P.st_parts = ((P.N + tn - 1) / tn) * tile_wnw(tm, tn, P.geglu);
   if (P.st_out && (splits > 1 || ((uintptr_t)P.st_out & 7))) return LR_E_ARG;

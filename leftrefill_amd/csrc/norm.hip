@@ -359,6 +359,74 @@ extern "C" int lr_groupnorm_finalize(const float* p1, int C1, int R1, const floa
   return lr_launch_status();
 }
 
+// GroupNorm folded into the pointwise GEMM that consumes it (lr_gn_fold_weights_f16): per sample the normalisation is a per-channel
+// scale / shift, which goes into a per-sample copy of the weights.  grid = (N / FOLD_ROWS, B), block = 256 = 4 waves; prologue as in
+// gn_apply_kernel (mean / rstd of the sample's 32 groups from the chunk partials, fp64, fixed order), then one wave per weight row.
+#define FOLD_ROWS 16
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fold_weights_kernel(const float* __restrict__ gpart, int nchunks, int HW, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              const T* __restrict__ w, const float* __restrict__ bias, int N,
+                                                              T* __restrict__ w_out, float* __restrict__ bias_out) {
+  __shared__ float s_mean[32], s_rstd[32];
+  __shared__ float s_a[2048], s_m[2048];      // per channel: scale a = gamma rstd, and the group mean
+  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int Cg = C / 32;
+  if (t < 128) {
+    const int g = t >> 2, sub = t & 3;
+    double s = 0.0, q = 0.0;
+    const float* ps = gpart + ((size_t)b * nchunks * 32 + g) * 2;
+    for (int c = sub; c < nchunks; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+#pragma unroll
+    for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+    if (sub == 0) {
+      const double cnt = (double)HW * (double)Cg;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) { const int g = c / Cg; s_a[c] = gamma[c] * s_rstd[g]; s_m[c] = s_mean[g]; }
+  __syncthreads();
+  for (int r = wv; r < FOLD_ROWS; r += 4) {
+    const int n = blockIdx.x * FOLD_ROWS + r;
+    if (n >= N) break;
+    const T* src = w + (size_t)n * C;
+    T* dst = w_out + ((size_t)b * N + n) * C;
+    float acc_b = 0.f, acc_m = 0.f;      // sum_c W beta ; sum_c rounded(W a) mean
+    for (int c0 = lane * 8; c0 < C; c0 += 512) {
+      float f[8], o[8];
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(src + c0), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { o[i] = f[i] * s_a[c0 + i]; acc_b = fmaf(f[i], beta[c0 + i], acc_b); }
+      const uint4 pk = lr_pack8<T>(o);
+      *reinterpret_cast<uint4*>(dst + c0) = pk;
+      lr_unpack8<T>(pk, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc_m = fmaf(o[i], s_m[c0 + i], acc_m);
+    }
+    acc_b = lr_wave_sum(acc_b);
+    acc_m = lr_wave_sum(acc_m);
+    if (lane == 0) bias_out[(size_t)b * N + n] = (bias ? bias[n] : 0.f) + acc_b - acc_m;
+  }
+}
+
+template <typename T>
+static int lr_gn_fold_weights_t(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
+                                const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s) {
+  if (!gpart || !gamma || !beta || !w || !w_out || !bias_out || chunks <= 0 || B <= 0 || HW <= 0 || N <= 0) return LR_E_ARG;
+  if (C % 32 || C % 8 || C > 2048) return LR_E_ALIGN;
+  if (((uintptr_t)w | (uintptr_t)w_out) & 15) return LR_E_ALIGN;
+  hipLaunchKernelGGL(gn_fold_weights_kernel<T>, dim3((N + FOLD_ROWS - 1) / FOLD_ROWS, B), dim3(256), 0, (hipStream_t)s, gpart, chunks, HW, C,
+                     gamma, beta, eps, (const T*)w, bias, N, (T*)w_out, bias_out);
+  return lr_launch_status();
+}
+extern "C" int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps, const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s) { return lr_gn_fold_weights_t<f16>(gpart, chunks, B, HW, C, gamma, beta, eps, w, bias, N, w_out, bias_out, s); }
+extern "C" int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps, const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s) { return lr_gn_fold_weights_t<bf16>(gpart, chunks, B, HW, C, gamma, beta, eps, w, bias, N, w_out, bias_out, s); }
+
 template <typename T>
 static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                                 int nchunks_in, const float* gamma, const float* beta, float eps, int silu, lr_half* y,

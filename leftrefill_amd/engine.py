@@ -56,7 +56,8 @@ class Act:
     H: int
     W: int
     tok2: Optional[torch.Tensor] = None
-    gs: Optional[tuple] = None       # GroupNorm statistics of tok from its producer's epilogue: (partials, rows per block)
+    gs: Optional[tuple] = None       # GroupNorm statistics of tok from its producer's epilogue: (per-channel partials, rows per
+                                     # block, per-group partials | None, chunks per sample) -- see ops.gemm_conv(want_gn_stats=True)
     gs2: Optional[tuple] = None      # ... of tok2
 
     @property
@@ -241,7 +242,11 @@ def gn(act: Act, pn: PackedNorm, silu):
     HW = act.HW
     fused = (act.gs is not None and HW % act.gs[1] == 0 and gn_fuse_ok(act.tok)
              and (act.tok2 is None or (act.gs2 is not None and HW % act.gs2[1] == 0)))
-    if fused:
+    if fused and act.tok2 is None and act.gs[2] is not None:
+        # the producer reduced its tile to per-group sums: ONE launch (no finalize); a virtual concat keeps the per-channel partials
+        # + finalize path, its groups can straddle the two sources
+        y = ops.group_norm_groups(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.gs[2], act.gs[3])
+    elif fused:
         y = ops.group_norm_fused(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.gs, act.tok2, act.gs2)
     else:
         y = ops.group_norm(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.tok2)
@@ -390,8 +395,9 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None):
     post = (proj_out pieces, bias, x_in, want_gn): when the fused kernel runs, SpatialTransformer.proj_out (+ x_in) rides behind it in
     the same launch and the result is ("post", out, GroupNorm statistics | None) instead."""
     if post is not None and FFN_POST and ffn_fused(x, pt):
-        pw, pb, x_in, want_gn = post
-        y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, post=(pw, pb, x_in), want_gn_stats=want_gn)
+        pw, pb, x_in, want_gn, hw = post
+        y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, post=(pw, pb, x_in), want_gn_stats=want_gn,
+                          gn_hw=hw)
         return ("post",) + (y if want_gn else (y, None))
     if ffn_fused(x, pt):
         # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
@@ -449,6 +455,17 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
     return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
 
 
+# GroupNorm of the SpatialTransformer folded into proj_in through per-sample weights (levels where the activation is much larger
+# than N copies of the weights); LEFTREFILL_ST_GN_FOLD=0 keeps GroupNorm-apply -> proj_in
+ST_GN_FOLD = __import__("os").environ.get("LEFTREFILL_ST_GN_FOLD", "1") != "0"
+
+
+def st_gn_fold_ok(x_in, act: Act, gs_in, ps: PackedST):
+    C = x_in.shape[1]
+    return (ST_GN_FOLD and gs_in is not None and gs_in[2] is not None and fold_ok(x_in) and gn_fuse_ok(x_in)
+            and x_in.shape[0] >= 2 * act.N * C and act.HW % 256 == 0 and ps.proj_in.w.shape == (C, C))
+
+
 def st_dup_ok(ps: PackedST):
     return len(ps.blocks) > 0 and ps.blocks[0].view_num is None
 
@@ -457,10 +474,18 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
     """dup: `act` holds the first half of a CFG batch whose halves are still identical (ctx has all 2 * act.N contexts);
     the result is the full batch."""
     x_in = act.materialize()
+    gs_in = act.gs if act.tok2 is None else None
     with plan_batch_scale(2 if dup else 1):
-        h = gn(Act(x_in, act.N, act.H, act.W, gs=act.gs if act.tok2 is None else None), ps.norm, False).tok
-        ws = fold_ok(h)
-        h = linear(h, ps.proj_in, want_stats=ws)
+        if st_gn_fold_ok(x_in, act, gs_in, ps):
+            # Normalize (GroupNorm(32, eps 1e-6, affine), attention.py:399-404) folded into proj_in: per-sample weights from the
+            # producer's per-group sums; the GEMM reads the RAW x_in and the normalised tensor is never written
+            ws = True
+            wb, bb = ops.gn_fold_weights(gs_in[2], gs_in[3], act.N, act.HW, ps.norm.g, ps.norm.b, ps.norm.eps, ps.proj_in.w, ps.proj_in.b)
+            h = ops.gemm_conv(x_in, wb, B=act.N, H=1, W=act.HW, taps=1, bias=bb, per_sample=True, want_stats=True)
+        else:
+            h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
+            ws = fold_ok(h)
+            h = linear(h, ps.proj_in, want_stats=ws)
     h, st = h if ws else (h, None)
     if dup:
         assert st_dup_ok(ps)
@@ -470,12 +495,13 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
         last = i + 1 == len(ps.blocks)
-        post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0) if last and ps.proj_out_x is not None else None
+        post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW) if last and ps.proj_out_x is not None else None
         r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post)
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
             return Act(r[1], act.N, act.H, act.W, gs=r[2])
         h, st = r
-    y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want)
+    y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want,
+                      gn_hw=act.HW)
     y, gs = y if want else (y, None)
     return Act(y, act.N, act.H, act.W, gs=gs)
 

@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import FfnArgs, GemmArgs, XattnArgs
 
 GN_CHUNKS = 256
+# per-group GroupNorm partials from the producers' epilogues (no lr_groupnorm_finalize launch); LEFTREFILL_GN_GROUPS=0 keeps the
+# per-channel partials + finalize for every GroupNorm
+GN_GROUPS = os.environ.get("LEFTREFILL_GN_GROUPS", "1") != "0"
 
 # ---- tile plan of lr_gemm_conv_f16 ----------------------------------------------------------------------------------
 # The UNet has ~60 distinct static GEMM shapes.  Their (tile_m, tile_n, splits) come from an IN-TREE table
@@ -133,8 +136,8 @@ def group_norm_fused(x1, N, HW, gamma, beta, eps, silu, gs1, x2=None, gs2=None):
     _chk16(x1, "x1")
     C1 = x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
-    p1, r1 = gs1
-    p2, r2 = gs2 if x2 is not None else (None, 1)
+    p1, r1 = gs1[:2]
+    p2, r2 = gs2[:2] if x2 is not None else (None, 1)
     assert p1.shape == (N * HW // r1, C1, 2) and HW % r1 == 0
     if x2 is not None:
         _chk16(x2, "x2")
@@ -147,6 +150,34 @@ def group_norm_fused(x1, N, HW, gamma, beta, eps, silu, gs1, x2=None, gs2=None):
     _lib.check(_fn(lib, "lr_groupnorm_apply_n", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), 1, _p(gamma), _p(beta), float(eps),
                                         int(bool(silu)), _p(y), st), "groupnorm_apply_n")
     return y
+
+
+def group_norm_groups(x1, N, HW, gamma, beta, eps, silu, gp, chunks):
+    """GroupNorm(32)(+SiLU) of a single tensor whose per-GROUP (sum, sumsq) partials gp [N, chunks, 32, 2] came out of its producer's
+    epilogue (gemm_conv / ffn_block `want_gn_stats`): ONE launch, the apply kernel reduces the chunks in its prologue."""
+    lib = _lib.load()
+    _chk16(x1, "x1")
+    C1 = x1.shape[-1]
+    assert gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (N, chunks, 32, 2), (gp.shape, N, chunks)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C1
+    y = torch.empty(N * HW, C1, device=x1.device, dtype=x1.dtype)
+    _lib.check(_fn(lib, "lr_groupnorm_apply_n", x1.dtype)(_p(x1), C1, 0, 0, N, HW, _p(gp), chunks, _p(gamma), _p(beta), float(eps),
+                                                          int(bool(silu)), _p(y), _stream()), "groupnorm_apply_n")
+    return y
+
+
+def gn_fold_weights(gp, chunks, N, HW, gamma, beta, eps, w, bias):
+    """Per-sample copies of a pointwise layer's weights with GroupNorm(32, affine) folded in (lr_gn_fold_weights_f16):
+    w [Nout, C] 16-bit, bias [Nout] fp32 | None -> (w_b [N, Nout, C], bias_b [N, Nout] fp32); gp / chunks as in group_norm_groups."""
+    lib = _lib.load()
+    _chk16(w, "w")
+    Nout, C = w.shape
+    assert gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (N, chunks, 32, 2)
+    wb = torch.empty(N, Nout, C, device=w.device, dtype=w.dtype)
+    bb = torch.empty(N, Nout, device=w.device, dtype=torch.float32)
+    _lib.check(_fn(lib, "lr_gn_fold_weights_f16", w.dtype)(_p(gp), chunks, N, HW, C, _p(gamma), _p(beta), float(eps), _p(w), _p(bias), Nout,
+                                                           _p(wb), _p(bb), _stream()), "gn_fold_weights")
+    return wb, bb
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
@@ -184,14 +215,17 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
               resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, pipe=0, ln=None,
-              want_stats=False, want_gn_stats=False):
+              want_stats=False, want_gn_stats=False, gn_hw=0, per_sample=False):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
 
     ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
     are the gamma / beta folded weights, see lr_gemm_args).  want_stats: also return the per-row (sum, sumsq) partials of
     the output, [M, parts, 2] fp32 -- the `stats` a following LayerNorm-folded GEMM consumes; returns (out, stats).
     want_gn_stats: also return per-channel (sum, sumsq) over row blocks for the GroupNorm that consumes the output:
-    returns (out, (partials [M / R, N, 2] fp32, R)), or (out, None) when R does not divide H*W."""
+    returns (out, (partials [M / R, N, 2] fp32, R, gp, chunks)), or (out, None) when R does not divide the rows of a sample
+    (gn_hw, default H*W); gp [samples, chunks, 32, 2] = per-GROUP sums for a consumer that normalises this tensor alone
+    (group_norm_groups: no finalize launch), None when the plan cannot produce them.
+    per_sample: wt is [B, N, K] and bias [B, N] -- one weight set per sample (rows b*H*W .. of sample b), see ops.gn_fold_weights."""
     lib = _lib.load()
     _chk16(x1, "x1")
     _chk16(wt, "wt")
@@ -202,8 +236,10 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     if x2 is not None:
         _chk16(x2, "x2")
         C2 = x2.shape[-1]
-    Nw = wt.shape[0]
-    assert wt.shape[1] == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+    if per_sample:
+        assert wt.dim() == 3 and wt.shape[0] == B and taps == 1 and x2 is None and wt.is_contiguous()
+    Nw = wt.shape[-2]
+    assert wt.shape[-1] == taps * (C1 + C2), (wt.shape, taps, C1, C2)
     assert x1.shape[0] == B * Hs * Ws, (x1.shape, B, Hs, Ws)
     M = B * H * W
     n_out = Nw // 2 if geglu else Nw
@@ -216,7 +252,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.wt, a.N = _p(wt), Nw
     a.bias = _p(bias)
     if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() == Nw
+        assert bias.dtype == torch.float32 and bias.numel() == (Nw * B if per_sample else Nw)
     a.rowvec, a.ld_rowvec = _p(rowvec), (rowvec.stride(0) if rowvec is not None else 0)
     a.resid, a.ld_resid = _p(resid), (resid.stride(0) if resid is not None else 0)
     if resid is not None:
@@ -230,6 +266,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.pipe = pipe
     a.workspace, a.workspace_bytes = 0, 0
     a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
+    a.gn_group_out, a.gn_hw = 0, int(gn_hw)
+    a.wt_bstride, a.bias_bstride = (Nw * wt.shape[-1], Nw if bias is not None else 0) if per_sample else (0, 0)
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
     a.dtype = int(x1.dtype == torch.bfloat16)      # LR_DTYPE_F16 | LR_DTYPE_BF16
     if ln is not None:
@@ -240,7 +278,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     st = _stream()
     if tile_m == 0 and tile_n == 0 and splits == 0:
         scale = _PLAN_BATCH_SCALE[0]
-        key = tile_key(M * scale, Nw, wt.shape[1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
+        key = tile_key(M * scale, Nw, wt.shape[-1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
         if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
             a.B = B * scale
@@ -271,9 +309,13 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         lib.lr_gemm_plan(a, plan)
         a.splits = plan[2]                  # pinned: the row-block size of the statistics depends on it (32 behind split-K)
         rows = lib.lr_gemm_gn_rows(a)
-        if (H * W) % rows == 0:             # row blocks never straddle two samples
-            gstats = (torch.empty((M + rows - 1) // rows, n_out, 2, device=x1.device, dtype=torch.float32), rows)
+        hw = gn_hw or H * W
+        if hw % rows == 0:                  # row blocks never straddle two samples
+            chunks = lib.lr_gemm_gn_group_chunks(a) if GN_GROUPS else 0
+            gp = torch.empty(M // hw, chunks, 32, 2, device=x1.device, dtype=torch.float32) if chunks > 0 else None
+            gstats = (torch.empty((M + rows - 1) // rows, n_out, 2, device=x1.device, dtype=torch.float32), rows, gp, chunks)
             a.gn_stats_out = _p(gstats[0])
+            a.gn_group_out = _p(gp)
     ws = _workspace(lib, a, x1.device)
     _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
     if want_gn_stats:
@@ -468,7 +510,7 @@ def ffn_ok(M, C, H):
     return C == FFN_C and M % FFN_ROWS == 0 and H % 64 == 0 and 0 < H <= FFN_MAX_H
 
 
-def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, want_gn_stats=False):
+def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, want_gn_stats=False, gn_hw=0):
     """x + W2 (u * gelu(g)) + b2 with [u | g] = LayerNorm(x) W1^T + b1, in one launch (lr_ffn_block_f16).
     w1 / b1: LayerNorm-folded GEGLU projection in the interleaved [u16 | g16] row order (packing.pack_geglu / fold_layernorm);
     w2: second Linear as packing.pack_pieces ([H / 64, C, 64]).  post = (Wp pieces, bp, x_in): out = x3 Wp^T + bp + x_in as well
@@ -490,6 +532,7 @@ def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, 
     a.x, a.out, a.w1, a.b1, a.w2, a.b2, a.stats_out = _p(x), _p(out), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats)
     a.M, a.C, a.H, a.ln_eps = M, C, H, float(eps)
     a.post_w = a.post_b = a.post_resid = a.gn_stats_out = 0
+    a.gn_group_out, a.gn_hw = 0, 0
     gstats = None
     if post is not None:
         # (Wp pieces [5, C, 64], bp, x_in): out = (x + ff(LN x)) Wp^T + bp + x_in in the same launch (SpatialTransformer.proj_out)
@@ -499,7 +542,12 @@ def ffn_block(x, w1, b1, w2, b2, *, eps, want_stats=False, out=None, post=None, 
         assert pb_.dtype == torch.float32 and pb_.numel() == C
         a.post_w, a.post_b, a.post_resid = _p(pw_), _p(pb_), _p(pr_)
         if want_gn_stats:
-            gstats = (torch.empty(M // FFN_ROWS, C, 2, device=x.device, dtype=torch.float32), FFN_ROWS)
+            gp, chunks = None, 0
+            if GN_GROUPS and gn_hw and gn_hw % FFN_ROWS == 0 and M % gn_hw == 0:
+                chunks = gn_hw // FFN_ROWS
+                gp = torch.empty(M // gn_hw, chunks, 32, 2, device=x.device, dtype=torch.float32)
+                a.gn_group_out, a.gn_hw = _p(gp), gn_hw
+            gstats = (torch.empty(M // FFN_ROWS, C, 2, device=x.device, dtype=torch.float32), FFN_ROWS, gp, chunks)
             a.gn_stats_out = _p(gstats[0])
     else:
         assert not want_gn_stats

@@ -118,11 +118,18 @@ def test_ffn_block_with_fused_proj_out(M):
     ref = x_in + torch.nn.functional.linear(x3, wp, bp)
     wf, bf, _cs = packing.fold_layernorm(sd["f.net.0.proj.weight"], sd["f.net.0.proj.bias"], gamma, beta)
     perm = packing.geglu_perm(H)
-    out, (gs, rows) = ops.ffn_block(x.half().to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d),
-                                    packing.pack_pieces(sd["f.net.2.weight"]).to(d), sd["f.net.2.bias"].to(d), eps=1e-5,
-                                    post=(packing.pack_pieces(wp).to(d), bp.to(d), x_in.half().to(d)), want_gn_stats=True)
+    out, (gs, rows, gp, chunks) = ops.ffn_block(x.half().to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d),
+                                                packing.pack_pieces(sd["f.net.2.weight"]).to(d), sd["f.net.2.bias"].to(d), eps=1e-5,
+                                                post=(packing.pack_pieces(wp).to(d), bp.to(d), x_in.half().to(d)), want_gn_stats=True,
+                                                gn_hw=128 if M == 128 else 256)
     report(f"ffn+proj_out M{M}", out, ref, rtol=3e-3, atol=5e-3)
     assert rows == 128 and gs.shape == (M // 128, C, 2)
+    # per-group sums (10 channels per group) of every 128-row block, laid out [sample][chunk][32][2] for lr_groupnorm_apply_n
+    hw = 128 if M == 128 else 256
+    assert chunks == hw // 128 and gp.shape == (M // hw, chunks, 32, 2)
+    og = out.double().reshape(M // hw, chunks, 128, 32, C // 32)
+    torch.testing.assert_close(gp[..., 0].double(), og.sum((2, 4)), rtol=1e-5, atol=5e-3)
+    torch.testing.assert_close(gp[..., 1].double(), (og * og).sum((2, 4)), rtol=1e-5, atol=5e-3)
     o32 = out.float().reshape(M // 128, 128, C)
     torch.testing.assert_close(gs[:, :, 0], o32.sum(1), rtol=1e-5, atol=2e-3)
     torch.testing.assert_close(gs[:, :, 1], (o32 * o32).sum(1), rtol=1e-5, atol=2e-3)

@@ -388,10 +388,16 @@ def test_groupnorm_statistics_from_gemm_epilogue(tile):
         y, gs = ops.gemm_conv(to_tok(x), packing.pack_conv(w, cin_pad=Cin).to(d), B=N, H=H, W=W, taps=taps,
                               bias=packing.pack_bias(b).to(d), want_gn_stats=True, **kw)
         assert gs is not None
-        part, R = gs
+        part, R, gp, chunks = gs
         yf = y.float().reshape(N * H * W // R, R, Cout)
         assert torch.allclose(part[..., 0], yf.sum(1), rtol=1e-5, atol=2e-3), name
         assert torch.allclose(part[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=2e-3), name
+        if gp is not None:      # per-group sums of the tile's rows (lr_gemm_args.gn_group_out): chunk = row tile inside the sample
+            yg = y.double().reshape(N, chunks, H * W // chunks, 32, Cout // 32)
+            assert torch.allclose(gp[..., 0].double(), yg.sum((2, 4)), rtol=1e-5, atol=5e-3), name
+            assert torch.allclose(gp[..., 1].double(), (yg * yg).sum((2, 4)), rtol=1e-5, atol=5e-3), name
+        elif k == 0:
+            assert tn % (Cout // 32) != 0 or (H * W) % tm != 0, f"{name}: no group sums although the tile covers whole groups"
         outs.append((y, gs))
     (y1, g1), (y2, g2) = outs
     C = y1.shape[1] + y2.shape[1]
@@ -404,6 +410,10 @@ def test_groupnorm_statistics_from_gemm_epilogue(tile):
     ref1 = F.group_norm(from_tok(y1, N, H, W), 32, gam[:320], bet[:320], 1e-6)
     out1 = ops.group_norm_fused(y1, N, H * W, gam[:320].contiguous().to(d), bet[:320].contiguous().to(d), 1e-6, False, g1)
     report(name + " gn(single)", from_tok(out1, N, H, W), ref1)
+    if g1[2] is not None:       # the same GroupNorm straight from the producer's per-group sums: no finalize launch
+        out2 = ops.group_norm_groups(y1, N, H * W, gam[:320].contiguous().to(d), bet[:320].contiguous().to(d), 1e-6, False, g1[2], g1[3])
+        report(name + " gn(groups)", from_tok(out2, N, H, W), ref1)
+        assert (out2.float() - out1.float()).abs().max().item() <= 2e-3
 
 
 @pytest.mark.parametrize("M,C", [(10240, 320), (9000, 640)])
@@ -450,10 +460,14 @@ def test_groupnorm_statistics_from_splitk_reduce():
     for splits in (2, 3, 5):
         y, gs = ops.gemm_conv(to_tok(x), wp, B=N, H=H, W=W, taps=9, bias=bp, resid=to_tok(rs), want_gn_stats=True, splits=splits)
         assert gs is not None and gs[1] == 32
-        part, R = gs
+        part, R, gp, chunks = gs
         yf = y.float().reshape(N * H * W // R, R, Cout)
         assert torch.allclose(part[..., 0], yf.sum(1), rtol=1e-5, atol=2e-3)
         assert torch.allclose(part[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=2e-3)
+        assert gp is not None and chunks == H * W // 32      # the reduce kernel's 32-row x 160-channel blocks cover whole groups of 10
+        yg = y.double().reshape(N, chunks, 32, 32, Cout // 32)
+        assert torch.allclose(gp[..., 0].double(), yg.sum((2, 4)), rtol=1e-5, atol=5e-3)
+        assert torch.allclose(gp[..., 1].double(), (yg * yg).sum((2, 4)), rtol=1e-5, atol=5e-3)
         y1 = ops.gemm_conv(to_tok(x), wp, B=N, H=H, W=W, taps=9, bias=bp, resid=to_tok(rs), splits=splits)
         assert torch.equal(y, y1)
         report(f"splitk{splits} conv", from_tok(y, N, H, W), F.conv2d(x, w, b, padding=1) + rs)
@@ -461,6 +475,8 @@ def test_groupnorm_statistics_from_splitk_reduce():
         bet = 0.2 * G.T("gns.be", (Cout,))
         out = ops.group_norm_fused(y, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gs)
         report(f"splitk{splits} gn", from_tok(out, N, H, W), F.silu(F.group_norm(from_tok(y, N, H, W), 32, gam, bet, 1e-5)))
+        out = ops.group_norm_groups(y, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gp, chunks)
+        report(f"splitk{splits} gn(groups)", from_tok(out, N, H, W), F.silu(F.group_norm(from_tok(y, N, H, W), 32, gam, bet, 1e-5)))
     # ragged M and N (tails of the reduce kernel's 32-row x 256-channel blocks), rowvec, no statistics
     M, K, Nn = 300, 2560, 328
     a = h16(G.T("gns.a", (M, K)))
@@ -468,6 +484,78 @@ def test_groupnorm_statistics_from_splitk_reduce():
     rv = h16(G.T("gns.rv", (1, Nn)))
     y2 = ops.gemm_conv(a.half().to(d), w2.half().to(d), B=1, H=1, W=M, taps=1, rowvec=rv.half().to(d), splits=4)
     report("splitk ragged", y2, F.linear(a, w2) + rv)
+
+
+@pytest.mark.parametrize("C,HW,tile", [(320, 2048, (256, 320)), (320, 512, (256, 160)), (640, 512, (256, 160)), (640, 256, (128, 160)),
+                                       (1280, 512, (128, 160, 4)), (1280, 256, (256, 320)), (640, 512, (256, 128))],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_groupnorm_group_sums_at_unet_widths(C, HW, tile):
+    """lr_gemm_args.gn_group_out at the UNet's widths (10 / 20 / 40 channels per group) for every tile family that produces GroupNorm
+    inputs, several row tiles per sample: the per-group partials equal the sums over the stored tensor, and the one-launch GroupNorm
+    (no finalize) matches F.group_norm of it.  A tile whose width is not a whole number of groups reports none (fallback path)."""
+    from leftrefill_amd import ops
+    d = dev()
+    N = 3
+    M = N * HW
+    x = h16(G.T(f"gng.{C}.{HW}.x", (M, 320)) + 0.3)
+    w = h16(torch.from_numpy(weights.fill_like(f"gng.{C}.w", (C, 320))) * 2.0)
+    b = torch.from_numpy(weights.fill_like(f"gng.{C}.b", (C,))) + 0.5
+    y, gs = ops.gemm_conv(x.half().to(d), w.half().to(d), B=N, H=1, W=HW, taps=1, bias=b.to(d), want_gn_stats=True, splits=1, **tile_kw(tile))
+    part, R, gp, chunks = gs
+    if tile[1] % (C // 32):
+        assert gp is None
+        return
+    assert gp is not None and chunks == HW // tile[0]
+    yg = y.double().reshape(N, chunks, HW // chunks, 32, C // 32)
+    assert torch.allclose(gp[..., 0].double(), yg.sum((2, 4)), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(gp[..., 1].double(), (yg * yg).sum((2, 4)), rtol=1e-5, atol=1e-2)
+    gam = 1.0 + 0.3 * G.T(f"gng.{C}.g", (C,))
+    bet = 0.2 * G.T(f"gng.{C}.be", (C,))
+    ref = F.silu(F.group_norm(y.float().cpu().reshape(N, HW, C).permute(0, 2, 1), 32, gam, bet, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    out = ops.group_norm_groups(y, N, HW, gam.to(d), bet.to(d), 1e-5, True, gp, chunks)
+    report(f"gn(groups) C{C} HW{HW} {tile}", out, ref)
+    assert torch.equal(out, ops.group_norm_groups(y, N, HW, gam.to(d), bet.to(d), 1e-5, True, gp, chunks))
+
+
+@pytest.mark.parametrize("C,HW", [(320, 2048), (640, 512), (320, 256)])
+def test_groupnorm_folded_into_pointwise_gemm(C, HW):
+    """SpatialTransformer.norm folded into proj_in (lr_gn_fold_weights_f16 + lr_gemm_args.wt_bstride, attention.py:399-408): the GEMM on
+    the RAW activation with per-sample weights equals proj_in(GroupNorm(x)) in fp32 on the same fp16 inputs; samples with very
+    different statistics (a constant offset of 30 on one of them, |mean| >> std) keep the tolerance (the mean term is formed with the
+    rounded weights)."""
+    from leftrefill_amd import ops
+    d = dev()
+    N = 3
+    M = N * HW
+    scale = torch.tensor([1.0, 0.05, 4.0]).reshape(N, 1, 1)
+    shift = torch.tensor([0.2, 30.0, -3.0]).reshape(N, 1, 1)
+    x0 = h16(G.T(f"gnfold.{C}.x0", (M, 320)))
+    w0 = h16(torch.from_numpy(weights.fill_like(f"gnfold.{C}.w0", (C, 320))) * 2.0)
+    # producer: a linear layer whose output is the tensor to be normalised; its epilogue supplies the per-group sums
+    y, gs = ops.gemm_conv(x0.half().to(d), w0.half().to(d), B=N, H=1, W=HW, taps=1, want_gn_stats=True, splits=1)
+    y = (y.float().reshape(N, HW, C).cpu() * scale + shift).half()            # re-scaled per sample on the host ...
+    yd = y.reshape(M, C).to(d)
+    one = torch.eye(C).half().to(d)                                            # ... and passed through an identity GEMM for its sums
+    y2, gs = ops.gemm_conv(yd, one, B=N, H=1, W=HW, taps=1, want_gn_stats=True, splits=1)
+    assert torch.equal(y2, yd) and gs[2] is not None
+    gam = 1.0 + 0.3 * G.T(f"gnfold.{C}.g", (C,))
+    bet = 0.2 * G.T(f"gnfold.{C}.be", (C,))
+    w = h16(torch.from_numpy(weights.fill_like(f"gnfold.{C}.w", (C, C))))
+    b = torch.from_numpy(weights.fill_like(f"gnfold.{C}.b", (C,)))
+    xn = F.group_norm(y.float().reshape(N, HW, C).permute(0, 2, 1), 32, gam, bet, 1e-6).permute(0, 2, 1).reshape(M, C)
+    ref = F.linear(xn, w, b)
+    wb, bb = ops.gn_fold_weights(gs[2], gs[3], N, HW, gam.to(d), bet.to(d), 1e-6, w.half().to(d), b.to(d))
+    assert wb.shape == (N, C, C) and bb.shape == (N, C)
+    out, st = ops.gemm_conv(yd, wb, B=N, H=1, W=HW, taps=1, bias=bb, per_sample=True, want_stats=True)
+    # composite: the unfused path rounds the normalised tensor to fp16 before the GEMM, the fold rounds W a instead
+    report(f"gn-fold C{C} HW{HW}", out, ref, rtol=3e-3, atol=4e-3)
+    unf = ops.gemm_conv(ops.group_norm_groups(yd, N, HW, gam.to(d), bet.to(d), 1e-6, False, gs[2], gs[3]), w.half().to(d), B=1, H=1, W=M,
+                        taps=1, bias=b.to(d))
+    e_f, e_u = (out.float().cpu() - ref).norm() / ref.norm(), (unf.float().cpu() - ref).norm() / ref.norm()
+    print(f"[gn-fold C{C}] rel-L2 folded {e_f:.3e} unfused {e_u:.3e}")
+    assert e_f <= 2.0 * e_u + 1e-4
+    of = out.float()
+    assert torch.allclose(st[:, :, 0].sum(1), of.sum(1), rtol=1e-4, atol=2e-2)
 
 
 def test_tile_plan_is_static_and_tiles_agree_bitwise():
