@@ -38,12 +38,110 @@ struct AttnParams {
   float* lse;  // optional [B][heads][Nq]: log2-domain log-sum-exp m*c + log2(l) (saved for the backward), or NULL
 };
 
+// Online softmax of one 32-query block of a wave over one 64-key tile: S^T accumulators -> P^T (16-bit, the PV B operand), running
+// max / sum, deferred rescale of O (only when some row's max grew by more than 2^8: P stays <= 256).  One query per lane; the
+// partner lane ^ 32 holds the other half of the keys.
+// FOLD = false: sacc holds raw q.k, m_run the raw running max (starts at -inf), p = exp2(c (s - m)).
+// FOLD = true : Q was pre-multiplied by c = scale log2(e) and the accumulators were INITIALISED with -m_run (`minit`, the C operand of
+//               the first QK^T MFMA), so sacc already is the exp2 argument: no per-element multiply-subtract (64 of the ~185
+//               non-transcendental VALU instructions of a tile; the kernel is VALU-bound at d_head = 64).  m_run starts at 0 and the
+//               first tile always takes the rescale path (sets m_run to the tile's row max).  Q's extra fp16 rounding moves a logit
+//               by <= 2^-12 relative per term -- far inside the fp16 rounding of P; the training forward (log-sum-exp output for the
+//               backward, which recomputes P from unscaled q, k) keeps FOLD = false.
+template <typename T, bool FOLD>
+__device__ __forceinline__ void softmax_block(f32x16 (&sacc)[2], f32x16 (&oacc)[2], vec8<T> (&pf)[2][2], float& m_run, float& l_run,
+                                              f32x16& minit, const float c, const bool first) {
+  float mx = sacc[0][0];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+  {  // max across the two half-waves with one VALU lane swap (v_permlane32_swap) instead of an LDS round trip
+    const unsigned u = __builtin_bit_cast(unsigned, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+  }
+  if constexpr (FOLD) {
+    if (first || !__all(mx <= 8.0f)) {
+      const float d = first ? mx : fmaxf(mx, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d);
+      m_run += d;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] -= d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(sacc[kb][r]), p1 = __builtin_amdgcn_exp2f(sacc[kb][r + 1]);
+        ps += p0 + p1;
+        pf[kb][r >> 3][r & 7] = (T)p0;
+        pf[kb][r >> 3][(r & 7) + 1] = (T)p1;
+      }
+    l_run += ps;
+  } else {
+    if (!__all((mx - m_run) * c <= 8.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two values per VALU issue) for the exp2 argument and the row sum
+    const f32x2 c2 = {c, c};
+    const f32x2 mc2 = {m_run * c, m_run * c};
+    f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {sacc[kb][r], sacc[kb][r + 1]};
+        const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
+        const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        ps2 += pv;
+        pf[kb][r >> 3][r & 7] = (T)pv[0];
+        pf[kb][r >> 3][(r & 7) + 1] = (T)pv[1];
+      }
+    l_run += ps2[0] + ps2[1];
+  }
+}
+
+// Q^T fragment of a query row, pre-multiplied by c when the scale is folded into the operand (softmax_block<FOLD = true>)
+template <typename T, bool FOLD>
+__device__ __forceinline__ vec8<T> load_q(const T* p, const float c) {
+  vec8<T> q = *reinterpret_cast<const vec8<T>*>(p);
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (T)((float)q[i] * c);
+  }
+  return q;
+}
+
 // VT = true: P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below):
 // the V tile then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment
 // is ONE ds_read_b128.
 // CAUSAL = true: key j is visible to query i only if j <= i (the text tower's attn_mask); every tile takes the masked path.
-template <typename T, bool VT, bool CAUSAL = false>
+// EXACT = true: unscaled Q, softmax_block<FOLD = false> (the training forward with its log-sum-exp output).
+template <typename T, bool VT, bool CAUSAL = false, bool EXACT = false>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams<T> P) {
+#ifdef LR_ATTN_NOFOLD      // developer A/B build (tools/build_variant.sh nofold -DLR_ATTN_NOFOLD)
+  constexpr bool FOLD = false;
+#else
+  constexpr bool FOLD = !EXACT && !CAUSAL;      // (the causal text-tower instance would need 272 registers with the fold: kept exact)
+#endif
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KB * 128 + 2 * 64 * VT_PITCH];
   char* Ksm = smem;
   char* Vsm = smem + 2 * ATT_KB * 128;
@@ -75,7 +173,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     const int qc = min(qrow[qb], P.Nq - 1);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
-      qf[qb][s4] = *reinterpret_cast<const vec8<T>*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
+      qf[qb][s4] = load_q<T, FOLD>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8, P.c);
   }
 
   const int ntiles = (P.Nkv + ATT_KB - 1) / ATT_KB;
@@ -134,8 +232,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[2] = {FOLD ? 0.f : -INFINITY, FOLD ? 0.f : -INFINITY}, l_run[2] = {0.f, 0.f};
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 minit[2] = {zero16, zero16};      // FOLD: -m_run of the query, the C operand of the first QK^T MFMA of every tile
 
   stage_k(0, 0);
   if constexpr (VT) {
@@ -174,7 +273,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
         const vec8<T> kf = *reinterpret_cast<const vec8<T>*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          sacc[qb][kb] = lr_mfma32(kf, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][kb]);
+          sacc[qb][kb] = lr_mfma32(kf, qf[qb][s4], s4 == 0 ? (FOLD ? minit[qb] : zero16) : sacc[qb][kb]);
       }
 
     vec8<T> pf[2][2][2];
@@ -190,45 +289,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
             if (key >= P.Nkv || (CAUSAL && key > qrow[qb])) sacc[qb][kb][r] = -INFINITY;
           }
       }
-      // ---- online softmax, one query per lane (partner lane ^ 32 holds the other half of the keys).  The running max
-      // is only raised (and O, l rescaled) when some row's max grew by more than 2^8 in the exp2 domain: P stays
-      // <= 256 and the common path skips 32 accumulator multiplies per lane.  m_run starts at -inf.
-      float mx = sacc[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
-      {  // max across the two half-waves with one VALU lane swap (v_permlane32_swap) instead of an LDS round trip
-        const unsigned u = __builtin_bit_cast(unsigned, mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-      }
-      if (!__all((mx - m_run[qb]) * P.c <= 8.0f)) {
-        const float m_new = fmaxf(m_run[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * P.c);
-        m_run[qb] = m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
-      }
-      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two values per VALU issue) for the exp2 argument and the row sum
-      const f32x2 c2 = {P.c, P.c};
-      const f32x2 mc2 = {m_run[qb] * P.c, m_run[qb] * P.c};
-      f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 sv = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
-          const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
-          const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          ps2 += pv;
-          pf[qb][kb][r >> 3][r & 7] = (T)pv[0];
-          pf[qb][kb][r >> 3][(r & 7) + 1] = (T)pv[1];
-        }
-      l_run[qb] += ps2[0] + ps2[1];
+      softmax_block<T, FOLD>(sacc[qb], oacc[qb], pf[qb], m_run[qb], l_run[qb], minit[qb], P.c, tile == 0);
     }
 
     // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; k-slot (hi*8 + jj) of MFMA (kb, tt) is key
@@ -276,7 +337,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     }
     const float inv = 1.0f / lt;
     if (P.lse && hi == 0 && qrow[qb] < P.Nq)
-      P.lse[((size_t)b * P.heads + h) * P.Nq + qrow[qb]] = fmaf(m_run[qb], P.c, __builtin_amdgcn_logf(lt));
+      P.lse[((size_t)b * P.heads + h) * P.Nq + qrow[qb]] = (FOLD ? m_run[qb] : m_run[qb] * P.c) + __builtin_amdgcn_logf(lt);
     // The two half-waves of a query (lane, lane ^ 32) hold the two 4-channel halves of every 8-channel group: one
     // v_permlane32_swap per dword hands group g to the lower and group g + 1 to the upper half-wave, so each lane stores
     // 16 contiguous bytes (8 x dwordx4 per lane instead of 16 x dwordx2: the store tail is issue-bound, and it is most of
@@ -360,7 +421,7 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
     const int qc = min(qrow[qb], P.Nq - 1);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
-      qf[qb][s4] = *reinterpret_cast<const vec8<T>*>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8);
+      qf[qb][s4] = load_q<T, true>(qp + (size_t)qc * P.ldq + s4 * 16 + hi * 8, P.c);
   }
   const int T_ = P.Nkv / ATT_KB;
 
@@ -385,8 +446,11 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
       for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
   float m_run[NQB], l_run[NQB];
 #pragma unroll
-  for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+  for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = 0.f; l_run[qb] = 0.f; }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 minit[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) minit[qb] = zero16;
   f32x16 sacc[NQB][2];
   vec8<T> pf[NQB][2][2];
 
@@ -420,8 +484,8 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
       const int s4 = step - 4;
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb) {
-        sacc[qb][0] = lr_mfma32(f0, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][0]);
-        sacc[qb][1] = lr_mfma32(f1, qf[qb][s4], s4 == 0 ? zero16 : sacc[qb][1]);
+        sacc[qb][0] = lr_mfma32(f0, qf[qb][s4], s4 == 0 ? minit[qb] : sacc[qb][0]);
+        sacc[qb][1] = lr_mfma32(f1, qf[qb][s4], s4 == 0 ? minit[qb] : sacc[qb][1]);
       }
     }
   };
@@ -455,45 +519,10 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
   using IC4 = std::integral_constant<int, 4>;
   using IC8 = std::integral_constant<int, 8>;
   // ---- softmax segment: S^T(j) -> P^T(j) (fp16 / bf16, the PV B-operand), running max / sum, deferred rescale of O
-  auto softmax_segment = [&]() {
+  auto softmax_segment = [&](const bool first) {
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-      float mx = sacc[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
-      {
-        const unsigned u = __builtin_bit_cast(unsigned, mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-      }
-      if (!__all((mx - m_run[qb]) * P.c <= 8.0f)) {
-        const float m_new = fmaxf(m_run[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * P.c);
-        m_run[qb] = m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
-      }
-      const f32x2 c2 = {P.c, P.c};
-      const f32x2 mc2 = {m_run[qb] * P.c, m_run[qb] * P.c};
-      f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 sv = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
-          const f32x2 a = __builtin_elementwise_fma(sv, c2, -mc2);
-          const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          ps2 += pv;
-          pf[qb][kb][r >> 3][r & 7] = (T)pv[0];
-          pf[qb][kb][r >> 3][(r & 7) + 1] = (T)pv[1];
-        }
-      l_run[qb] += ps2[0] + ps2[1];
-    }
+    for (int qb = 0; qb < NQB; ++qb)
+      softmax_block<T, true>(sacc[qb], oacc[qb], pf[qb], m_run[qb], l_run[qb], minit[qb], P.c, first);
   };
 
   // phase ends: `mid` keeps the LDS-DMA of the next stage in flight, `end` retires it (it is first read in the next iteration)
@@ -516,11 +545,11 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
   if (grp == 0) {
     if (T_ > 1) stage(1);
     matrix_segment(IC4{}, IC8{}, 0, 0); mid();
-    softmax_segment(); end();
+    softmax_segment(true); end();
     for (int j = 1; j < T_; ++j) {
       if (j + 1 < T_) stage(j + 1);
       matrix_segment(IC0{}, IC8{}, j - 1, j); mid();
-      softmax_segment(); end();
+      softmax_segment(false); end();
     }
     matrix_segment(IC0{}, IC4{}, T_ - 1, 0); mid();
     end();
@@ -530,10 +559,10 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
     matrix_segment(IC4{}, IC8{}, 0, 0); end();
     for (int j = 1; j < T_; ++j) {
       if (j + 1 < T_) stage(j + 1);
-      softmax_segment(); mid();
+      softmax_segment(j == 1); mid();
       matrix_segment(IC0{}, IC8{}, j - 1, j); end();
     }
-    softmax_segment(); mid();
+    softmax_segment(T_ == 1); mid();
     matrix_segment(IC0{}, IC4{}, T_ - 1, 0); end();
   }
 
@@ -606,7 +635,10 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
     }
     return lr_launch_status();
   }
-  if (vt) hipLaunchKernelGGL((attention_kernel<T, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  if (lse) {      // training forward: exact scale handling, the backward recomputes P from the unscaled operands and this log-sum-exp
+    if (vt) return LR_E_UNSUPPORTED;
+    hipLaunchKernelGGL((attention_kernel<T, false, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  } else if (vt) hipLaunchKernelGGL((attention_kernel<T, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   else hipLaunchKernelGGL((attention_kernel<T, false>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }

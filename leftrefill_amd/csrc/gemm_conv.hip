@@ -595,7 +595,8 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
                                              gsl + wm * (BN * 2));
   if constexpr (MODE == 0) {
     if (P.gp_out != nullptr && P.splits == 1) {
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       gn_group_reduce<BN, 2, BM>(P, gsl, m0, n0, t);
     }
   }
@@ -907,8 +908,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
     epilogue_units<TM, TN, MODE, PAR_LD, WNW, T>(P, acc, m0 + wm * (TM * 16), n0, wn, lane, rs + 2 * (wm * TM * 16), par,
                                               tile_n * WNW + wn, gsl + wm * (BN * 2));
     if constexpr (MODE == 0) {
-      if (gp) {
-        __syncthreads();
+      if (gp) {      // only the LDS writes of the per-channel sums have to be visible: the epilogue's global stores stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         gn_group_reduce<BN, WMW, BM2>(P, gsl, m0, n0, t);
       }
     }

@@ -362,21 +362,22 @@ extern "C" int lr_groupnorm_finalize(const float* p1, int C1, int R1, const floa
 // GroupNorm folded into the pointwise GEMM that consumes it (lr_gn_fold_weights_f16): per sample the normalisation is a per-channel
 // scale / shift, which goes into a per-sample copy of the weights.  grid = (N / FOLD_ROWS, B), block = 256 = 4 waves; prologue as in
 // gn_apply_kernel (mean / rstd of the sample's 32 groups from the chunk partials, fp64, fixed order), then one wave per weight row.
-#define FOLD_ROWS 16
+#define FOLD_ROWS 4      // one weight row per wave: the row work is a dependent load -> scale -> store -> wave-reduce chain
 template <typename T>
 __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const float* __restrict__ gpart, int nchunks, int HW, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                               const T* __restrict__ w, const float* __restrict__ bias, int N,
                                                               T* __restrict__ w_out, float* __restrict__ bias_out) {
   __shared__ float s_mean[32], s_rstd[32];
-  __shared__ float s_a[2048], s_m[2048];      // per channel: scale a = gamma rstd, and the group mean
+  __shared__ float s_a[2048], s_m[2048], s_b[2048];      // per channel: scale a = gamma rstd, the group mean, beta
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int Cg = C / 32;
   if (t < 128) {
     const int g = t >> 2, sub = t & 3;
     double s = 0.0, q = 0.0;
     const float* ps = gpart + ((size_t)b * nchunks * 32 + g) * 2;
-    for (int c = sub; c < nchunks; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+#pragma unroll 8
+    for (int c = sub; c < nchunks; c += 4) { const float2 v = *reinterpret_cast<const float2*>(ps + c * 64); s += (double)v.x; q += (double)v.y; }
 #pragma unroll
     for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
     if (sub == 0) {
@@ -388,20 +389,24 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const float* __res
       s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
     }
   }
+  // this wave's weight row is requested before the statistics prologue (its latency hides under it)
+  const int n = blockIdx.x * FOLD_ROWS + wv;
+  const bool have = n < N && lane * 8 < C;
+  uint4 w0 = make_uint4(0, 0, 0, 0);
+  if (have) w0 = *reinterpret_cast<const uint4*>(w + (size_t)n * C + lane * 8);
   __syncthreads();
-  for (int c = t; c < C; c += 256) { const int g = c / Cg; s_a[c] = gamma[c] * s_rstd[g]; s_m[c] = s_mean[g]; }
+  for (int c = t; c < C; c += 256) { const int g = c / Cg; s_a[c] = gamma[c] * s_rstd[g]; s_m[c] = s_mean[g]; s_b[c] = beta[c]; }
   __syncthreads();
   for (int r = wv; r < FOLD_ROWS; r += 4) {
-    const int n = blockIdx.x * FOLD_ROWS + r;
     if (n >= N) break;
     const T* src = w + (size_t)n * C;
     T* dst = w_out + ((size_t)b * N + n) * C;
     float acc_b = 0.f, acc_m = 0.f;      // sum_c W beta ; sum_c rounded(W a) mean
     for (int c0 = lane * 8; c0 < C; c0 += 512) {
       float f[8], o[8];
-      lr_unpack8<T>(*reinterpret_cast<const uint4*>(src + c0), f);
+      lr_unpack8<T>(c0 == lane * 8 ? w0 : *reinterpret_cast<const uint4*>(src + c0), f);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { o[i] = f[i] * s_a[c0 + i]; acc_b = fmaf(f[i], beta[c0 + i], acc_b); }
+      for (int i = 0; i < 8; ++i) { o[i] = f[i] * s_a[c0 + i]; acc_b = fmaf(f[i], s_b[c0 + i], acc_b); }
       const uint4 pk = lr_pack8<T>(o);
       *reinterpret_cast<uint4*>(dst + c0) = pk;
       lr_unpack8<T>(pk, o);

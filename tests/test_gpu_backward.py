@@ -166,7 +166,9 @@ def test_attention_backward(B, heads, Nq, Nkv):
     o = T.attention(qd, kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, 0.125)
     with torch.no_grad():
         o_plain = ops.attention(qd.detach(), kv.detach()[:, :C], kv.detach()[:, C:], B, heads, Nq, Nkv, 0.125)
-    assert torch.equal(o.detach(), o_plain)
+    # the training forward keeps the scale outside the QK^T operands (the backward recomputes P from the unscaled q, k and the saved
+    # log-sum-exp); the inference kernel folds scale * log2(e) into Q: same result to fp16 rounding, not bit for bit
+    assert (o.detach().float() - o_plain.float()).abs().max().item() <= 2e-3
     o.backward(do.reshape(B * Nq, C).half().to(d))
     check(tag + " dq", qd.grad.reshape(B, Nq, C), qr.grad)
     check(tag + " dk", kv.grad[:, :C].reshape(B, Nkv, C), kr.grad)

@@ -532,11 +532,12 @@ def test_groupnorm_folded_into_pointwise_gemm(C, HW):
     x0 = h16(G.T(f"gnfold.{C}.x0", (M, 320)))
     w0 = h16(torch.from_numpy(weights.fill_like(f"gnfold.{C}.w0", (C, 320))) * 2.0)
     # producer: a linear layer whose output is the tensor to be normalised; its epilogue supplies the per-group sums
-    y, gs = ops.gemm_conv(x0.half().to(d), w0.half().to(d), B=N, H=1, W=HW, taps=1, want_gn_stats=True, splits=1)
+    tile = dict(tile_m=256, tile_n=320 if C == 320 else 160)                   # a tile that covers whole groups (10 / 20 channels)
+    y = ops.gemm_conv(x0.half().to(d), w0.half().to(d), B=N, H=1, W=HW, taps=1, splits=1)
     y = (y.float().reshape(N, HW, C).cpu() * scale + shift).half()            # re-scaled per sample on the host ...
     yd = y.reshape(M, C).to(d)
     one = torch.eye(C).half().to(d)                                            # ... and passed through an identity GEMM for its sums
-    y2, gs = ops.gemm_conv(yd, one, B=N, H=1, W=HW, taps=1, want_gn_stats=True, splits=1)
+    y2, gs = ops.gemm_conv(yd, one, B=N, H=1, W=HW, taps=1, want_gn_stats=True, splits=1, **tile)
     assert torch.equal(y2, yd) and gs[2] is not None
     gam = 1.0 + 0.3 * G.T(f"gnfold.{C}.g", (C,))
     bet = 0.2 * G.T(f"gnfold.{C}.be", (C,))
@@ -726,7 +727,8 @@ def test_attention_pingpong_kernel_matches_reference_kernel(B, heads, Nq, Nkv):
     for mode in ("2", "3", "1"):
         assert torch.equal(outs[mode], outs["0"]), f"LR_ATTN_PP={mode} differs from attention_kernel"
     ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))
-    report(f"attention pp B{B} h{heads} {Nq}x{Nkv}", outs["1"].reshape(B, Nq, C), ref, atol=4e-3)
+    # rows whose max jumped carry P up to 2^8 in fp16 until the deferred rescale: a few times the plain error on those rows
+    report(f"attention pp B{B} h{heads} {Nq}x{Nkv}", outs["1"].reshape(B, Nq, C), ref, atol=8e-3)
 
 
 def test_mv_gather_scatter():

@@ -25,7 +25,7 @@ for name, B, heads, Nq, Nkv in SHAPES:
         sets.append((qkv, vt, torch.empty(B * Nq, C, device=dev, dtype=torch.float16)))
     res = {}
     for r in range(rounds):
-        for mode in ("0", "2", "3", "1"):
+        for mode in os.environ.get("LR_BENCH_MODES", "0,2,3,1").split(","):
             os.environ["LR_ATTN_PP"] = mode
             f = lambda i: ops.attention(sets[i % 3][0][:, :C], sets[i % 3][0][:, C:2 * C], sets[i % 3][0][:, 2 * C:], B, heads, Nq, Nkv,
                                         0.125, out=sets[i % 3][2], vt=sets[i % 3][1])
