@@ -334,10 +334,9 @@ static int lr_attention_bwd_t(const lr_attn_bwd_args* a, lr_stream_t s) {
   if (rc) return rc;
   P.ntile_blocks = (a->Nkv + 127) / 128;
   const int dkv_smem = 2 * 4 * AB_TILE * 128 + 4 * AB_TILE * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (lr_attr_needed(&attr_done)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), dkv_smem, st, P);
   return lr_launch_status();

@@ -23,6 +23,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // translation unit (no relocatable device code needed).
 static __device__ uint4 lr_zero_page[16];
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one bit per device ordinal records where
+// it has been set (a process that launches on a second GPU would otherwise fail there: ADVICE r3).
+static inline bool lr_attr_needed(unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*done & bit) return false;
+  *done |= bit;
+  return true;
+}
+
 static inline int lr_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -442,11 +442,10 @@ static int ffn_block_t(const lr_ffn_args* a, lr_stream_t s) {
     if (a->gn_hw <= 0 || a->gn_hw % FF_ROWS || a->M % a->gn_hw || ((uintptr_t)P.gp_out & 7)) return LR_E_ARG;
     P.gp_hw = a->gn_hw; P.gp_chunks = a->gn_hw / FF_ROWS;
   }
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[post]) {
+  static unsigned long long attr_done[2] = {0, 0};
+  if (lr_attr_needed(&attr_done[post])) {
     hipFuncSetAttribute(post ? reinterpret_cast<const void*>(ffn_block_kernel<T, true>) : reinterpret_cast<const void*>(ffn_block_kernel<T, false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done[post] = true;
   }
   if (post) hipLaunchKernelGGL((ffn_block_kernel<T, true>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);
   else hipLaunchKernelGGL((ffn_block_kernel<T, false>), dim3(P.nblocks), dim3(FF_THREADS), smem, (hipStream_t)s, P);

@@ -933,11 +933,10 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
   P.nblocks = P.ntiles_n * ntm;
   // stages + (mean, rstd) rows + (bias, ln_colsum) columns
   const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (lr_attr_needed(&attr_done)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   const int gx = P.nblocks;
   hipLaunchKernelGGL((gemm_conv_pipe_kernel<BM2, NW, BN, WMW, NSTAGE, MODE, T>), dim3(gx, P.splits), dim3(NW * 64), smem, st, P);
@@ -1058,11 +1057,10 @@ static int launch_gemm_t(const GemmParams& P0, hipStream_t st) {
   P.nblocks = P.ntiles_n * ntm;
   // stages + (mean, rstd) rows + (bias, ln_colsum) columns
   const size_t smem = 2 * (size_t)(BM + BN) * 128 + BM * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (lr_attr_needed(&attr_done)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_kernel<BN, MODE, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm_conv_kernel<BN, MODE, T>), dim3(P.nblocks, P.splits), dim3(GEMM_THREADS), smem, st, P);
   return lr_launch_status();

@@ -514,11 +514,10 @@ static int xattn_block_t(const lr_xattn_args* a, lr_stream_t s) {
   P.pre_a = a->pre_a; P.pre_w = a->pre_w; P.pre_b = a->pre_b;
   const void* fns[4] = {reinterpret_cast<const void*>(xattn_block_kernel<T, 5, false>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, false>),
                         reinterpret_cast<const void*>(xattn_block_kernel<T, 5, true>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, true>)};
-  static bool attr_done[4] = {false, false, false, false};
+  static unsigned long long attr_done[4] = {0, 0, 0, 0};
   const int v = (pre ? 2 : 0) + (six ? 1 : 0);
-  if (!attr_done[v]) {
+  if (lr_attr_needed(&attr_done[v])) {
     hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done[v] = true;
   }
   const dim3 grid(P.nblocks), block(XA_THREADS);
   if (v == 0) hipLaunchKernelGGL((xattn_block_kernel<T, 5, false>), grid, block, smem, (hipStream_t)s, P);

@@ -184,6 +184,33 @@ class DDIMSampler(object):
             eps = torch.cat([e, e])      # degenerate CFG: e_u = e_c = e  ->  e_t = e
             scale = 1.0
         else:
+            from leftrefill_amd import dist as lrd
+            if lrd.split_cfg_active():
+                # cond / uncond passes on two ranks (or, without a process group, one after the other): batch B each, one
+                # all-gather of the eps halves per step -- leftrefill_amd/dist.py.  (The [uncond; cond] batch is not built here.)
+                # The ranks of a pair must hold the same x and draw the same DDIM noise: the caller seeds them identically
+                # (bench.py: seed 1234 + rank // 2).
+                role = lrd.split_cfg_role()
+                if role is None:
+                    # one process runs both passes: each gets its own captured step (graph slot), so the per-context K / V cache
+                    # of a slot sees ONE context and is not recomputed twice per DDIM step
+                    unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+                    halves = []
+                    for slot, cc in enumerate((unconditional_conditioning, c)):
+                        if unet is not None:
+                            unet._graph_slot = slot
+                        try:
+                            halves.append(self.model.apply_model(x, t, cc))
+                        finally:
+                            if unet is not None:
+                                unet._graph_slot = 0
+                    eps = torch.cat(halves)
+                else:
+                    eps = lrd.cfg_exchange(self.model.apply_model(x, t, unconditional_conditioning if role == 0 else c))
+                noise = noise_like(x.shape, device, repeat_noise)
+                sigma = float(self.ddim_sigmas[index])
+                return ops.ddim_cfg_step(x, eps.contiguous(), noise, scale, self.ddim_alphas[index], self.ddim_alphas_prev[index],
+                                         sigma * float(temperature), self.ddim_sqrt_one_minus_alphas[index])
             cache = getattr(self, "_cfg_cache", None)
             if cache is not None and cache[0] == id(c) and cache[1] == id(unconditional_conditioning):
                 c_in = cache[2]
@@ -192,19 +219,6 @@ class DDIMSampler(object):
                 c_in = {k: ([torch.cat([unconditional_conditioning[k][i], c[k][i]]) for i in range(len(c[k]))]
                             if isinstance(c[k], list) else torch.cat([unconditional_conditioning[k], c[k]]))
                         for k in c}
-            from leftrefill_amd import dist as lrd
-            if lrd.split_cfg_active():
-                # cond / uncond passes on two ranks (or, without a process group, one after the other): batch B each, one
-                # all-gather of the eps halves per step -- leftrefill_amd/dist.py
-                role = lrd.split_cfg_role()
-                if role is None:
-                    eps = torch.cat([self.model.apply_model(x, t, unconditional_conditioning), self.model.apply_model(x, t, c)])
-                else:
-                    eps = lrd.cfg_exchange(self.model.apply_model(x, t, unconditional_conditioning if role == 0 else c))
-                noise = noise_like(x.shape, device, repeat_noise)
-                sigma = float(self.ddim_sigmas[index])
-                return ops.ddim_cfg_step(x, eps.contiguous(), noise, scale, self.ddim_alphas[index], self.ddim_alphas_prev[index],
-                                         sigma * float(temperature), self.ddim_sqrt_one_minus_alphas[index])
             x_in = torch.cat([x] * 2)
             t_in = torch.cat([t] * 2)
             unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)

@@ -395,8 +395,11 @@ class UNetModel(nn.Module):
             n_, h_, w_ = act.N, act.H, act.W
             shape = {}
 
+            gs_, gs2_ = act.gs, act.gs2      # producer statistics (no gradient flows through them): the recomputed block takes
+                                             # exactly the path -- fused GroupNorm / GroupNorm-folded proj_in -- of the plain forward
+
             def body(tok, tok2, *ts):
-                out = fn(E.Act(tok, n_, h_, w_, tok2=tok2), *ts)
+                out = fn(E.Act(tok, n_, h_, w_, tok2=tok2, gs=gs_, gs2=gs2_), *ts)
                 shape["hw"] = (out.H, out.W)
                 return out.materialize()
 
@@ -448,7 +451,8 @@ class UNetModel(nn.Module):
             act = self._block_out(act, bstate)
             if shared and i == 0:      # the skip connection of the last output block wants the full batch
                 hs.append(E.Act(E.dup2(act.tok), N, act.H, act.W,
-                                gs=None if act.gs is None else (E.dup2(act.gs[0]), act.gs[1])))
+                                gs=None if act.gs is None else (E.dup2(act.gs[0]), act.gs[1],
+                                                                None if act.gs[2] is None else E.dup2(act.gs[2]), act.gs[3])))
             else:
                 hs.append(act)
             tap(f"in{i}", hs[-1])
@@ -464,8 +468,8 @@ class UNetModel(nn.Module):
         act = E.conv(act, P["out_conv"])
         return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels)
 
-    def _needs_autograd(self, context):
-        return torch.is_grad_enabled() and context.requires_grad
+    def _needs_autograd(self, context, c_input=None):
+        return torch.is_grad_enabled() and (context.requires_grad or (c_input is not None and c_input.requires_grad))
 
     def _add_c_input(self, act, c_input):
         """h += c_input, or its right half when c_input is half as wide (NVS_ldm.py:64-68).  Layout conversion + one add of a
@@ -490,18 +494,19 @@ class UNetModel(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the noisy latent is not produced (p_losses feeds x_noisy without grad)")
         context = context.to(self.compute_dtype).contiguous()
-        if self._needs_autograd(context):
-            # training (frozen weights, gradient flows to `context`): eager launches through leftrefill_amd.train_ops,
-            # torch.autograd records the HIP backward kernels; no hipGraph, no K/V cache
-            return self._run_plan(x, timesteps, context)
         c_input = kwargs.get("c_input")
+        if self._needs_autograd(context, c_input):
+            # training (frozen weights, gradient flows to `context` and / or to the refinement branch behind `c_input`,
+            # NVS_ldm.py:64-68): eager launches through leftrefill_amd.train_ops, torch.autograd records the HIP backward
+            # kernels; no hipGraph, no K/V cache
+            return self._run_plan(x, timesteps, context, c_input=c_input)
         if not self.use_hip_graph or c_input is not None or getattr(self, "eager_only", False):
             # eager inference: the same launches as the captured step (per-context K / V operands computed first), so the
             # two modes stay bit-identical.  (c_input / separator tokens of the NVS UNet: eager only.)
             with torch.no_grad():
                 return self._run_plan(x, timesteps, context, self._context_kv(context), c_input=c_input)
         shared = bool(self.cfg_shared_prefix)
-        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared)
+        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared, getattr(self, "_graph_slot", 0))
         g = self._graphs.pop(key, None)
         if g is None:
             g = _StepGraph(self, x, timesteps, context, shared)

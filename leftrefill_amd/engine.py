@@ -292,8 +292,14 @@ def xattn_fused(x, pa: PackedAttn, B, L, Lc, kv):
     return (XATTN and kv is not None and len(kv) > 2 and fold_ok(x) and ops.xattn_ok(B * L, L, x.shape[1], pa.heads, Lc))
 
 
-def ffn_fused(x, pt):
-    return FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(x.shape[0], x.shape[1], pt.ff2_x.shape[0] * 64)
+def ffn_fused(x, pt, rows=None, ctx=None):
+    """Will _ffn take the one-launch path (lr_ffn_block_f16)?  rows: rows of the tensor the feed-forward will see (x may still hold
+    half of a CFG batch when the decision is taken, see transformer_block); ctx: the block's context -- when it requires grad the
+    feed-forward input will too (it sits behind the cross-attention), and the fused kernel has no backward."""
+    rows = x.shape[0] if rows is None else rows
+    if ctx is not None and torch.is_grad_enabled() and ctx.requires_grad:
+        return False
+    return FFN_FUSED and pt.ff2_x is not None and fold_ok(x) and ops.ffn_ok(rows, x.shape[1], pt.ff2_x.shape[0] * 64)
 
 
 XATTN_PRE = __import__("os").environ.get("LEFTREFILL_XATTN_PRE", "1") != "0"
@@ -317,12 +323,12 @@ def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False):
                            scale=pa2.dim_head ** -0.5, want_stats=want_stats, pre=(a, pa1.out.w, pa1.out.b))
 
 
-def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False, dup=False):
+def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stats=False, dup=False, fused=None):
     """x + to_out(attention(LayerNorm(x) Wq, ctx Wk, ctx Wv)).  kv: optional precomputed ([B*Lc, 2C] = ctx @ [Wk; Wv]^T,
     V^T in the attention kernel's layout) -- constant over the DDIM steps, see UNetModel._context_kv.
     dup: x holds only the first B / 2 samples (the two CFG halves are identical up to here): the query projection runs
     once, then x and q are duplicated for the B contexts."""
-    if xattn_fused(x, pa, B, L, Lc, kv):
+    if xattn_fused(x, pa, B, L, Lc, kv) if fused is None else fused:
         # one launch: LayerNorm + to_q + attention + to_out + residual (+ the row statistics of the next LayerNorm)
         if dup:
             x = dup2(x)
@@ -348,15 +354,17 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
     dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
     self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix)."""
+    # The two fused-block decisions are taken ONCE per block (ADVICE r3): they steer which producers emit row statistics, so every
+    # consumer below must see the same answer.  (Both are pure functions of shapes, switches and the autograd state.)
+    use_xattn = xattn_fused(x, pt.attn2, N, L, Lc, kv)
+    use_ffn = ffn_fused(x, pt, rows=N * L, ctx=ctx)      # rows of the block's output: x may still hold half of a CFG batch here (`dup`)
     # ask the residual GEMMs for the row statistics the next LayerNorm fold needs (the fused blocks normalise their rows themselves)
-    ws = fold_ok(x) and not xattn_fused(x, pt.attn2, N, L, Lc, kv)
-    n_rows = N * L          # rows of the block's output (x may still hold half of a CFG batch here: `dup`)
-    ffn_f = FFN_FUSED and pt.ff2_x is not None and ops.ffn_ok(n_rows, x.shape[1], pt.ff2_x.shape[0] * 64)
-    if pt.view_num is None and XATTN_PRE and xattn_fused(x, pt.attn2, N, L, Lc, kv) and pt.attn1.out.b is not None:
-        ws = fold_ok(x) and not ffn_f
+    ws = fold_ok(x) and not use_xattn
+    if pt.view_num is None and XATTN_PRE and use_xattn and pt.attn1.out.b is not None:
+        ws = fold_ok(x) and not use_ffn
         x = self_then_cross_attention(x, st, pt, N, L, Lc, kv, ws, dup=dup)
         x, st = x if ws else (x, None)
-        return _ffn(x, st, pt, want_stats, post)
+        return _ffn(x, st, pt, want_stats, post, use_ffn)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
             x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
@@ -381,25 +389,26 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         assert b * v == N
         x = self_attention(x, st, pt.n1, pt.attn1, b, v * L, want_stats=ws)
     x, st = x if ws else (x, None)
-    ws = fold_ok(x) and not ffn_f
-    x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup)
+    ws = fold_ok(x) and not use_ffn
+    x = cross_attention(x, st, pt.n2, ctx, pt.attn2, N, L, Lc, kv, want_stats=ws, dup=dup, fused=use_xattn)
     x, st = x if ws else (x, None)
-    return _ffn(x, st, pt, want_stats, post)
+    return _ffn(x, st, pt, want_stats, post, use_ffn)
 
 
 FFN_POST = __import__("os").environ.get("LEFTREFILL_FFN_POST", "1") != "0"
 
 
-def _ffn(x, st, pt: PackedTBlock, want_stats, post=None):
+def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
     """x + ff(LayerNorm(x)) (attention.py:282); st: row statistics of x (or None); returns (y, statistics of y | None).
     post = (proj_out pieces, bias, x_in, want_gn): when the fused kernel runs, SpatialTransformer.proj_out (+ x_in) rides behind it in
     the same launch and the result is ("post", out, GroupNorm statistics | None) instead."""
-    if post is not None and FFN_POST and ffn_fused(x, pt):
+    fused = ffn_fused(x, pt) if fused is None else fused
+    if post is not None and FFN_POST and fused:
         pw, pb, x_in, want_gn, hw = post
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, post=(pw, pb, x_in), want_gn_stats=want_gn,
                           gn_hw=hw)
         return ("post",) + (y if want_gn else (y, None))
-    if ffn_fused(x, pt):
+    if fused:
         # one launch: LayerNorm + GEGLU projection + gate + second Linear + residual; the hidden activation stays in registers
         ws = want_stats and fold_ok(x)
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, want_stats=ws)

@@ -69,6 +69,32 @@ def test_nvs_separator_and_context_gradients_flow():
         p.requires_grad_(False)
 
 
+def test_nvs_c_input_reaches_the_training_path_and_gets_a_gradient():
+    """with `use_input_refinement` NVSLDM.get_input passes c_input = refinement_model(inp) * refinement_alpha (reference
+    NVS_ldm.py:64-68 always adds it).  The autograd path of UNetModel.forward must add it too, and the gradient must reach it -- also
+    when ONLY c_input requires grad (frozen context)."""
+    m = nvs_unet(False)
+    x, t, ctx, c_input = G.nvs_unet_inputs("nvs_cgrad", (2, 320, 8, 16), 2, 8, 16, [501, 101])
+    x, t, ctx = x.to(dev()), t.to(dev()), ctx.to(dev())
+    alpha = torch.nn.Parameter(torch.tensor(0.5, device=dev()))
+    base = c_input.to(dev())
+    with torch.no_grad():
+        y_inf = m(x, t, context=ctx, c_input=base * 0.5)            # inference path (eager, no autograd)
+        y_none = m(x, t, context=ctx)
+    for ctx_grad in (True, False):
+        c = ctx.clone().requires_grad_(ctx_grad)
+        alpha.grad = None
+        y = m(x, t, context=c, c_input=base * alpha)
+        (y.float() ** 2).mean().backward()
+        assert alpha.grad is not None and torch.isfinite(alpha.grad) and alpha.grad.abs() > 0, ctx_grad
+        if ctx_grad:
+            assert c.grad is not None and c.grad.abs().max() > 0
+        # the training forward really added c_input: it agrees with the inference forward that has it, not with the one without
+        d_with = (y.detach().float() - y_inf.float()).abs().max().item()
+        d_without = (y.detach().float() - y_none.float()).abs().max().item()
+        assert d_with < 0.1 * d_without, (d_with, d_without)
+
+
 def test_nvsldm_log_images_and_multi_cond():
     """NVSLDM.log_images / log_multi_cond_images (reference 244-319) with identity first / cond stages at MID width: shapes, finite
     outputs, K = 1 multi-conditioning == the plain sampler up to the DDIM noise draw (eta = 0: identical)."""
