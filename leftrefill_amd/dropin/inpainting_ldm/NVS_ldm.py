@@ -33,10 +33,10 @@ class NVSUnetModel(UNetModel):
             self.sep_token = nn.ParameterDict({str(ch): nn.Parameter(torch.randn(ch), requires_grad=True) for ch in SEP_CHANNELS})
             self.eager_only = True        # block shapes change inside the step: no captured graph for this variant
 
-    def _needs_autograd(self, context):
+    def _needs_autograd(self, context, c_input=None):
         # the separator tokens are trainable parameters of the UNet itself: their gradient needs the autograd path too
         sep_grad = self.use_sep and any(p.requires_grad for p in self.sep_token.values())
-        return torch.is_grad_enabled() and (context.requires_grad or sep_grad)
+        return super()._needs_autograd(context, c_input) or (torch.is_grad_enabled() and sep_grad)
 
     def _block_in(self, act, steps):
         """[left | right] -> [left | sep | right] for blocks that do not end in a Down / Upsample (57-60, 85-88)."""

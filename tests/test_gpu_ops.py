@@ -662,6 +662,37 @@ def test_attention_online_softmax_rescale():
     report("attention spike", o.reshape(B, N, 64), ref, atol=2e-3)
 
 
+@pytest.mark.parametrize("vt", [False, True], ids=["plain", "vt"])
+def test_attention_logit_jumps_of_every_size(vt):
+    """The inference kernels form P without a row max (the partial row sum is the overflow guard, running max anchored by tile 0):
+    a logit ~20 / ~70 octaves above the running max takes the in-place repair, one more than 127 octaves above it makes P infinite in
+    fp32 and the block reruns with the row max in every tile -- first, middle and last tiles, against the fp32 oracle (guide rule 26)."""
+    from leftrefill_amd import ops
+    d = dev()
+    B, heads, N = 1, 2, 768
+    C = heads * 64
+    q = h16(G.T("attj.q", (B, N, C)))
+    k = h16(G.T("attj.k", (B, N, C)))
+    v = h16(G.T("attj.v", (B, N, C)))
+    # head 0: moderate and large jumps (repair path); head 1: an overflowing one (robust rerun), each in a different tile
+    k[0, 70, :64] = q[0, 300, :64] * 2.0       # ~ +20 octaves in tile 1
+    k[0, 400, :64] = q[0, 40, :64] * 6.0       # ~ +70 octaves in a middle tile
+    k[0, 760, :64] = q[0, 7, :64] * 5.0        # last tile
+    k[0, 130, 64:] = q[0, 500, 64:] * 14.0     # > 127 octaves: fp32 overflow of P
+    k[0, 5, 64:] = q[0, 100, 64:] * 3.0        # first tile (covered by the anchor)
+    ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))
+    old_min = ops.VT_MIN_KEYS
+    try:
+        ops.VT_MIN_KEYS = 1 if vt else 1 << 30
+        o = ops.attention(q.reshape(N, C).half().to(d), k.reshape(N, C).half().to(d), v.reshape(N, C).half().to(d), B, heads, N, N, 64 ** -0.5)
+        o2 = ops.attention(q.reshape(N, C).half().to(d), k.reshape(N, C).half().to(d), v.reshape(N, C).half().to(d), B, heads, N, N, 64 ** -0.5)
+    finally:
+        ops.VT_MIN_KEYS = old_min
+    assert torch.equal(o, o2)
+    # rows that jumped are dominated by one key (weight ~1): P near 1 is rounded to fp16, a few times the plain error
+    report(f"attention jumps vt={vt}", o.reshape(B, N, C), ref, atol=4e-3)
+
+
 def test_attention_vt_rescale_and_hot_shapes():
     """The pre-transposed-V kernel (the self-attention path of the UNet) against the CPU oracle DIRECTLY: (a) forced
     running-max jumps in the first, a middle and the last tile (guide rule 26), (b) the level-0 shape of configs[1]
