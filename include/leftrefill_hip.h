@@ -167,6 +167,10 @@ typedef struct lr_gemm_args {
    * bias + b * bias_bstride (elements).  Pointwise calls only (taps == 1), H * W a multiple of the tile's rows, no split-K.
    * Used for the GroupNorm of SpatialTransformer folded into proj_in (lr_gn_fold_weights_f16). */
   int32_t wt_bstride, bias_bstride;
+  /* wt_pm != 0 (ABI 20): wt is piece-major, [K / 64][N][64] -- the 64-element (128-byte) pieces of all N rows for K-step 0, then for
+   * K-step 1, ... (lr packing: w.reshape(N, K / 64, 64).permute(1, 0, 2)).  Same arithmetic, same K order; a tile's weight slice of one
+   * K-step is then one contiguous run instead of tile_n pieces 2 K bytes apart.  Not with wt_bstride. */
+  int32_t wt_pm;
 } lr_gemm_args;
 /* row tiles per sample of gn_group_out for this call, 0 if the plan cannot produce per-group sums */
 int lr_gemm_gn_group_chunks(const lr_gemm_args* args);

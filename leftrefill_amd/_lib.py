@@ -41,6 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("pipe", ctypes.c_int32),
         ("gn_group_out", c_void_p), ("gn_hw", ctypes.c_int32),
         ("wt_bstride", ctypes.c_int32), ("bias_bstride", ctypes.c_int32),
+        ("wt_pm", ctypes.c_int32),
     ]
 
 

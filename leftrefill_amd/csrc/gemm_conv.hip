@@ -45,6 +45,10 @@ struct GemmParams {
   int gs_store;   // split-K reduce: write gs_out (0 when gs_out only carries the "statistics wanted" flag for gp_out)
   // per-sample weights / bias (GroupNorm folded into a pointwise GEMM, lr_gn_fold_weights_f16): sample = m / rows_per_batch
   int wt_bstride, bias_bstride;
+  // weight layout: 0 = [N][K] (a K-step's 128-byte pieces of consecutive rows lie 2 K bytes apart), 1 = piece-major [K / 64][N][64]
+  // (the 128-byte pieces of a K-step are consecutive: a tile's weight slice of one K-step is ONE contiguous run of tile_n * 128
+  // bytes -- DRAM pages and L2 channels see a stream instead of a 2K-byte stride)
+  int wt_pm;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
@@ -506,8 +510,9 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
     const int row = (i * 4 + w) * 8 + (lane >> 3);
     const int n = n0 + row;
     const int chunk = slot ^ ((row >> 1) & 7);
-    wvo[i] = n < P.N ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
+    wvo[i] = n < P.N ? (unsigned)(((size_t)n * (P.wt_pm ? 64 : P.K) + chunk * 8) * 2) : OOB;
   }
+  const unsigned kstep_bytes = P.wt_pm ? (unsigned)P.N * 128u : 128u;
   unsigned avo[4] = {OOB, OOB, OOB, OOB};
   int seg_tap = -1, seg_src = -1;
   auto stage = [&](int buf, int kt) {
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * 4 + w) * 8) * 128), 16, avo[i], coff, 0, 0);
-    const unsigned koff = (unsigned)(kt * 128);
+    const unsigned koff = (unsigned)kt * kstep_bytes;
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * 4 + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       const int row = (i * NW + w) * 8 + (lane >> 3);
       const int n = n0 + row;
       const int chunk = slot ^ ((row >> 1) & 7);
-      wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * P.K + chunk * 8) * 2) : OOB;
+      wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * (P.wt_pm ? 64 : P.K) + chunk * 8) * 2) : OOB;
     }
     seg_tap = -1; seg_src = -1;
     smp = P.wt_bstride ? m0 / P.rows_per_batch : 0;      // per-sample weights: the tile lies inside one sample
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       }
     }
     coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
-    koff = (unsigned)(kt * 128);
+    koff = (unsigned)kt * (P.wt_pm ? (unsigned)P.N * 128u : 128u);
     }
     if (B_TAIL && w < TAIL_WAVES)     // the odd weight rows (first waves only): issued here, ahead of the step's other loads
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + buf * STAGE + A_BYTES + ((NB_FULL * NW + w) * 8) * 128), 16,
@@ -1290,6 +1295,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     P.gp_hw = a->gn_hw > 0 ? a->gn_hw : a->H * a->W;
   }
   // per-sample weights (GroupNorm of the SpatialTransformer folded into proj_in): pointwise, one tile = one sample, no split
+  P.wt_pm = a->wt_pm ? 1 : 0;
+  if (P.wt_pm && (a->wt_bstride || P.K % 64)) return LR_E_ARG;
   P.wt_bstride = a->wt_bstride; P.bias_bstride = a->bias_bstride;
   if (P.wt_bstride) {
     if (a->taps != 1 || splits > 1 || P.rows_per_batch % tm || P.wt_bstride < 0 || P.bias_bstride < 0 || (P.wt_bstride & 7)) return LR_E_ARG;

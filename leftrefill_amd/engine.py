@@ -175,6 +175,10 @@ class PackedTBlock:
         self.view_num = getattr(blk, "view_num", None)
         self.concat_target = getattr(blk, "concat_target", False)
         self.no_rearrange = getattr(blk, "no_rearrange_selfattn", False)
+        if self.concat_target and self.no_rearrange:
+            # the reference applies its forward rearrange twice on this branch (multiview_attention.py:437-438, 452-453): it cannot run
+            # there (shape error unless b % (view_num - 1) == 0, then a context batch mismatch); no config uses it -- see oracle/unet_ref.py
+            raise NotImplementedError("no_rearrange_selfattn=True with concat_target=True is unusable in the reference and not implemented")
 
 
 class PackedST:

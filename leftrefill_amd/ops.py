@@ -215,7 +215,7 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
               resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, pipe=0, ln=None,
-              want_stats=False, want_gn_stats=False, gn_hw=0, per_sample=False):
+              want_stats=False, want_gn_stats=False, gn_hw=0, per_sample=False, wt_pm=False):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
 
     ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
@@ -237,9 +237,13 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         _chk16(x2, "x2")
         C2 = x2.shape[-1]
     if per_sample:
-        assert wt.dim() == 3 and wt.shape[0] == B and taps == 1 and x2 is None and wt.is_contiguous()
-    Nw = wt.shape[-2]
-    assert wt.shape[-1] == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+        assert wt.dim() == 3 and wt.shape[0] == B and taps == 1 and x2 is None and wt.is_contiguous() and not wt_pm
+    if wt_pm:      # piece-major weights [K / 64, N, 64] (packing.pack_pm)
+        assert wt.dim() == 3 and wt.shape[2] == 64 and wt.is_contiguous()
+        Nw, Kw = wt.shape[1], wt.shape[0] * 64
+    else:
+        Nw, Kw = wt.shape[-2], wt.shape[-1]
+    assert Kw == taps * (C1 + C2), (wt.shape, taps, C1, C2)
     assert x1.shape[0] == B * Hs * Ws, (x1.shape, B, Hs, Ws)
     M = B * H * W
     n_out = Nw // 2 if geglu else Nw
@@ -267,7 +271,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.workspace, a.workspace_bytes = 0, 0
     a.ln_stats, a.ln_parts, a.ln_eps, a.ln_colsum, a.stats_out, a.gn_stats_out = 0, 0, 0.0, 0, 0, 0
     a.gn_group_out, a.gn_hw = 0, int(gn_hw)
-    a.wt_bstride, a.bias_bstride = (Nw * wt.shape[-1], Nw if bias is not None else 0) if per_sample else (0, 0)
+    a.wt_bstride, a.bias_bstride = (Nw * Kw, Nw if bias is not None else 0) if per_sample else (0, 0)
+    a.wt_pm = int(bool(wt_pm))
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
     a.dtype = int(x1.dtype == torch.bfloat16)      # LR_DTYPE_F16 | LR_DTYPE_BF16
     if ln is not None:
@@ -278,7 +283,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     st = _stream()
     if tile_m == 0 and tile_n == 0 and splits == 0:
         scale = _PLAN_BATCH_SCALE[0]
-        key = tile_key(M * scale, Nw, wt.shape[-1], taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
+        key = tile_key(M * scale, Nw, Kw, taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
         if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
             a.B = B * scale

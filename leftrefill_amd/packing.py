@@ -83,3 +83,10 @@ def pack_xattn(wk, wo, dtype=torch.float16):
     """(to_k.weight with its ROWS in k-slot order, to_out[0].weight as per-head pieces [heads, C, 64] with k-slot column order)."""
     perm = xattn_perm(wk.shape[0], wk.device)
     return wk[perm].to(dtype).contiguous(), pack_pieces(wo, dtype)
+
+
+def pack_pm(w):
+    """[N, K] packed weights -> piece-major [K / 64, N, 64] (lr_gemm_args.wt_pm): the 128-byte pieces of a K-step are consecutive."""
+    N, K = w.shape
+    assert K % 64 == 0
+    return w.reshape(N, K // 64, 64).permute(1, 0, 2).contiguous()

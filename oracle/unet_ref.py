@@ -278,7 +278,12 @@ def mv_gather(x, view_num, concat_target, no_rearrange):
     if concat_target:
         v = view_num - 1
         if no_rearrange:
-            return x.reshape(x.shape[0] // v, v * x.shape[1], x.shape[2]), None
+            # multiview_attention.py:437-438 and 452-453 apply the SAME forward rearrange '(b v) hw c -> b (v hw) c' twice: the second
+            # one runs on a [b, v hw, c] tensor, i.e. it fails unless b % v == 0 and otherwise folds the batch again, after which
+            # attn2 meets a context of the wrong batch size.  The branch cannot run in the reference (no config uses it); it is
+            # rejected here and in the HIP engine instead of guessing an "intended" inverse.
+            raise NotImplementedError("no_rearrange_selfattn with concat_target: unusable in the reference (the forward rearrange is applied twice, "
+                                      "multiview_attention.py:437-438 / 452-453); not restated")
         s = int(math.sqrt(x.shape[1] / 2))
         xn = x.reshape(x.shape[0] // v, v, s, 2 * s, x.shape[2])
         seq = torch.cat((xn[:, 0:1, :, s:, :], xn[:, :, :, 0:s, :]), dim=1)  # [target, ref_0..ref_{v-1}]
@@ -290,8 +295,7 @@ def mv_scatter(x, view_num, concat_target, no_rearrange, info):
     """multiview_attention.py:452-462: inverse of mv_gather (target written to every canvas)."""
     if concat_target:
         v = view_num - 1
-        if no_rearrange:
-            return x.reshape(x.shape[0] * v, x.shape[1] // v, x.shape[2])
+        assert not no_rearrange      # rejected in mv_gather
         v, s = info
         c = x.shape[2]
         xs = x.reshape(x.shape[0], view_num, s, s, c)

@@ -561,6 +561,29 @@ def test_groupnorm_folded_into_pointwise_gemm(C, HW):
     assert torch.allclose(st[:, :, 0].sum(1), of.sum(1), rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("tile", [(128, 64), (128, 160), (256, 160), (256, 320), (128, 160, 4)], ids=lambda t_: "x".join(map(str, t_)))
+def test_gemm_piece_major_weights_are_bit_identical(tile):
+    """lr_gemm_args.wt_pm: the same weights stored [K / 64][N][64] (a K-step's 128-byte pieces consecutive) give the same bits as
+    the [N][K] layout -- 3x3 conv with a virtual concat, a split-K call, a pointwise call with ragged N."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W = 2, 8, 16
+    x1 = to_tok(h16(G.T("pm.x1", (N, 128, H, W))))
+    x2 = to_tok(h16(G.T("pm.x2", (N, 64, H, W))))
+    w = packing.pack_conv(h16(torch.from_numpy(weights.fill_like("pm.w", (320, 192, 3, 3)))), cin_pad=192).to(d)
+    b = torch.from_numpy(weights.fill_like("pm.b", (320,))).to(d)
+    for splits in (1, 3):
+        y0 = ops.gemm_conv(x1, w, x2=x2, B=N, H=H, W=W, taps=9, bias=b, splits=splits, **tile_kw(tile))
+        y1 = ops.gemm_conv(x1, packing.pack_pm(w), x2=x2, B=N, H=H, W=W, taps=9, bias=b, splits=splits, wt_pm=True, **tile_kw(tile))
+        assert torch.equal(y0, y1), (tile, splits)
+    report("pm conv", from_tok(y1, N, H, W), F.conv2d(torch.cat([from_tok(x1, N, H, W), from_tok(x2, N, H, W)], 1),
+                                                       h16(torch.from_numpy(weights.fill_like("pm.w", (320, 192, 3, 3)))), b.cpu(), padding=1))
+    a = h16(G.T("pm.a", (300, 640))).half().to(d)
+    wl = h16(torch.from_numpy(weights.fill_like("pm.wl", (328, 640)))).half().to(d)
+    assert torch.equal(ops.gemm_conv(a, wl, B=1, H=1, W=300, taps=1, splits=1, **tile_kw(tile)),
+                       ops.gemm_conv(a, packing.pack_pm(wl), B=1, H=1, W=300, taps=1, splits=1, wt_pm=True, **tile_kw(tile)))
+
+
 def test_tile_plan_is_static_and_tiles_agree_bitwise():
     """The (tile, split-K) plan is a pure function of the shape (in-tree table or the static heuristic -- never timing),
     and with the split factor pinned every tile gives bit-identical results (same K order per output element)."""

@@ -60,12 +60,16 @@ def make_case(M, N, K, taps, fl, dev, nsets):
             d["st"] = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).reshape(M, 1, 2).contiguous()
         sets.append(d)
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+    pm = os.environ.get("LR_BENCH_PM", "0") == "1"
+    if pm:
+        from leftrefill_amd import packing
+        w = packing.pack_pm(w)
     b = torch.randn(N, device=dev)
-    cs = w.float().sum(1).contiguous()
+    cs = (w.float().sum(2).sum(0) if pm else w.float().sum(1)).contiguous()
     rv = torch.randn(B, N, device=dev).half() if fl.get("rowvec") else None
 
     def launch(d, tm, tn, sp, stg=0):
-        return ops.gemm_conv(d["x"], w, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp, pipe=stg,
+        return ops.gemm_conv(d["x"], w, wt_pm=pm, B=B, H=H, W=W, taps=taps, bias=b, out=d["out"], tile_m=tm, tile_n=tn, splits=sp, pipe=stg,
                              geglu=bool(fl.get("geglu")), resid=d.get("resid"), rowvec=rv,
                              ln=(d["st"], 1e-5, cs) if fl.get("ln") else None, want_stats=bool(fl.get("stats")))
     return sets, launch
