@@ -429,7 +429,18 @@ def train_bench(a, rank, world, device, model=None, steps=None):
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / 3 * 1e3
     unet.compute_dtype = prev_dtype
+    from leftrefill_amd.flops import unet_train_flops
+    tf = unet_train_flops(unet, h, w)
+    step_tflops = Bt * tf["total"] / (dt / steps) / 1e12
+    roof = {"bound": "mfma", "kernel": "whole training step (forward + input-gradient backward; AdamW on 73 x 1024 tokens is negligible)",
+            "achieved": step_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / MFMA_PEAK_TFLOPS,
+            "algorithmic_tflop_per_step": Bt * tf["total"] / 1e12, "forward_tflop": Bt * tf["forward"] / 1e12,
+            "backward_tflop": Bt * tf["backward"] / 1e12,
+            "forward_only_frac": Bt * tf["forward"] / (fwd_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+            "note": "2 MAC of the conv / linear / attention products of ONE step at batch 16 (leftrefill_amd/flops.py::unet_train_flops: dgrad "
+                    "GEMMs for every layer behind the first cross-attention, attention backward = 2.5 x forward) / measured step time"}
     return {"metric": "training samples/sec (UNet fwd + bwd to the prompt tokens, frozen weights)", "value": world * Bt * steps / dt,
+            "roofline": roof,
             "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f16", "data": "synthetic",
             "config": {"workload": ("configs[4] (NVS task model: NVSLDM.p_losses, prompt tokens + pose MLP trainable): " if task == "nvs"
@@ -739,8 +750,12 @@ def main():
         samples_per_step = max(1, a.batch // 4)
         B, h, w = samples_per_step * views, mv["h"], mv["w"]
         if a.mv_shard:              # configs[3]: the canvases of a sample spread over the ranks, one each
-            if a.workload != "mv5" or world != views:
-                raise SystemExit(f"--mv-shard: --workload mv5 with --gpus {views} (one canvas [ref_i | target] per rank)")
+            if a.workload != "mv5" or world not in (1, views):
+                raise SystemExit(f"--mv-shard: --workload mv5 with --gpus {views} (one canvas [ref_i | target] per rank), or --gpus 1 for the "
+                                 "per-rank cost with simulated peers")
+            if world == 1:          # ONE rank of the 4-rank job on its own: the peers' rows are local copies (leftrefill_amd.dist._sim_world)
+                os.environ["LEFTREFILL_MV_SIM_WORLD"] = str(views)
+                os.environ.setdefault("LEFTREFILL_MV_SIM_RANK", "0")
             B, replicas = samples_per_step, 1
     if a.split_cfg:
         if a.workload != "single" or world % 2:
@@ -803,7 +818,16 @@ def main():
         res["config"]["workload"] = (f"config 4 ({a.workload}): {MV_WORKLOADS[a.workload]}, {samples_per_step} sample(s) = {B} "
                                      f"canvases per GPU (UNet batch {2 * B}), {S_DDIM} DDIM steps, cfg=2.5, eta=1.0, fp16")
         res["config"]["global_batch"], res["config"]["per_gpu_batch"] = replicas * samples_per_step, samples_per_step
-        if a.mv_shard:
+        if a.mv_shard and world == 1:
+            views_ = MV_WORKLOADS[a.workload]["view_num"] - 1
+            res["metric"] = "PER-RANK cost of the sharded multi-view step (rank %s of %d, peers simulated by local copies: no wire time)" % (
+                os.environ.get("LEFTREFILL_MV_SIM_RANK", "0"), views_)
+            res["unit"] = "samples/s if the collectives were free"
+            res["config"]["parallelism"] = (f"mv-shard x{views_} simulated on one GPU: one canvas per rank; per transformer block the rows an "
+                                            "all_gather_into_tensor of the reference halves + a broadcast of the target half would deliver are "
+                                            "written from local data (same kernels, same bytes)")
+            res["per_rank_unet_step_ms"] = unet_step_ms
+        elif a.mv_shard:
             res["scaling"] = "strong"
             res["metric"] = "multi-view samples/sec (4-ref, 5 x 4096-token cross-view self-attention) @ 50 DDIM steps, cfg=2.5; canvases sharded over ranks"
             res["unit"] = "samples/s"
@@ -888,7 +912,7 @@ def main():
         if world == 1:      # next row 8f-2: one training step of the prompt tokens (see train_bench)
             def train():
                 tr = train_bench(a, rank, world, device, model=model, steps=3)
-                return {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib")}
+                return {k: tr[k] for k in ("value", "unit", "ms_per_step", "forward_only_ms", "final_loss", "peak_memory_gib", "roofline")}
             side("training_256x512_b16", train)
 
             def train_bf16():

@@ -70,8 +70,28 @@ def sample_sharded(sample_fn, cond, uncond, x_T, batch_size):
 # Everything else in the UNet is canvas-local.  The helpers are device-agnostic (torch + torch.distributed only) so the
 # index logic is covered by gloo tests on CPU; on GPUs the backend is `nccl` (RCCL over xGMI).
 # ---------------------------------------------------------------------------------------------------------------
+# Per-rank cost of the sharded multi-view step without the other ranks (bench.py --workload mv5 --mv-shard --gpus 1): with
+# LEFTREFILL_MV_SIM_WORLD = v and no process group, this process plays rank LEFTREFILL_MV_SIM_RANK (default 0) of a v-rank job --
+# the sequence buffer is filled with local copies where the all-gather / broadcast would deliver the other ranks' rows (same
+# shapes, same kernels, same bytes written; only the wire is missing).
+def _sim_world():
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return 0
+    return int(os.environ.get("LEFTREFILL_MV_SIM_WORLD", "0"))
+
+
 def mv_group_size():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return _sim_world() or 1
+
+
+def mv_rank():
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(os.environ.get("LEFTREFILL_MV_SIM_RANK", "0")) if _sim_world() else 0
 
 
 def _staged(x):
@@ -88,7 +108,7 @@ def mv_gather_sequence(x_local, s, seq=None):
     s2 = s * s
     assert T == 2 * s2
     world = mv_group_size()
-    rank = dist.get_rank() if world > 1 else 0
+    rank = mv_rank()
     g = x_local.reshape(b, s, 2 * s, C)
     if seq is None:
         seq = torch.empty(b, world + 1, s2, C, dtype=x_local.dtype, device=x_local.device)
@@ -100,6 +120,10 @@ def mv_gather_sequence(x_local, s, seq=None):
         seq[:, 0] = tgt
         seq[:, 1] = ref
         return seq.reshape(b, 2 * s2, C)
+    if _sim_world():          # simulated peers: what the collectives would write, written from local data
+        seq[:, 0] = tgt
+        seq[:, 1:] = ref[:, None]
+        return seq.reshape(b, (world + 1) * s2, C)
     if _staged(x_local):
         ref_h, tgt_h = ref.cpu(), tgt.cpu()
         allr = torch.empty(world * b, s2, C, dtype=ref_h.dtype)           # concatenation form (the one gloo accepts)
@@ -142,8 +166,11 @@ def mv_sequence_from_canvases(x_all, s):
 
 
 def mv_own_rows(seq, rank, s):
-    """Rows this rank owns as queries: the target block and its own reference block -> [b, 2*s*s, C]."""
+    """Rows this rank owns as queries: the target block and its own reference block -> [b, 2*s*s, C].  Rank 0's two blocks are
+    adjacent in the sequence: a view (no copy; contiguous when b == 1)."""
     s2 = s * s
+    if rank == 0:
+        return seq[:, :2 * s2]
     return torch.cat([seq[:, :s2], seq[:, (1 + rank) * s2:(2 + rank) * s2]], dim=1)
 
 

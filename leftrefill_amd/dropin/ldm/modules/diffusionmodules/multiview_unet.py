@@ -25,8 +25,9 @@ class MultiViewUnetModel(UNetModel):
         if not self.mv_shard:
             return super().forward(x, timesteps, context, y, **kwargs)
         import torch.distributed as tdist
-        graph_ok = (self.mv_shard_graph and self.use_hip_graph and tdist.is_available() and tdist.is_initialized()
-                    and tdist.get_backend() == "nccl")
+        from leftrefill_amd import dist as lrd
+        graph_ok = self.mv_shard_graph and self.use_hip_graph and (
+            (tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "nccl") or lrd._sim_world() > 0)
         prev_graph, prev_flag = self.use_hip_graph, engine.MV_SHARDED
         self.use_hip_graph, engine.MV_SHARDED = graph_ok, True
         try:

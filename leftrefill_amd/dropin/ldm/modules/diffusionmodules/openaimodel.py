@@ -506,7 +506,8 @@ class UNetModel(nn.Module):
             with torch.no_grad():
                 return self._run_plan(x, timesteps, context, self._context_kv(context), c_input=c_input)
         shared = bool(self.cfg_shared_prefix)
-        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared, getattr(self, "_graph_slot", 0))
+        key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared, getattr(self, "_graph_slot", 0),
+               bool(engine.MV_SHARDED))
         g = self._graphs.pop(key, None)
         if g is None:
             g = _StepGraph(self, x, timesteps, context, shared)

@@ -375,7 +375,7 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     elif pt.view_num is None:
         x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws)
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
-        x = _mv_sharded_self_attention(x, pt, N, L)
+        x = _mv_sharded_self_attention(x, pt, N, L, st)
         ws = False
     elif pt.concat_target and not pt.no_rearrange:
         v = pt.view_num - 1
@@ -384,7 +384,13 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         assert 2 * s * s == L and b * v == N, "concat_target needs square halves and batch = b*(view_num-1)"
         seq = ops.mv_gather(x, b, v, s)
         Ls = pt.view_num * s * s
-        seq = self_attention(seq, None, pt.n1, pt.attn1, b, Ls)
+        st_seq = None
+        if st is not None and fold_ok(x):
+            # the rows' LayerNorm statistics take the same re-arrangement (8 bytes x parts per row; torch index glue), so the fused
+            # QKV projection of the sequence folds its LayerNorm like every other block -- and stays bit-identical to the sharded path
+            g = st.reshape(b, v, s, 2 * s, st.shape[1] * 2)
+            st_seq = torch.cat((g[:, 0:1, :, s:], g[:, :, :, :s]), dim=1).reshape(b * Ls, st.shape[1], 2).contiguous()
+        seq = self_attention(seq, st_seq, pt.n1, pt.attn1, b, Ls)
         x = ops.mv_scatter(seq, b, v, s)
         ws = False
     else:
@@ -441,12 +447,14 @@ LN_FOLD = __import__("os").environ.get("LEFTREFILL_LN_FOLD", "1") != "0"
 MV_SHARDED = False
 
 
-def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
+def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
     """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (leftrefill_amd.dist:
     all-gather of the reference halves + broadcast of rank 0's target half per block).  x [N*L, C] = this rank's canvas
     for each of its N local samples.  K / V are built for the whole sequence, Q / attention / out-projection only for the
-    rows this rank owns ([target, ref_rank]); the target rows are replicated, bit-identical work on every rank."""
-    import torch.distributed as tdist
+    rows this rank owns ([target, ref_rank]); the target rows are replicated, bit-identical work on every rank.
+    st: per-row (sum, sumsq) partials of x from its producer.  With them the LayerNorm is folded into the K|V and Q projections
+    (round 4): the statistics travel with the rows (8 bytes x parts per row next to 2 C bytes), no normalised sequence is written,
+    and the rank's own rows are formed ONCE (a view on rank 0) instead of one copy for the normalised and one for the raw rows."""
     from . import dist as lrd
     C = x.shape[1]
     s = int(math.sqrt(L / 2))
@@ -454,15 +462,23 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L):
     v = pt.view_num - 1
     world = lrd.mv_group_size()
     assert world == v, f"multi-view sharding needs world_size == view_num - 1 ({world} vs {v})"
-    rank = tdist.get_rank() if world > 1 else 0
+    rank = lrd.mv_rank()
     Ls = (v + 1) * s * s
+    pq = pt.attn1.qkv                                                         # rows [Wq; Wk; Wv] of the fused projection
     seq = lrd.mv_gather_sequence(x.reshape(N, L, C), s)                       # [N, Ls, C]
-    n_seq = ops.layer_norm(seq.reshape(N * Ls, C), pt.n1.g, pt.n1.b, pt.n1.eps)
-    w = pt.attn1.qkv.w                                                        # rows [Wq; Wk; Wv] of the fused projection
-    kv = ops.gemm_conv(n_seq, w[C:], B=1, H=1, W=N * Ls, taps=1)              # K | V for every row of the sequence
-    own_n = lrd.mv_own_rows(n_seq.reshape(N, Ls, C), rank, s).reshape(N * L, C).contiguous()
-    own_x = lrd.mv_own_rows(seq, rank, s).reshape(N * L, C).contiguous()
-    q = ops.gemm_conv(own_n, w[:C], B=1, H=1, W=N * L, taps=1)                # Q only for the rows this rank owns
+    own_x = lrd.mv_own_rows(seq, rank, s).reshape(N * L, C)                   # rows [target, ref_rank] (a view on rank 0, N = 1)
+    if st is not None and pq.wf is not None and fold_ok(x):
+        parts = st.shape[1]
+        st_seq = lrd.mv_gather_sequence(st.reshape(N, L, parts * 2), s)       # [N, Ls, parts * 2] fp32
+        own_st = lrd.mv_own_rows(st_seq, rank, s).reshape(N * L, parts, 2).contiguous()
+        kv = ops.gemm_conv(seq.reshape(N * Ls, C), pq.wf[C:], B=1, H=1, W=N * Ls, taps=1, bias=pq.bf[C:],
+                           ln=(st_seq.reshape(N * Ls, parts, 2), pq.eps, pq.cs[C:]))
+        q = ops.gemm_conv(own_x, pq.wf[:C], B=1, H=1, W=N * L, taps=1, bias=pq.bf[:C], ln=(own_st, pq.eps, pq.cs[:C]))
+    else:
+        n_seq = ops.layer_norm(seq.reshape(N * Ls, C), pt.n1.g, pt.n1.b, pt.n1.eps)
+        kv = ops.gemm_conv(n_seq, pq.w[C:], B=1, H=1, W=N * Ls, taps=1)       # K | V for every row of the sequence
+        own_n = lrd.mv_own_rows(n_seq.reshape(N, Ls, C), rank, s).reshape(N * L, C)
+        q = ops.gemm_conv(own_n, pq.w[:C], B=1, H=1, W=N * L, taps=1)         # Q only for the rows this rank owns
     a = ops.attention(q, kv[:, :C], kv[:, C:], N, pt.attn1.heads, L, Ls, pt.attn1.dim_head ** -0.5)
     y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target', ref_rank']
     return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']

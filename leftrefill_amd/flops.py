@@ -61,3 +61,20 @@ def unet_flops(model, H, W, ctx_len=77):
         walk(blk)
     gemm += 2.0 * h * w * 9 * mc * model.out_channels
     return {"gemm": gemm, "attn": attn, "total": gemm + attn}
+
+
+def unet_train_flops(model, H, W, ctx_len=77):
+    """FLOPs of ONE training sample with frozen weights (gradient only to the context): forward + input-gradient backward.
+    Every conv / linear on the gradient path has one dgrad GEMM of the forward's size; attention backward = 5 products against the
+    forward's 2 (S recomputed, dP, dV, dQ, dK).  The layers in front of the first cross-attention (input conv, first ResBlock,
+    proj_in, the first self-attention with its projections) receive no gradient: nothing trainable sits upstream of them."""
+    f = unet_flops(model, H, W, ctx_len)
+    mc = model.model_channels
+    hw = H * W
+    cin = model.in_channels
+    prefix_gemm = 2.0 * hw * (9 * cin * mc + 9 * 2 * mc * mc + mc * mc + 4 * mc * mc) + 2.0 * 4 * mc * mc
+    prefix_attn = 4.0 * hw * hw * mc
+    bwd_gemm = max(f["gemm"] - prefix_gemm, 0.0)
+    bwd_attn = 2.5 * max(f["attn"] - prefix_attn, 0.0)
+    return {"forward": f["total"], "backward": bwd_gemm + bwd_attn, "total": f["total"] + bwd_gemm + bwd_attn,
+            "backward_gemm": bwd_gemm, "backward_attn": bwd_attn}
