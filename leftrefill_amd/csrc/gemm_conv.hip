@@ -795,11 +795,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
     }
   };
   auto mma = [&](const vec8<T> (&xf)[TM], const vec8<T> (&wf)[TN]) {
+#ifdef LR_GEMM_SETPRIO      // developer A/B build: raise the wave's priority over its SIMD partner while it issues matrix work
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
+#ifdef LR_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   // wait until all of this wave's LDS-DMA except the newest INFLIGHT stages has landed
   auto wait_stages = [&](auto inflight) __attribute__((always_inline)) {
