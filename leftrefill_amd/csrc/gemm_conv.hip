@@ -49,6 +49,11 @@ struct GemmParams {
   // (the 128-byte pieces of a K-step are consecutive: a tile's weight slice of one K-step is ONE contiguous run of tile_n * 128
   // bytes -- DRAM pages and L2 channels see a stream instead of a 2K-byte stride)
   int wt_pm;
+  // c16: 3x3 conv over a 16-channel source (the UNet's 9-channel input padded to 16: 32 bytes per pixel).  A K-step of 64 covers FOUR
+  // taps (k = tap * 16 + c, 9 taps -> 144, zero-padded to K = 192 = 3 K-steps): the 16-byte chunk c of a gathered row comes from tap
+  // 4 kt + (c >> 1), half c & 1, so the per-lane gather offset changes every K-step.  Replaces the 64-channel padding of round 1-3
+  // (K = 576, 86 % zero work).
+  int c16;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
@@ -703,9 +708,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
     rsB = uniform_rsrc(P.wt + (size_t)smp * P.wt_bstride, (size_t)P.N * P.K * 2);
   };
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
-  const int cpt = (P.C1 + P.C2) >> 6;
-  const int cpt1 = P.C1 >> 6;
-  const int nk_all = P.taps * cpt;
+  const int cpt = P.c16 ? 1 : (P.C1 + P.C2) >> 6;
+  const int cpt1 = P.c16 ? 1 : P.C1 >> 6;
+  const int nk_all = P.c16 ? 3 : P.taps * cpt;
   const int k_per = (nk_all + P.splits - 1) / P.splits;
   const int k_begin = blockIdx.y * k_per;
   const int nk = min(nk_all, k_begin + k_per);
@@ -728,6 +733,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   auto stage_prepare = [&](int buf, int kt) __attribute__((always_inline)) {
     if (kt >= nk) {      // (no real stage follows in this tile; setup_tile / the next segment change restore them)
       rsA = uniform_rsrc((const void*)P.wt, 0); rsB = rsA;
+    } else if (P.c16) {
+      // 16-channel source: this lane's chunk of each gathered row belongs to tap 4 kt + (chunk >> 1) (taps >= 9: zero padding of K)
+      rsA = uniform_rsrc((const void*)P.p1, a1_bytes);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int row = (i * NW + w) * 8 + (lane >> 3);
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int tap = kt * 4 + (chunk >> 1);
+        const int t3 = (tap * 11) >> 5;                        // tap / 3 for tap < 12
+        const int dy = t3 - P.pad, dx = tap - 3 * t3 - P.pad;
+        const unsigned m = (unsigned)(m0 + row);
+        const unsigned b = lr_udiv(m, P.hw_mul, P.hw_sh), rem = m - b * (unsigned)HW;
+        const unsigned y = lr_udiv(rem, P.w_mul, P.w_sh), x = rem - y * (unsigned)P.W;
+        const int iy = (int)y + dy, ix = (int)x + dx;
+        const bool ok = (int)m < P.M && tap < 9 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+        avo[i] = ok ? (unsigned)(((size_t)((int)b * P.Hs * P.Ws + iy * P.Ws + ix) * 16 + (chunk & 1) * 8) * 2) : OOB;
+      }
+      seg_tap = -1; seg_src = -1;
+      coff = 0;
+      koff = (unsigned)kt * (P.wt_pm ? (unsigned)P.N * 128u : 128u);
     } else {
     const int tap = kt / cpt, cc = kt - tap * cpt;
     const int srcsel = cc < cpt1 ? 0 : 1;
@@ -980,6 +1005,23 @@ __global__ __launch_bounds__(RED_ROWS * RED_GROUPS) void splitk_reduce_kernel(co
     const float* src = P.ws + (size_t)m * P.N + n;
     const size_t slice = (size_t)P.M * P.N;
     int sidx = 0;
+    if (P.splits > 4 && P.splits <= 8) {      // every partial of the thread in flight at once (one latency instead of two)
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = k < P.splits ? k : 0;
+        a[k] = *reinterpret_cast<const f32x4*>(src + kk * slice);
+        b[k] = *reinterpret_cast<const f32x4*>(src + kk * slice + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {     // same order as a plain loop over the splits
+        if (k < P.splits) {
+          v[0] += a[k][0]; v[1] += a[k][1]; v[2] += a[k][2]; v[3] += a[k][3];
+          v[4] += b[k][0]; v[5] += b[k][1]; v[6] += b[k][2]; v[7] += b[k][3];
+        }
+      }
+      sidx = P.splits;
+    }
     for (; sidx + 4 <= P.splits; sidx += 4) {
       f32x4 a[4], b[4];
 #pragma unroll
@@ -1224,7 +1266,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   GemmParams P;
   P.p1 = (const f16*)a->p1; P.C1 = a->C1;
   P.p2 = (const f16*)a->p2; P.C2 = a->p2 ? a->C2 : 0;
-  if (P.C1 <= 0 || P.C1 % 64 || P.C2 % 64) return LR_E_ALIGN;
+  P.c16 = (P.C1 == 16 && P.C2 == 0 && a->taps == 9 && a->stride == 1 && a->up == 0 && !a->asym) ? 1 : 0;
+  if (P.C1 <= 0 || (!P.c16 && P.C1 % 64) || P.C2 % 64) return LR_E_ALIGN;
   if (a->taps != 1 && a->taps != 9) return LR_E_UNSUPPORTED;
   if (a->stride != 1 && a->stride != 2) return LR_E_UNSUPPORTED;
   if (a->up < 0 || a->up > 2) return LR_E_UNSUPPORTED;
@@ -1236,7 +1279,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.pad = a->asym ? 0 : 1;   // asym: F.pad(x, (0,1,0,1)) + conv padding 0 (VAE Downsample)
   P.wt = (const f16*)a->wt; P.N = a->N; P.bias = a->bias;
   P.M = a->B * a->H * a->W;
-  P.K = a->taps * (P.C1 + P.C2);
+  P.K = P.c16 ? 192 : a->taps * (P.C1 + P.C2);      // c16: wt is [N][192] (k = tap * 16 + c, taps 9..11 zero)
   // 32-bit byte offsets in the gather (bit 31 marks out-of-range): every operand must stay below 2 GiB
   const int64_t lim = (int64_t)1 << 31;
   const int64_t src_rows = (int64_t)a->B * a->Hs * a->Ws;
@@ -1266,6 +1309,10 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(P.M, P.N, P.geglu || P.gelu, &tm, &tn);
   int splits = a->splits;
+  if (P.c16) {      // only the pipelined 256-row instances gather 16-channel taps; three K-steps: never split
+    if (tm != 256 || (a->splits > 1) || P.geglu || P.gelu || a->wt_bstride) return LR_E_UNSUPPORTED;
+    splits = 1;
+  }
   if (splits == 0) splits = choose_splits(P.M, P.N, P.K, tm, tn, P.geglu, a->pipe);
   if (splits > 1 && P.geglu) return LR_E_UNSUPPORTED;
   if (splits > 1) {
@@ -1330,6 +1377,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     else return LR_E_UNSUPPORTED;
   } else if (mode == 1) {
     if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 1>(P, st);
+    else if (deep) return LR_E_UNSUPPORTED;
     else if (tm == 128 && tn == 128) rc = launch_gemm<128, 1>(P, st);
     else if (tm == 128 && tn == 64) rc = launch_gemm<64, 1>(P, st);
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 1>(P, st);

@@ -15,6 +15,8 @@ The product path has no PyTorch-eager fallback; a missing HIP library raises.
 """
 from abc import abstractmethod
 
+import os
+
 import torch
 import torch as th
 import torch.nn as nn
@@ -290,7 +292,8 @@ class UNetModel(nn.Module):
         plan = {"sig": sig}
         plan["t0"] = E.PackedLinear(self.time_embed[0])
         plan["t2"] = E.PackedLinear(self.time_embed[2])
-        cin_pad = max(64, ((self.in_channels + 63) // 64) * 64)
+        # the 9 input channels travel as 16 (32 bytes per pixel, lr_gemm_conv_f16's 16-channel gather); wider inputs pad to 64s
+        cin_pad = 16 if self.in_channels <= 16 and os.environ.get("LEFTREFILL_CONV_IN_C16", "1") != "0" else max(64, ((self.in_channels + 63) // 64) * 64)
         plan["cin_pad"] = cin_pad
         res_list = []
 

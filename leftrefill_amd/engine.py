@@ -83,6 +83,10 @@ class PackedConv:
         self.cout = w.shape[0]
         self.taps = w.shape[2] * w.shape[3]
         self.w = packing.pack_conv(w, cin_pad=cin_pad, dtype=compute_dtype())
+        if cin_pad == 16 and self.taps == 9:
+            # 16-channel source (the UNet's input conv): k = tap * 16 + c, zero-padded from 144 to 192 = three K-steps of four taps
+            # (lr_gemm_conv_f16's c16 gather)
+            self.w = torch.cat([self.w, self.w.new_zeros(self.w.shape[0], 192 - self.w.shape[1])], dim=1).contiguous()
         self.b = packing.pack_bias(conv.bias.detach(), self.w.shape[0]) if conv.bias is not None else None
         self.stride = conv.stride[0]
 

@@ -243,7 +243,11 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         Nw, Kw = wt.shape[1], wt.shape[0] * 64
     else:
         Nw, Kw = wt.shape[-2], wt.shape[-1]
-    assert Kw == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+    c16 = C1 == 16 and C2 == 0 and taps == 9 and Kw == 192      # 16-channel 3x3 source: K = 144 zero-padded to three K-steps
+    assert c16 or Kw == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+    if c16 and tile_m == 0 and tile_n == 0:
+        # only the pipelined 256-row instances gather 16-channel taps
+        tile_m, tile_n, splits = 256, (320 if Nw % 320 == 0 else 160 if Nw % 160 == 0 else 128), 1
     assert x1.shape[0] == B * Hs * Ws, (x1.shape, B, Hs, Ws)
     M = B * H * W
     n_out = Nw // 2 if geglu else Nw

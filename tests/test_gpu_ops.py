@@ -584,6 +584,37 @@ def test_gemm_piece_major_weights_are_bit_identical(tile):
                        ops.gemm_conv(a, packing.pack_pm(wl), B=1, H=1, W=300, taps=1, splits=1, wt_pm=True, **tile_kw(tile)))
 
 
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 8, 16, 320), (1, 16, 32, 128), (3, 9, 7, 320)])
+def test_conv_in_sixteen_channel_gather(N, H, W, Cout):
+    """The UNet's input conv (openaimodel.py:546: 9 -> model_channels, 3x3 pad 1) through the 16-channel gather of lr_gemm_conv_f16
+    (k = tap * 16 + c, four taps per K-step, K = 144 zero-padded to 192) instead of a 64-channel padded source: vs F.conv2d on the
+    same fp16 inputs, borders and ragged row tails included, and vs the 64-padded path."""
+    from leftrefill_amd import engine as E, ops
+    d = dev()
+    x = h16(G.T(f"c16.{H}.x", (N, 9, H, W)))
+    conv = torch.nn.Conv2d(9, Cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(h16(torch.from_numpy(weights.fill_like(f"c16.{Cout}.w", (Cout, 9, 3, 3)))))
+        conv.bias.copy_(torch.from_numpy(weights.fill_like(f"c16.{Cout}.b", (Cout,))))
+    ref = F.conv2d(x, conv.weight, conv.bias, padding=1)
+    p16, p64 = E.PackedConv(conv, cin_pad=16), E.PackedConv(conv, cin_pad=64)
+    assert p16.w.shape[1] == 192 and p64.w.shape[1] == 576
+    a16 = E.Act(ops.nchw_to_nhwc(x.to(d), cpad=16), N, H, W)
+    a64 = E.Act(ops.nchw_to_nhwc(x.to(d), cpad=64), N, H, W)
+    y16 = E.conv(a16, E_to(p16, d), gn_stats=False)
+    y64 = E.conv(a64, E_to(p64, d), gn_stats=False)
+    report(f"conv_in c16 {N}x{H}x{W}->{Cout}", from_tok(y16.tok, N, H, W)[:, :Cout], ref)
+    assert (y16.tok.float() - y64.tok.float()).abs().max().item() <= 2e-3
+    assert torch.equal(y16.tok, E.conv(a16, E_to(p16, d)).tok)
+
+
+def E_to(pc, d):
+    pc.w = pc.w.to(d)
+    if pc.b is not None:
+        pc.b = pc.b.to(d)
+    return pc
+
+
 def test_tile_plan_is_static_and_tiles_agree_bitwise():
     """The (tile, split-K) plan is a pure function of the shape (in-tree table or the static heuristic -- never timing),
     and with the split factor pinned every tile gives bit-identical results (same K order per output element)."""
