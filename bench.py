@@ -141,7 +141,7 @@ def kernel_roofline(model, batch, B, dump=None):
             out = orig[name](*a, **k)
             e1.record()
             if name == "gemm_conv":
-                desc = dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[0], K=a[1].shape[1], taps=k.get("taps", 1),
+                desc = dict(M=k["B"] * k["H"] * k["W"], N=a[1].shape[-2], K=a[1].shape[-1], taps=k.get("taps", 1),      # (per-sample weights: [B, N, K])
                             stride=k.get("stride", 1), up=k.get("up", 0), geglu=bool(k.get("geglu", False)),
                             cat=k.get("x2") is not None, resid=k.get("resid") is not None)
             elif name == "xattn_block":      # fused LayerNorm + to_q + 77-key attention + to_out + residual (level 0)

@@ -293,7 +293,10 @@ class UNetModel(nn.Module):
         plan["t0"] = E.PackedLinear(self.time_embed[0])
         plan["t2"] = E.PackedLinear(self.time_embed[2])
         # the 9 input channels travel as 16 (32 bytes per pixel, lr_gemm_conv_f16's 16-channel gather); wider inputs pad to 64s
-        cin_pad = 16 if self.in_channels <= 16 and os.environ.get("LEFTREFILL_CONV_IN_C16", "1") != "0" else max(64, ((self.in_channels + 63) // 64) * 64)
+        # (not for the separator-token variant, NVSUnetModel.use_sep: its input conv needs an input gradient, and the dgrad weights are
+        # derived from the [N][taps * C] layout)
+        c16 = self.in_channels <= 16 and not getattr(self, "use_sep", False) and os.environ.get("LEFTREFILL_CONV_IN_C16", "1") != "0"
+        cin_pad = 16 if c16 else max(64, ((self.in_channels + 63) // 64) * 64)
         plan["cin_pad"] = cin_pad
         res_list = []
 

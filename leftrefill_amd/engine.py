@@ -389,7 +389,7 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         seq = ops.mv_gather(x, b, v, s)
         Ls = pt.view_num * s * s
         st_seq = None
-        if st is not None and fold_ok(x):
+        if st is not None and fold_ok(x) and MV_LN_FOLD:
             # the rows' LayerNorm statistics take the same re-arrangement (8 bytes x parts per row; torch index glue), so the fused
             # QKV projection of the sequence folds its LayerNorm like every other block -- and stays bit-identical to the sharded path
             g = st.reshape(b, v, s, 2 * s, st.shape[1] * 2)
@@ -447,6 +447,8 @@ FFN_FUSED = __import__("os").environ.get("LEFTREFILL_FFN_FUSED", "1") != "0"
 # LayerNorm folded into the consuming GEMM (inference path); LEFTREFILL_LN_FOLD=0 runs the stand-alone LayerNorm kernel.
 LN_FOLD = __import__("os").environ.get("LEFTREFILL_LN_FOLD", "1") != "0"
 
+# LayerNorm fold in the re-arranged multi-view self-attention (fused and sharded forms); LEFTREFILL_MV_LN_FOLD=0: stand-alone LayerNorm
+MV_LN_FOLD = __import__("os").environ.get("LEFTREFILL_MV_LN_FOLD", "1") != "0"
 # One canvas per rank (torch.distributed world == view_num - 1): set by UNetModel when `mv_shard=True`.
 MV_SHARDED = False
 
@@ -471,7 +473,7 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
     pq = pt.attn1.qkv                                                         # rows [Wq; Wk; Wv] of the fused projection
     seq = lrd.mv_gather_sequence(x.reshape(N, L, C), s)                       # [N, Ls, C]
     own_x = lrd.mv_own_rows(seq, rank, s).reshape(N * L, C)                   # rows [target, ref_rank] (a view on rank 0, N = 1)
-    if st is not None and pq.wf is not None and fold_ok(x):
+    if st is not None and pq.wf is not None and fold_ok(x) and MV_LN_FOLD:
         parts = st.shape[1]
         st_seq = lrd.mv_gather_sequence(st.reshape(N, L, parts * 2), s)       # [N, Ls, parts * 2] fp32
         own_st = lrd.mv_own_rows(st_seq, rank, s).reshape(N * L, parts, 2).contiguous()
