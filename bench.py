@@ -810,9 +810,10 @@ def main():
                       "global_batch": replicas * B, "per_gpu_batch": B, "ddim_steps": S_DDIM, "cfg": CFG, "eta": ETA,
                       "parallelism": f"dp{world} (sample-sharded, no data-path collective)",
                       "ranks": world, "backend": backend,
-                      "note": "every DDIM step runs the full UNet at batch 2B (the exact shared-prefix optimisation of the sampler is OFF for this number); the only loop-invariant hoisted out of the step is the "
-                              "cross-attention K/V projection of the constant context (3.9 of 1850 GFLOP per sample per forward, "
-                              "0.2 %), computed once per sampling"},
+                      "note": "every DDIM step runs the full UNet at batch 2B (the exact shared-prefix optimisation of the sampler is OFF for this number); two loop-invariants are "
+                              "computed once per sampling, inside the timed region, instead of once per step: the cross-attention K/V projection of the constant "
+                              "context (3.9 of 1850 GFLOP per sample per forward, 0.2 %) and the timestep-embedding rows (time MLP + the 22 emb_layers: functions "
+                              "of the schedule alone, 50 rows in 4 batched launches; LEFTREFILL_EMB_TABLE=0 recomputes them every step, +0.09 ms per step)"},
            "per_unet_step_ms": unet_step_ms}
     if a.workload != "single":
         res["config"]["workload"] = (f"config 4 ({a.workload}): {MV_WORKLOADS[a.workload]}, {samples_per_step} sample(s) = {B} "

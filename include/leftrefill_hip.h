@@ -79,6 +79,17 @@ int lr_groupnorm_finalize(const float* p1, int C1, int R1, const float* p2, int 
  *   C % 32 == 0, C % 8 == 0, C <= 2048. */
 int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
                            const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
+/* ---- the UNet's `out` block in one launch (ABI 21) -------------------------------------------------------------------------
+ * replaces: `self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3,
+ *           padding=1)))` applied as `self.out(h)` (reference ldm/modules/diffusionmodules/openaimodel.py:714-718, 812) and the
+ *           NHWC -> NCHW conversion of its result: GroupNorm(32) + SiLU + 3x3 pad-1 conv to Cout <= 4 channels, input read once.
+ *   x [B][H][W][C] fp16 (NHWC tokens), gpart [B][chunks][32][2] per-group (sum, sumsq) partials of x from its producer
+ *   (lr_gemm_args.gn_group_out), gamma / beta [C] fp32; w [>= Cout][ldw] fp16 with k = tap * C + channel (the packed conv weight,
+ *   rows >= Cout ignored), bias [>= Cout] fp32 or NULL; y [B][Cout][H][W] fp16 (NCHW).  The normalised + SiLU'd activation is
+ *   rounded to fp16 before the product exactly like the two-launch path stores it.
+ *   C % 64 == 0, H % 8 == 0, W % 16 == 0, Cout <= 4, 9 C small enough for LDS (C <= 704): otherwise LR_E_UNSUPPORTED. */
+int lr_gn_conv_out_f16(const lr_half* x, int B, int H, int W, int C, const float* gpart, int chunks, const float* gamma, const float* beta,
+                       float eps, const lr_half* w, int ldw, const float* bias, int Cout, lr_half* y, lr_stream_t s);
 /* lr_groupnorm_apply with an explicit chunk count of `partials` ([N][nchunks][32][2]) */
 int lr_groupnorm_apply_n(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
                          int nchunks, const float* gamma, const float* beta, float eps, int silu, lr_half* y, lr_stream_t s);
@@ -365,6 +376,8 @@ int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s,
 int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
 int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
                             const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
+int lr_gn_conv_out_bf16(const lr_half* x, int B, int H, int W, int C, const float* gpart, int chunks, const float* gamma, const float* beta,
+                        float eps, const lr_half* w, int ldw, const float* bias, int Cout, lr_half* y, lr_stream_t s);
 int lr_attention_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int
     ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
 int lr_attention_causal_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half*

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "lr_gemm_gn_group_chunks": [ctypes.POINTER(GemmArgs)],
     "lr_gn_fold_weights_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p],
+    "lr_gn_conv_out_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
+                           c_int, c_void_p, c_void_p],
     "lr_groupnorm_finalize": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "lr_groupnorm_apply_n": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float,
                              c_int, c_void_p, c_void_p],
@@ -126,7 +128,7 @@ BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n"
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
               "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",
-              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_gn_fold_weights_f16"]
+              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_gn_fold_weights_f16", "lr_gn_conv_out_f16"]
 
 
 def twin(name):

@@ -130,13 +130,20 @@ __device__ __forceinline__ vec8<T> load_q(const T* p, const float c) {
   return q;
 }
 
-// VT = true: P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below):
-// the V tile then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment
-// is ONE ds_read_b128.
+// VM = how the V tile reaches the PV product's A operand (V^T fragments: lane = one d row, 8 k-slots = keys):
+//   0  V [key][d] is loaded into registers, transposed there and written to LDS as [d][key] (packed key pairs);
+//   1  P.v is the pre-transposed, key-permuted V^T produced by lr_transpose_v_f16 ([B][heads*64][ldv], see below): the V tile
+//      then takes the same LDS-DMA + XOR-swizzle path as K (no registers, no VALU packing) and every PV fragment is ONE ds_read_b128;
+//   2  V stays [key][d] all the way: LDS-DMA like K, and the fragment is gathered by the LDS transpose read of gfx950
+//      (ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block, 8 bytes per lane, and every lane receives ONE d column of
+//      the four keys).  The four keys of a read are exactly one k-slot group of the S^T accumulator (key0 .. key0 + 3), so two reads
+//      make a fragment and no transposed / permuted copy of V exists anywhere.  16-byte chunk c of row r sits in slot
+//      c ^ (4 ((r >> 1) & 1)): the four rows of a read (128 bytes apart) then cover 64 distinct banks per half-wave.
 // CAUSAL = true: key j is visible to query i only if j <= i (the text tower's attn_mask); every tile takes the masked path.
 // EXACT = true: unscaled Q, softmax_block<FOLD = false> (the training forward with its log-sum-exp output).
-template <typename T, bool VT, bool CAUSAL = false, bool EXACT = false>
+template <typename T, int VM, bool CAUSAL = false, bool EXACT = false>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams<T> P) {
+  constexpr bool VT = VM == 1, TR = VM == 2;
 #ifdef LR_ATTN_NOFOLD      // developer A/B build (tools/build_variant.sh nofold -DLR_ATTN_NOFOLD)
   constexpr bool FOLD = false;
 #else
@@ -203,6 +210,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Vs + rbase * 128), 16, 0, 0);
     }
   };
+  // natural V staging (TR): rows = keys like K; chunk slot = chunk ^ 4 ((row >> 1) & 1) (see the header of this kernel)
+  auto stage_vn = [&](int buf, int tile) {
+    char* Vs = Vsm + buf * (64 * VT_PITCH);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (i * 4 + w) * 8;
+      const int row = rbase + (lane >> 3);
+      const int key = tile * ATT_KB + row;
+      const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+      const T* g = key < P.Nkv ? vp + (size_t)key * P.ldv + chunk * 8 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Vs + rbase * 128), 16, 0, 0);
+    }
+  };
+  // per-lane byte offset of its 8 bytes inside a [4 keys][16 d] block of the transpose read: lane i of a 16-lane group supplies
+  // key j = i >> 2, d columns 4 (i & 3) .. + 3; the group's d base is 16 ((lane >> 4) & 1) (+ 32 db), its key base 4 hi (+ ...)
+  const int tr_j = (lane & 15) >> 2, tr_q = lane & 3;
+  const int tr_off = (4 * hi + tr_j) * 128 + (tr_q & 1) * 8;
+  const int tr_chunk = 2 * ((lane >> 4) & 1) + (tr_q >> 1);      // + 4 db, then ^ 4 (tr_j >> 1)
   // V staging through registers: thread owns key pair kpair = w*8 + lane/8 and d-chunk j = lane%8
   const int vj = lane & 7, vkp = w * 8 + (lane >> 3);
   auto load_v = [&](int tile, uint4& v0, uint4& v1) {
@@ -239,6 +264,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   stage_k(0, 0);
   if constexpr (VT) {
     stage_vt(0, 0);
+  } else if constexpr (TR) {
+    stage_vn(0, 0);
   } else {
     uint4 v0, v1;
     load_v(0, v0, v1);
@@ -256,6 +283,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     if (more) {
       stage_k(cur ^ 1, tile + 1);
       if constexpr (VT) stage_vt(cur ^ 1, tile + 1);
+      else if constexpr (TR) stage_vn(cur ^ 1, tile + 1);
       else load_v(tile + 1, nv0, nv1);
     }
     const char* Ks = Ksm + cur * (ATT_KB * 128);
@@ -306,6 +334,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           if constexpr (VT) {
             const int vc = kb * 4 + tt * 2 + hi;     // 16-byte chunk = this lane's 8 k-slots, contiguous after the permute
             vf = *reinterpret_cast<const vec8<T>*>(Vs + drow * 128 + ((vc ^ ((drow >> 1) & 7)) << 4));
+          } else if constexpr (TR) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+            const char* a = Vs + (kb * 32 + 16 * tt) * 128 + tr_off + (((4 * db + tr_chunk) ^ ((tr_j >> 1) << 2)) << 4);
+            const vec4<T> va = __builtin_bit_cast(vec4<T>, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)a));
+            const vec4<T> vb = __builtin_bit_cast(vec4<T>, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(a + 8 * 128)));
+            vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+            vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
           } else {
             const int key0 = kb * 32 + 16 * tt + 4 * hi;
             const vec4<T> va = *reinterpret_cast<const vec4<T>*>(Vs + drow * VT_PITCH + key0 * 2);
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
           for (int qb = 0; qb < 2; ++qb)
             oacc[qb][db] = lr_mfma32(vf, pf[qb][kb][tt], oacc[qb][db]);
         }
-    if constexpr (!VT) {
+    if constexpr (VM == 0) {
       if (more) write_v(cur ^ 1, nv0, nv1);
     }
     __syncthreads();
@@ -605,6 +641,12 @@ static int attn_pp_mode() {
   return v ? atoi(v) : 0;
 }
 
+// developer switch: LR_ATTN_TR=0 sends natural-layout V through the register transpose (VM = 0) instead of the LDS transpose read
+static bool attn_tr_mode() {
+  const char* v = getenv("LR_ATTN_TR");
+  return v ? atoi(v) != 0 : true;
+}
+
 template <typename T>
 static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                             int ldo, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s, bool vt,
@@ -637,9 +679,10 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   }
   if (lse) {      // training forward: exact scale handling, the backward recomputes P from the unscaled operands and this log-sum-exp
     if (vt) return LR_E_UNSUPPORTED;
-    hipLaunchKernelGGL((attention_kernel<T, false, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
-  } else if (vt) hipLaunchKernelGGL((attention_kernel<T, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
-  else hipLaunchKernelGGL((attention_kernel<T, false>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+    hipLaunchKernelGGL((attention_kernel<T, 0, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  } else if (vt) hipLaunchKernelGGL((attention_kernel<T, 1>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  else if (attn_tr_mode()) hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }
 
@@ -663,7 +706,7 @@ static int lr_attention_causal_t(const lr_half* q, int ldq, const lr_half* k, in
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = nullptr;
-  hipLaunchKernelGGL((attention_kernel<T, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  hipLaunchKernelGGL((attention_kernel<T, 0, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }
 

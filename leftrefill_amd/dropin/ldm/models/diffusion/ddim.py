@@ -82,6 +82,7 @@ class DDIMSampler(object):
         time_range = np.flip(steps)
         total_steps = steps.shape[0]
         self._prepare_cfg_inputs(cond, unconditional_conditioning, unconditional_guidance_scale)
+        self._prepare_timesteps(time_range)
         for i, step in enumerate(time_range):
             index = total_steps - i - 1          # bit-identical step indexing (ddim.py:254)
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
@@ -90,9 +91,13 @@ class DDIMSampler(object):
                 img = self.model.q_sample(x0, ts) * mask + (1. - mask) * img
             if ucg_schedule is not None:
                 unconditional_guidance_scale = ucg_schedule[i]
-            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
-                                              unconditional_guidance_scale=unconditional_guidance_scale,
-                                              unconditional_conditioning=unconditional_conditioning)
+            self._step_hint(step)
+            try:
+                img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                                  unconditional_conditioning=unconditional_conditioning)
+            finally:
+                self._step_hint(None)
             if callback:
                 callback(i)
             if img_callback:
@@ -125,17 +130,22 @@ class DDIMSampler(object):
             end = int(min(timesteps / steps.shape[0], 1) * steps.shape[0]) - 1
             steps = steps[:end]
         total_steps = steps.shape[0]
+        self._prepare_timesteps(steps)
         for i, step in enumerate(np.flip(steps)):
             index = total_steps - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             if ucg_schedule is not None:
                 unconditional_guidance_scale = ucg_schedule[i]
             new_img = []
-            for img_, cond_, uc_ in zip(img, cond, ucs):
-                x_prev, _ = self.p_sample_ddim(img_, cond_, ts, index=index, temperature=temperature,
-                                               unconditional_guidance_scale=unconditional_guidance_scale,
-                                               unconditional_conditioning=uc_)
-                new_img.append(x_prev)
+            self._step_hint(step)
+            try:
+                for img_, cond_, uc_ in zip(img, cond, ucs):
+                    x_prev, _ = self.p_sample_ddim(img_, cond_, ts, index=index, temperature=temperature,
+                                                   unconditional_guidance_scale=unconditional_guidance_scale,
+                                                   unconditional_conditioning=uc_)
+                    new_img.append(x_prev)
+            finally:
+                self._step_hint(None)
             order = list(range(K))
             random.shuffle(order)                 # same RNG consumption and same pick as shuffling the K tensors
             half = new_img[0].shape[-1] // 2
@@ -146,6 +156,21 @@ class DDIMSampler(object):
             if callback:
                 callback(i)
         return img[0], {}
+
+    def _unet(self):
+        return getattr(getattr(self.model, "model", None), "diffusion_model", None)
+
+    def _prepare_timesteps(self, steps):
+        """The schedule is known before the first step: the UNet computes the embedding rows of all its timesteps in one go
+        (UNetModel.prepare_timesteps) and each step names its timestep on the host (`_step_hint`)."""
+        unet = self._unet()
+        if hasattr(unet, "prepare_timesteps"):
+            unet.prepare_timesteps(int(s_) for s_ in steps)
+
+    def _step_hint(self, step):
+        unet = self._unet()
+        if hasattr(unet, "prepare_timesteps"):
+            unet._t_host = None if step is None else int(step)
 
     # the conditioning is constant over the loop: build the [uncond; cond] batch once instead of 50 torch.cat calls
     def _prepare_cfg_inputs(self, c, uc, scale):

@@ -26,6 +26,9 @@ from leftrefill_amd import train_ops as ops     # == leftrefill_amd.ops unless a
 from ldm.modules.attention import SpatialTransformer
 from ldm.modules.diffusionmodules.util import conv_nd, linear, normalization, zero_module
 
+# a sampler's per-timestep embedding rows computed once per sampling (UNetModel.prepare_timesteps); 0 = recompute them every step
+EMB_TABLE = os.environ.get("LEFTREFILL_EMB_TABLE", "1") != "0"
+
 
 class TimestepBlock(nn.Module):
     """Any module whose forward takes the timestep embedding as second argument."""
@@ -357,7 +360,8 @@ class UNetModel(nn.Module):
             o, ot, xk, xvt = (None,) * 4 if out is None else (tuple(out[i]) + (None, None))[:4]
             kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=N * L, taps=1, out=o)
             C = kv.shape[1] // 2
-            ent = (kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot))   # V^T: the V tile streams by LDS-DMA
+            # V^T copy for lr_attention_vt_f16 (none when the kernel reads V with the LDS transpose read, ops.ATTN_VT = 0)
+            ent = (kv, ops.transpose_v(kv[:, C:], N, pt.attn2.heads, L, out=ot) if ops.ATTN_VT else None)
             if pt.attn2.xk is not None and L <= ops.XATTN_MAX_KEYS:
                 # operands of the fused cross-attention block: K in its k-slot order, V^T pack
                 ent += (ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=N * L, taps=1, out=xk),
@@ -372,20 +376,58 @@ class UNetModel(nn.Module):
     def _block_out(self, act, state):
         return act
 
-    def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False, c_input=None):
+    def _embed(self, timesteps):
+        """timesteps [M] int64 -> [M, sum Cout]: sinusoidal embedding, time MLP (reference openaimodel.py:775-776) and the
+        emb_layers projection of every ResBlock (266) as one batched GEMV.  A row depends on its own timestep only."""
+        P = self._plan
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels, self.compute_dtype)
+        e = ops.linear_small_m(t_emb, P["t0"].w, P["t0"].b, act_out=True)
+        emb = ops.linear_small_m(e, P["t2"].w, P["t2"].b)
+        return ops.linear_small_m(emb, P["emb_w"], P["emb_b"], act_in=True)
+
+    def prepare_timesteps(self, steps):
+        """Embedding rows of every timestep of one sampling, computed up front (16 timesteps per launch).  The rows are functions
+        of the timestep alone -- not of x, not of the sample -- and a sampler knows its schedule before the first step, so the
+        50 x 3 weight-streaming launches (56 MB each step) of the loop become 4 x 3 per sampling.  `forward` uses a row only when
+        the sampler also names the step's timestep on the host (`_t_host`); any other caller gets the embedding computed from
+        its `timesteps` tensor as before.  Row arithmetic does not depend on the number of rows in a launch: bit-identical."""
+        self.prepare()
+        if not EMB_TABLE:
+            self._emb_table = {}
+            return
+        steps = [int(s_) for s_ in dict.fromkeys(int(s_) for s_ in steps)]
+        dev = next(self.parameters()).device
+        table = {}
+        with torch.no_grad():
+            for i in range(0, len(steps), 16):
+                chunk = steps[i:i + 16]
+                rows = self._embed(torch.tensor(chunk, device=dev, dtype=torch.int64))
+                for j, s_ in enumerate(chunk):
+                    table[s_] = rows[j]
+        self._emb_table = table
+
+    def _emb_rows(self, timesteps, N, out=None):
+        """[N, sum Cout] embedding of this call: the precomputed row of the host-named timestep, else computed from `timesteps`."""
+        hint = self.__dict__.get("_t_host")
+        row = self.__dict__.get("_emb_table", {}).get(hint) if hint is not None else None
+        if row is not None and row.dtype == self.compute_dtype:
+            rows = row.unsqueeze(0).expand(N, -1)
+            return rows.contiguous() if out is None else out.copy_(rows)
+        rows = self._embed(timesteps)
+        return rows if out is None else out.copy_(rows)
+
+    def _run_plan(self, x, timesteps, context, kv_cache=None, shared_prefix=False, c_input=None, emb_all=None):
         """x [N,Cin,H,W] fp32, timesteps [N] int64, context [N,L,D] fp16 -> eps [N,Cout,H,W] fp16.
         shared_prefix: x[:N/2] == x[N/2:] and timesteps likewise (see `cfg_shared_prefix`).
         c_input: optional [N, model_channels, H, W (or W/2: right half)] added to the output of the first input block
-        (reference NVS_ldm.py:64-68)."""
+        (reference NVS_ldm.py:64-68).  emb_all: [N, sum Cout] embedding rows if the caller has them (`_emb_rows`)."""
         P = self._plan
         E = engine
         N, _, H, W = x.shape
         L = context.shape[1]
         ctx = context.reshape(N * L, context.shape[2])
-        t_emb = ops.timestep_embedding(timesteps, self.model_channels, self.compute_dtype)
-        e = ops.linear_small_m(t_emb, P["t0"].w, P["t0"].b, act_out=True)
-        emb = ops.linear_small_m(e, P["t2"].w, P["t2"].b)
-        emb_all = ops.linear_small_m(emb, P["emb_w"], P["emb_b"], act_in=True)   # [N, sum Cout]
+        if emb_all is None:
+            emb_all = self._embed(timesteps)       # [N, sum Cout]
 
         # Training: the reference's `use_checkpoint` (set by every LeftRefill config) keeps only each block's inputs and
         # recomputes the block in the backward (CheckpointFunction, ldm/modules/diffusionmodules/util.py:102-151) -- a memory
@@ -470,8 +512,13 @@ class UNetModel(nn.Module):
             act, bstate = self._block_in(E.Act(act.tok, act.N, act.H, act.W, tok2=skip.tok, gs=act.gs, gs2=skip.gs), steps)   # virtual th.cat([h, hs.pop()], 1)
             act = self._block_out(run(steps, act), bstate)
             tap(f"out{i}", act)
-        act = E.gn(act, P["out_norm"], True)
-        act = E.conv(act, P["out_conv"])
+        pn, pc = P["out_norm"], P["out_conv"]
+        if (act.tok2 is None and act.gs is not None and act.gs[2] is not None and E.gn_fuse_ok(act.tok) and pc.taps == 9
+                and ops.gn_conv_out_ok(act.H, act.W, act.tok.shape[1], self.out_channels)):
+            # `self.out` (reference 714-718, 812) in one launch: GroupNorm + SiLU + conv to 4 channels + NCHW, input read once
+            return ops.gn_conv_out(act.tok, N, act.H, act.W, pn.g, pn.b, pn.eps, act.gs[2], act.gs[3], pc.w, pc.b, self.out_channels)
+        act = E.gn(act, pn, True)
+        act = E.conv(act, pc)
         return ops.nhwc_to_nchw(act.tok, N, act.H, act.W, self.out_channels)
 
     def _needs_autograd(self, context, c_input=None):
@@ -510,7 +557,8 @@ class UNetModel(nn.Module):
             # eager inference: the same launches as the captured step (per-context K / V operands computed first), so the
             # two modes stay bit-identical.  (c_input / separator tokens of the NVS UNet: eager only.)
             with torch.no_grad():
-                return self._run_plan(x, timesteps, context, self._context_kv(context), c_input=c_input)
+                return self._run_plan(x, timesteps, context, self._context_kv(context), c_input=c_input,
+                                      emb_all=self._emb_rows(timesteps, x.shape[0]))
         shared = bool(self.cfg_shared_prefix)
         key = (tuple(x.shape), tuple(context.shape), x.device.index, self.compute_dtype, shared, getattr(self, "_graph_slot", 0),
                bool(engine.MV_SHARDED))
@@ -536,16 +584,19 @@ class _StepGraph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.kv = model._context_kv(self.ctx)                  # static per-context buffers
-            model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix)     # warm-up: kernel attributes / tile autotune
+            self.emb = model._embed(self.t).contiguous()           # static buffer of the step's embedding rows, filled per replay
+            model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix, emb_all=self.emb)   # warm-up: kernel attributes
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix)
+            self.out = model._run_plan(self.x, self.t, self.ctx, self.kv, shared_prefix, emb_all=self.emb)
 
     def replay(self, x, t, ctx, ctx_src):
         self.x.copy_(x)
-        self.t.copy_(t)
+        # the embedding rows are inputs of the captured step: a sampler's precomputed row (UNetModel.prepare_timesteps), else
+        # the same three launches the eager path runs, in front of the replay
+        self.model._emb_rows(t, x.shape[0], out=self.emb)
         # Same context tensor object, not modified in place since last time -> K/V projections are still valid.
         # Holding a reference to the source tensor keeps its storage alive, so identity cannot be a recycled address.
         if self.ctx_src is None or self.ctx_src[0] is not ctx_src or self.ctx_src[1] != ctx_src._version:

@@ -166,6 +166,32 @@ def group_norm_groups(x1, N, HW, gamma, beta, eps, silu, gp, chunks):
     return y
 
 
+OUT_FUSED = os.environ.get("LEFTREFILL_OUT_FUSED", "1") != "0"   # the UNet's `out` block as one launch (lr_gn_conv_out_f16)
+
+
+def gn_conv_out_ok(H, W, C, cout):
+    """Shapes lr_gn_conv_out_f16 takes (anything else keeps GroupNorm -> conv -> layout conversion)."""
+    return OUT_FUSED and 1 <= cout <= 4 and C % 64 == 0 and 64 <= C <= 704 and H % 8 == 0 and W % 16 == 0
+
+
+def gn_conv_out(x, N, H, W, gamma, beta, eps, gp, chunks, w, bias, cout):
+    """GroupNorm(32) + SiLU + 3x3 pad-1 conv to cout <= 4 channels + NHWC -> NCHW in one launch (the UNet's `out` block,
+    reference openaimodel.py:714-718).  x [N*H*W, C] 16-bit tokens, gp [N, chunks, 32, 2] group partials of x from its producer,
+    w [>= cout, 9*C] packed conv weight (k = tap * C + channel), bias fp32 | None -> [N, cout, H, W] in x's dtype."""
+    lib = _lib.load()
+    _chk16(x, "x")
+    _chk16(w, "w")
+    C = x.shape[1]
+    assert x.shape[0] == N * H * W and gn_conv_out_ok(H, W, C, cout), (x.shape, N, H, W, cout)
+    assert gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (N, chunks, 32, 2), (gp.shape, N, chunks)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    assert w.dtype == x.dtype and w.shape[0] >= cout and w.shape[1] == 9 * C and (bias is None or (bias.dtype == torch.float32 and bias.numel() >= cout))
+    y = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+    _lib.check(_fn(lib, "lr_gn_conv_out_f16", x.dtype)(_p(x), N, H, W, C, _p(gp), chunks, _p(gamma), _p(beta), float(eps), _p(w), w.stride(0),
+                                                       _p(bias), cout, _p(y), _stream()), "gn_conv_out")
+    return y
+
+
 def gn_fold_weights(gp, chunks, N, HW, gamma, beta, eps, w, bias):
     """Per-sample copies of a pointwise layer's weights with GroupNorm(32, affine) folded in (lr_gn_fold_weights_f16):
     w [Nout, C] 16-bit, bias [Nout] fp32 | None -> (w_b [N, Nout, C], bias_b [N, Nout] fp32); gp / chunks as in group_norm_groups."""
@@ -402,6 +428,9 @@ def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
 
 
 VT_MIN_KEYS = int(os.environ.get("LEFTREFILL_VT_MIN_KEYS", "1024"))   # pre-transpose V for key sequences at least this long
+# 0: V stays in its natural [key][d] layout everywhere (the kernel gathers PV fragments with the LDS transpose read) -- no
+# lr_transpose_v_f16 copies, cached `vt` operands are ignored
+ATTN_VT = os.environ.get("LEFTREFILL_ATTN_VT", "1") != "0"
 
 
 def transpose_v(v, B, heads, Nkv, out=None):
@@ -425,7 +454,9 @@ def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
         assert t_.is_cuda and t_.dtype == q.dtype and q.dtype in HALF_TYPES and t_.stride(1) == 1
     if out is None:
         out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=q.dtype)
-    if vt is None and Nkv >= VT_MIN_KEYS:
+    if not ATTN_VT:
+        vt = None
+    elif vt is None and Nkv >= VT_MIN_KEYS:
         vt = transpose_v(v, B, heads, Nkv)
     if vt is not None:
         _lib.check(_fn(lib, "lr_attention_vt_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),

@@ -517,6 +517,42 @@ def test_groupnorm_group_sums_at_unet_widths(C, HW, tile):
     assert torch.equal(out, ops.group_norm_groups(y, N, HW, gam.to(d), bet.to(d), 1e-5, True, gp, chunks))
 
 
+@pytest.mark.parametrize("N,H,W,C,cout,chunks", [(2, 16, 32, 320, 4, 2), (1, 8, 16, 64, 3, 1), (3, 24, 48, 128, 1, 4), (2, 64, 128, 320, 4, 32)],
+                         ids=lambda v: str(v))
+def test_out_block_groupnorm_silu_conv_one_launch(N, H, W, C, cout, chunks):
+    """lr_gn_conv_out_f16 = `self.out(h)` of the UNet (reference openaimodel.py:714-718, 812: GroupNorm32 -> SiLU -> 3x3 conv to
+    out_channels) incl. the NCHW conversion, against F.conv2d(F.silu(F.group_norm(x))) in fp32 on the same 16-bit inputs (the
+    normalised activation rounded to fp16 like the two-launch path stores it); image borders (zero padding of the ACTIVATED tensor),
+    tiles at every edge, fewer than 4 output channels; the headline shape; and agreement with the two-launch HIP path."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    HW = H * W
+    x = h16(G.T(f"outb.{N}.{H}.{C}.x", (N * HW, C)) * 1.5 + 0.4)
+    wc = torch.from_numpy(weights.fill_like(f"outb.{C}.{cout}.w", (cout, C, 3, 3))) * 3.0
+    bc = torch.from_numpy(weights.fill_like(f"outb.{C}.{cout}.b", (cout,))) + 0.1
+    gam = 1.0 + 0.3 * G.T(f"outb.{C}.g", (C,))
+    bet = 0.2 * G.T(f"outb.{C}.be", (C,))
+    wp = packing.pack_conv(wc, dtype=torch.float16).to(d)          # [64, 9 C], k = tap * C + channel
+    bp = packing.pack_bias(bc).to(d)
+    xd = x.half().to(d)
+    xg = xd.double().reshape(N, chunks, HW // chunks, 32, C // 32)      # the producer's per-group partial sums
+    gp = torch.stack([xg.sum((2, 4)), (xg * xg).sum((2, 4))], dim=-1).float().contiguous()
+    out = ops.gn_conv_out(xd, N, H, W, gam.to(d), bet.to(d), 1e-5, gp, chunks, wp, bp, cout)
+    assert out.shape == (N, cout, H, W) and out.dtype == torch.float16
+    xn = F.silu(F.group_norm(x.reshape(N, H, W, C).permute(0, 3, 1, 2), 32, gam, bet, 1e-5))
+    ref = F.conv2d(h16(xn).to(d), h16(wc).to(d), bc.to(d), padding=1).cpu()
+    report(f"out block N{N} {H}x{W} C{C} -> {cout}", out, ref, atol=2e-3)
+    assert torch.equal(out, ops.gn_conv_out(xd, N, H, W, gam.to(d), bet.to(d), 1e-5, gp, chunks, wp, bp, cout))
+    # the two-launch path on the same operands: same normalised fp16 activation, same products, another summation order
+    yn = ops.group_norm_groups(xd, N, HW, gam.to(d), bet.to(d), 1e-5, True, gp, chunks)
+    y2 = ops.nhwc_to_nchw(ops.gemm_conv(yn, wp, B=N, H=H, W=W, taps=9, bias=bp), N, H, W, cout)
+    assert (out.float() - y2.float()).abs().max().item() <= 2e-3 * max(1.0, y2.float().abs().max().item())
+    with pytest.raises(RuntimeError):          # a width that is not a whole number of 16-pixel tiles: refused, never silently wrong
+        ops._lib.check(ops._fn(ops._lib.load(), "lr_gn_conv_out_f16", xd.dtype)(xd.data_ptr(), N, H, W - 8, C, gp.data_ptr(), chunks,
+                                                                                 gam.to(d).data_ptr(), bet.to(d).data_ptr(), 1e-5, wp.data_ptr(),
+                                                                                 wp.stride(0), bp.data_ptr(), cout, out.data_ptr(), 0), "gn_conv_out")
+
+
 @pytest.mark.parametrize("C,HW", [(320, 2048), (640, 512), (320, 256)])
 def test_groupnorm_folded_into_pointwise_gemm(C, HW):
     """SpatialTransformer.norm folded into proj_in (lr_gn_fold_weights_f16 + lr_gemm_args.wt_bstride, attention.py:399-408): the GEMM on

@@ -100,6 +100,48 @@ def test_sample_is_deterministic_and_graph_reused():
     assert len(m.model.diffusion_model._graphs) >= 1
 
 
+def test_sampler_timestep_table_is_bit_identical(monkeypatch):
+    """DDIMSampler has the UNet compute the embedding rows (time MLP + emb_layers, reference openaimodel.py:775-776, 266) of all
+    its timesteps before the loop and names each step's timestep on the host: same samples, bit for bit, as computing them from
+    the `timesteps` tensor in every step -- in the captured-graph mode and in eager mode -- and the table is consulted at all."""
+    from ldm.modules.diffusionmodules import openaimodel as om
+    dev = torch.device("cuda:0")
+    m, cfg = model(dev)
+    B, h, w = 1, 8, 16
+    x_T = G.T("tt.x_T", (B, 4, h, w)).to(dev)
+    cond = {"c_concat": [G.T("tt.cc", (B, 5, h, w)).to(dev)], "c_crossattn": [G.T("tt.c", (B, 77, cfg.context_dim)).to(dev)]}
+    uc = {"c_concat": cond["c_concat"], "c_crossattn": [G.T("tt.uc", (B, 77, cfg.context_dim)).to(dev)]}
+    unet = m.model.diffusion_model
+    outs = {}
+    try:
+        for graph in (True, False):
+            unet.use_hip_graph = graph
+            for table in (True, False):
+                monkeypatch.setattr(om, "EMB_TABLE", table)
+                unet._graphs.clear()
+                torch.manual_seed(7)
+                outs[graph, table], _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=20, eta=1.0, x_T=x_T,
+                                                    unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+                assert (len(unet._emb_table) == 20) == table
+                assert unet._t_host is None
+        ref = outs[True, False]
+        assert all(torch.equal(o, ref) for o in outs.values())
+        # a caller that does not go through the sampler (no host hint) gets the embedding of ITS timesteps, table or not
+        monkeypatch.setattr(om, "EMB_TABLE", True)
+        unet.prepare_timesteps([999, 500])
+        x = torch.cat([x_T, x_T])
+        ctx = torch.cat([uc["c_crossattn"][0], cond["c_crossattn"][0]]).half()
+        xin = torch.cat([x, torch.cat([cond["c_concat"][0]] * 2)], 1)
+        e1 = unet(xin, torch.full((2,), 321, device=dev), ctx)
+        unet._emb_table = {}
+        e2 = unet(xin, torch.full((2,), 321, device=dev), ctx)
+        assert torch.equal(e1, e2)
+    finally:
+        unet.use_hip_graph = True
+        unet._emb_table = {}
+        unet._graphs.clear()
+
+
 def test_sampler_shared_prefix_matches_full_cfg(monkeypatch):
     """DDIMSampler sets UNetModel.cfg_shared_prefix for its [x; x] CFG batches when the non-context conditioning of uncond
     and cond is identical: same samples, bit for bit, as with LEFTREFILL_CFG_SHARED_PREFIX=0; and it does NOT set it when
@@ -114,9 +156,9 @@ def test_sampler_shared_prefix_matches_full_cfg(monkeypatch):
     seen = []
     orig = unet._run_plan
 
-    def spy(x, t, c, kv=None, shared_prefix=False):
+    def spy(x, t, c, kv=None, shared_prefix=False, **kw):
         seen.append(bool(shared_prefix))
-        return orig(x, t, c, kv, shared_prefix)
+        return orig(x, t, c, kv, shared_prefix, **kw)
     unet._run_plan = spy
     try:
         outs = {}

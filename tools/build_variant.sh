@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 out=leftrefill_amd/lib/variants; mkdir -p $out /tmp/lrv_$name
 objs=""
-for s in norm elementwise gemm_conv attention attention_bwd xattn_block ffn_block; do
+for s in norm elementwise gemm_conv attention attention_bwd xattn_block ffn_block conv_out; do
   extra=""
   case $s in attention|attention_bwd|xattn_block|ffn_block) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $extra "$@" -c leftrefill_amd/csrc/$s.hip -o /tmp/lrv_$name/$s.o &

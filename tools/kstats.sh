@@ -19,7 +19,7 @@ for r in rows:
     if "at::native" in name or "rocclr" in name or "rocblas" in name:
         continue
     tot += ns
-    if ns / steps > 20e3:
+    if ns / steps > 8e3:
         print(f"{name[:70]:70s} calls/step {int(r['Calls']) / steps:6.1f}  us/step {ns / steps / 1e3:8.1f}  avg us {float(r['AverageNs']) / 1e3:7.1f}")
 print(f"total kernel time per step {tot / steps / 1e6:.3f} ms")
 PY
