@@ -679,7 +679,7 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   }
   if (lse) {      // training forward: exact scale handling, the backward recomputes P from the unscaled operands and this log-sum-exp
     if (vt) return LR_E_UNSUPPORTED;
-    hipLaunchKernelGGL((attention_kernel<T, 0, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+    hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   } else if (vt) hipLaunchKernelGGL((attention_kernel<T, 1>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   else if (attn_tr_mode()) hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
@@ -706,7 +706,7 @@ static int lr_attention_causal_t(const lr_half* q, int ldq, const lr_half* k, in
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = nullptr;
-  hipLaunchKernelGGL((attention_kernel<T, 0, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  hipLaunchKernelGGL((attention_kernel<T, 2, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }
 

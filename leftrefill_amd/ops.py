@@ -428,9 +428,11 @@ def _tune_tiles(lib, a, device, geglu, no_split, want_stats, reps=4, rounds=2):
 
 
 VT_MIN_KEYS = int(os.environ.get("LEFTREFILL_VT_MIN_KEYS", "1024"))   # pre-transpose V for key sequences at least this long
-# 0: V stays in its natural [key][d] layout everywhere (the kernel gathers PV fragments with the LDS transpose read) -- no
-# lr_transpose_v_f16 copies, cached `vt` operands are ignored
-ATTN_VT = os.environ.get("LEFTREFILL_ATTN_VT", "1") != "0"
+# 0 (default): V stays in its natural [key][d] layout (lr_attention_f16 gathers the PV fragments with the LDS transpose read of gfx950):
+# no lr_transpose_v_f16 copy in front of long-sequence attention, no cached V^T of the context.  1: the round-1..3 path (pre-transposed,
+# key-permuted V^T through lr_attention_vt_f16 from VT_MIN_KEYS keys up).  Measured (profiles/r04_attn_tr.txt): the kernel itself is
+# 1-2 % slower on natural V, the copy it saves costs 11-18 us per launch -- 8192^2: 693 vs 681 + 18 us, 2048^2: 115 vs 113 + 13 us.
+ATTN_VT = os.environ.get("LEFTREFILL_ATTN_VT", "0") != "0"
 
 
 def transpose_v(v, B, heads, Nkv, out=None):
@@ -447,16 +449,14 @@ def transpose_v(v, B, heads, Nkv, out=None):
 def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     """q [B*Nq, >=heads*64] (row stride = ldq), k/v [B*Nkv, ...]; returns [B*Nq, heads*64] fp16.
 
-    q/k/v may be column slices of a fused projection (strided rows, unit column stride).  Long key sequences go through
-    the pre-transposed-V kernel (vt: optional cached result of transpose_v, e.g. for a fixed context)."""
+    q/k/v may be column slices of a fused projection (strided rows, unit column stride).  vt: optional transpose_v(v) -- the
+    pre-transposed-V kernel runs when it is given (or, with ATTN_VT, made here for long key sequences)."""
     lib = _lib.load()
     for t_ in (q, k, v):
         assert t_.is_cuda and t_.dtype == q.dtype and q.dtype in HALF_TYPES and t_.stride(1) == 1
     if out is None:
         out = torch.empty(B * Nq, heads * 64, device=q.device, dtype=q.dtype)
-    if not ATTN_VT:
-        vt = None
-    elif vt is None and Nkv >= VT_MIN_KEYS:
+    if vt is None and ATTN_VT and Nkv >= VT_MIN_KEYS:
         vt = transpose_v(v, B, heads, Nkv)
     if vt is not None:
         _lib.check(_fn(lib, "lr_attention_vt_f16", q.dtype)(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),

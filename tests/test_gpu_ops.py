@@ -38,6 +38,30 @@ def from_tok(y, N, H, W):
     return y.float().cpu().reshape(N, H, W, -1).permute(0, 3, 1, 2)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def v_path(mode):
+    """How V reaches the PV product of ops.attention: "tr" = natural V + LDS transpose read (lr_attention_f16, the default), "vt" =
+    lr_transpose_v_f16 + lr_attention_vt_f16 for every length, "reg" = natural V transposed in registers (LR_ATTN_TR=0)."""
+    from leftrefill_amd import ops
+    old = (ops.VT_MIN_KEYS, ops.ATTN_VT, os.environ.get("LR_ATTN_TR"))
+    ops.VT_MIN_KEYS, ops.ATTN_VT = (1, True) if mode == "vt" else (1 << 30, False)
+    if mode == "reg":
+        os.environ["LR_ATTN_TR"] = "0"
+    else:
+        os.environ.pop("LR_ATTN_TR", None)
+    try:
+        yield
+    finally:
+        ops.VT_MIN_KEYS, ops.ATTN_VT = old[:2]
+        if old[2] is None:
+            os.environ.pop("LR_ATTN_TR", None)
+        else:
+            os.environ["LR_ATTN_TR"] = old[2]
+
+
 def report(name, out, ref, rtol=RTOL, atol=ATOL):
     out, ref = out.float().cpu(), ref.float().cpu()
     err = (out - ref).abs()
@@ -706,8 +730,9 @@ def test_attention(B, heads, Nq, Nkv):
 @pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 2, 256, 256), (1, 3, 300, 200), (2, 1, 64, 77), (1, 2, 1024, 1024),
                                             (1, 1, 130, 1100), (1, 1, 256, 192), (1, 2, 70, 128), (1, 1, 1000, 4096), (2, 3, 333, 320)])
 def test_attention_pretransposed_v(B, heads, Nq, Nkv):
-    """lr_transpose_v_f16 + lr_attention_vt_f16 (V^T streamed by LDS-DMA): same result as the register-transposing
-    kernel -- bit-identical, since the MFMA operands are the same values in the same k order -- incl. key tails."""
+    """The three ways V reaches the PV product -- natural V gathered by the LDS transpose read (ds_read_b64_tr_b16, the default),
+    lr_transpose_v_f16 + lr_attention_vt_f16 (V^T streamed by LDS-DMA), natural V transposed in registers -- give bit-identical
+    results (the MFMA operands are the same values in the same k order), incl. key tails and strided operands."""
     from leftrefill_amd import ops
     d = dev()
     C = heads * 64
@@ -724,16 +749,12 @@ def test_attention_pretransposed_v(B, heads, Nq, Nkv):
     vpad[:, :Nkv] = v.reshape(B, Nkv, C)
     idx = (torch.arange(ld).reshape(-1, 16)[:, perm]).reshape(-1).to(d)
     assert torch.equal(vt, vpad[:, idx].permute(0, 2, 1).contiguous())
-    old_min = ops.VT_MIN_KEYS
-    try:
-        ops.VT_MIN_KEYS = 1 << 30
-        o_ref = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
-        ops.VT_MIN_KEYS = 1
-        o_vt = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
-    finally:
-        ops.VT_MIN_KEYS = old_min
-    assert torch.equal(o_ref, o_vt)
-    assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt), o_ref)
+    outs = {}
+    for mode in ("tr", "vt", "reg"):
+        with v_path(mode):
+            outs[mode] = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
+    assert torch.equal(outs["tr"], outs["vt"]) and torch.equal(outs["tr"], outs["reg"])
+    assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt), outs["tr"])
 
 
 def test_attention_online_softmax_rescale():
@@ -752,11 +773,11 @@ def test_attention_online_softmax_rescale():
     report("attention spike", o.reshape(B, N, 64), ref, atol=2e-3)
 
 
-@pytest.mark.parametrize("vt", [False, True], ids=["plain", "vt"])
+@pytest.mark.parametrize("vt", ["tr", "vt", "reg"])
 def test_attention_logit_jumps_of_every_size(vt):
-    """The inference kernels form P without a row max (the partial row sum is the overflow guard, running max anchored by tile 0):
-    a logit ~20 / ~70 octaves above the running max takes the in-place repair, one more than 127 octaves above it makes P infinite in
-    fp32 and the block reruns with the row max in every tile -- first, middle and last tiles, against the fp32 oracle (guide rule 26)."""
+    """The inference kernels fold the scale and the running max into the QK^T accumulators (the first tile anchors the max, later tiles
+    move it only when a shifted logit exceeds 2^3 in the exp2 domain): logits ~20 / ~70 / > 127 octaves above the running max in the
+    first, a middle and the last tile, against the fp32 oracle (guide rule 26), on every V path."""
     from leftrefill_amd import ops
     d = dev()
     B, heads, N = 1, 2, 768
@@ -771,27 +792,22 @@ def test_attention_logit_jumps_of_every_size(vt):
     k[0, 130, 64:] = q[0, 500, 64:] * 14.0     # > 127 octaves: fp32 overflow of P
     k[0, 5, 64:] = q[0, 100, 64:] * 3.0        # first tile (covered by the anchor)
     ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))
-    old_min = ops.VT_MIN_KEYS
-    try:
-        ops.VT_MIN_KEYS = 1 if vt else 1 << 30
+    with v_path(vt):
         o = ops.attention(q.reshape(N, C).half().to(d), k.reshape(N, C).half().to(d), v.reshape(N, C).half().to(d), B, heads, N, N, 64 ** -0.5)
         o2 = ops.attention(q.reshape(N, C).half().to(d), k.reshape(N, C).half().to(d), v.reshape(N, C).half().to(d), B, heads, N, N, 64 ** -0.5)
-    finally:
-        ops.VT_MIN_KEYS = old_min
     assert torch.equal(o, o2)
     # rows that jumped are dominated by one key (weight ~1): P near 1 is rounded to fp16, a few times the plain error
     report(f"attention jumps vt={vt}", o.reshape(B, N, C), ref, atol=4e-3)
 
 
-def test_attention_vt_rescale_and_hot_shapes():
-    """The pre-transposed-V kernel (the self-attention path of the UNet) against the CPU oracle DIRECTLY: (a) forced
-    running-max jumps in the first, a middle and the last tile (guide rule 26), (b) the level-0 shape of configs[1]
-    (8192 x 8192, one head) and the multi-view sequence of configs[3] (20480 keys)."""
+@pytest.mark.parametrize("vmode", ["tr", "vt"])
+def test_attention_vt_rescale_and_hot_shapes(vmode):
+    """The long-sequence kernels (the self-attention path of the UNet: natural V through the LDS transpose read, and the
+    pre-transposed-V kernel) against the CPU oracle DIRECTLY: (a) forced running-max jumps in the first, a middle and the last tile
+    (guide rule 26), (b) the level-0 shape of configs[1] (8192 x 8192, one head) and the multi-view sequence of configs[3] (20480 keys)."""
     from leftrefill_amd import ops
     d = dev()
-    old_min = ops.VT_MIN_KEYS
-    try:
-        ops.VT_MIN_KEYS = 1
+    with v_path(vmode):
         B, heads, N = 1, 1, 512
         q = h16(G.T("attp.q", (B, N, 64)))
         k = h16(G.T("attp.k", (B, N, 64)))
@@ -814,8 +830,6 @@ def test_attention_vt_rescale_and_hot_shapes():
                               v.reshape(Nkv, 64).half().to(d), 1, 1, Nq, Nkv, 64 ** -0.5)
             # averaging ~1e4 values: outputs are O(1e-2); P is rounded to fp16 before the second product
             report("attention vt " + name, o, ref, rtol=2e-3, atol=2e-4)
-    finally:
-        ops.VT_MIN_KEYS = old_min
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 512, 256), (2, 3, 1000, 1024), (1, 2, 700, 320), (1, 1, 2048, 2048), (1, 1, 130, 4096)])
@@ -1006,18 +1020,17 @@ def test_gemm_conv_randomised_shapes():
 
 
 def test_attention_randomised_shapes():
-    """30 random (B, heads, Nq, Nkv) problems, ragged in both dimensions, on both V paths (register-transposed and
-    pre-transposed), against the oracle's attention."""
+    """30 random (B, heads, Nq, Nkv) problems, ragged in both dimensions, on all three V paths (transpose read, pre-transposed,
+    register-transposed), against the oracle's attention."""
     import random
     from leftrefill_amd import ops
     rng = random.Random(99)
     d = dev()
-    old = ops.VT_MIN_KEYS
-    try:
-        for case in range(30):
-            B, heads = rng.randint(1, 3), rng.randint(1, 4)
-            Nq, Nkv = rng.randint(1, 400), rng.randint(1, 600)
-            ops.VT_MIN_KEYS = rng.choice([1, 1 << 30])
+    for case in range(30):
+        B, heads = rng.randint(1, 3), rng.randint(1, 4)
+        Nq, Nkv = rng.randint(1, 400), rng.randint(1, 600)
+        mode = rng.choice(["tr", "vt", "reg"])
+        with v_path(mode):
             C = heads * 64
             q = h16(G.T(f"attfz{case}.q", (B, Nq, C)))
             k = h16(G.T(f"attfz{case}.k", (B, Nkv, C)))
@@ -1026,6 +1039,4 @@ def test_attention_randomised_shapes():
             kv = torch.cat([k, v], -1).reshape(B * Nkv, 2 * C).half().to(d)
             o = ops.attention(q.reshape(B * Nq, C).half().to(d), kv[:, :C], kv[:, C:], B, heads, Nq, Nkv, 64 ** -0.5)
             err = (o.float().cpu().reshape(B, Nq, C) - ref).abs().max().item()
-            assert err < 3e-3, (case, B, heads, Nq, Nkv, ops.VT_MIN_KEYS, err)
-    finally:
-        ops.VT_MIN_KEYS = old
+            assert err < 3e-3, (case, B, heads, Nq, Nkv, mode, err)
