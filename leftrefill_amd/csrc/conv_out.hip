@@ -11,8 +11,8 @@
 //     v_mfma_f32_16x16x32 (rows 4..15 of the A operand are a zero row: the matrix work is 0.4 us either way), B fragments = one
 //     ds_read_b128 per lane (pixel = lane & 15 of a 16-pixel row segment shifted by the tap, 8 channels), conflict-free with the
 //     GEMM's row swizzle (slot = chunk ^ ((pixel >> 1) & 7)).
-// The patch is double buffered (the next chunk's loads are in flight under the MFMAs); weights ([Cout + 1 zero row][9 C]) and the
-// per-channel (a, b) table sit in LDS for the whole block.  HBM-bound: 2 B per input element + the halo from L2.
+// The patch is double buffered and the global loads run two chunks ahead in two register sets; weights ([Cout + 1 zero row][9 C]) and
+// the per-channel (a, b) table sit in LDS for the whole block.  HBM-bound: 2 B per input element + the halo from L2.
 #include "common.h"
 
 #define CO_THREADS 256
@@ -61,13 +61,15 @@ __global__ __launch_bounds__(CO_THREADS) void gn_conv_out_kernel(const ConvOutPa
     goff[it] = in ? (gy * P.W + gx) * C + c8 * 8 : -1;
     loff[it] = q < CO_PIECES ? pix * 128 + ((c8 ^ ((pix >> 1) & 7)) << 4) : -1;
   }
-  uint4 regs[CO_NLOAD];
-  auto load = [&](int chunk) {
+  // two register sets: the loads of chunk c + 2 are issued before chunk c + 1 is converted, so a chunk's global latency hides behind a
+  // whole iteration (MFMAs of chunk c + SiLU / LDS writes of chunk c + 1)
+  uint4 rega[CO_NLOAD], regb[CO_NLOAD];
+  auto load = [&](int chunk, uint4 (&regs)[CO_NLOAD]) {
 #pragma unroll
     for (int it = 0; it < CO_NLOAD; ++it)
       regs[it] = goff[it] >= 0 ? *reinterpret_cast<const uint4*>(x + goff[it] + chunk * 64) : make_uint4(0, 0, 0, 0);
   };
-  auto store = [&](int chunk, int buf) {
+  auto store = [&](int chunk, int buf, const uint4 (&regs)[CO_NLOAD]) {
     char* dst = patch + buf * CO_PATCH_BYTES;
 #pragma unroll
     for (int it = 0; it < CO_NLOAD; ++it) {
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(CO_THREADS) void gn_conv_out_kernel(const ConvOutPa
     }
   };
 
-  load(0);      // in flight under the prologue
+  const int nchunk = C / 64;
+  load(0, rega);      // in flight under the prologue
+  if (nchunk > 1) load(1, regb);
 
   // ---- GroupNorm statistics of sample n from the chunk partials [B][chunks][32][2] (fp64, fixed order: as gn_apply_kernel)
   const int Cg = C / 32;
@@ -127,16 +131,14 @@ __global__ __launch_bounds__(CO_THREADS) void gn_conv_out_kernel(const ConvOutPa
     s_b[c] = P.beta[c] - s_mean[g] * a;
   }
   __syncthreads();
-  store(0, 0);
+  store(0, 0, rega);
   __syncthreads();
 
   // ---- main loop: wave wv owns tile rows 2 wv, 2 wv + 1 (two 16-pixel segments)
   const int fr = lane & 15, fq = lane >> 4;
   const T* wrow = s_w + (size_t)(fr < P.Cout ? fr : 4) * K + fq * 8;
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  const int nchunk = C / 64;
-  for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) load(c + 1);
+  auto mma = [&](int c) {
     const char* src = patch + (c & 1) * CO_PATCH_BYTES;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -153,7 +155,17 @@ __global__ __launch_bounds__(CO_THREADS) void gn_conv_out_kernel(const ConvOutPa
         }
       }
     }
-    if (c + 1 < nchunk) store(c + 1, (c + 1) & 1);
+  };
+  // chunk c + 1 sits in regb when c is even, in rega when c is odd; the set that held chunk c is refilled with chunk c + 2
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 2 < nchunk) load(c + 2, rega);
+    mma(c);
+    if (c + 1 < nchunk) store(c + 1, 1, regb);
+    __syncthreads();
+    if (c + 1 >= nchunk) break;
+    if (c + 3 < nchunk) load(c + 3, regb);
+    mma(c + 1);
+    if (c + 2 < nchunk) store(c + 2, 0, rega);
     __syncthreads();
   }
 

@@ -29,7 +29,8 @@ AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "0") == "1"
 # (lr_gemm_args.pipe)
 TILE_CANDIDATES = ((128, 64, 0), (128, 128, 0), (128, 160, 0), (128, 128, 4), (128, 160, 4), (256, 128, 0), (256, 160, 0),
                    (256, 256, 0), (256, 320, 0))
-TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+TILE_TABLE_PATH = os.environ.get("LEFTREFILL_TILE_TABLE_PATH",      # (developer override: A/B of a freshly tuned table)
+                                 os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json"))
 _tile_cache = None
 
 
