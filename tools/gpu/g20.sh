@@ -17,4 +17,6 @@ b base X=1
 b merged LEFTREFILL_TILE_TABLE_PATH=$GRAFT_REPO_ROOT/gpurun_out/r4/tile_table_merged_r4.json
 b base2 X=1
 b merged2 LEFTREFILL_TILE_TABLE_PATH=$GRAFT_REPO_ROOT/gpurun_out/r4/tile_table_merged_r4.json
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "out_block" 2>&1 | tail -3 > gpurun_out/r4/g20_pytest.txt
+bash tools/kstats.sh r4d > gpurun_out/r4/g20_kstats.txt 2>&1
 echo done
