@@ -842,7 +842,7 @@ def main():
     if S_DDIM != 50:
         res["config"]["note"] = f"NOT the metric's configuration: {S_DDIM} DDIM steps per sampling (test / smoke run)"
 
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and not (a.mv_shard and world == 1):      # (the instrumented eager step is not built for simulated peers)
         kern, fl = kernel_roofline(model, batch, B, a.dump_kernels)
         g = kern["gemm_conv"]
         traffic, traffic_note = None, "not measured (--no-traffic / multi-GPU / other workload)"

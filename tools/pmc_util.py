@@ -29,9 +29,11 @@ def family(name):
                 "splitk_reduce", "transpose_v"):
         if key in name:
             return key
-    if "attention_kernel" in name:      # attention_kernel<T, VT, CAUSAL>
-        vt = ", true," in name or "_Lb1ELb" in name
-        return "attention_kernel (V^T by LDS-DMA)" if vt else "attention_kernel (V transposed in registers)"
+    if "attention_kernel" in name:      # attention_kernel<T, VM, CAUSAL, EXACT>: VM 0 = register transpose, 1 = pre-transposed V^T, 2 = LDS transpose read
+        for vm, label in (("Li1E", "pre-transposed V^T by LDS-DMA"), ("Li2E", "natural V, LDS transpose read"), ("Li0E", "V transposed in registers")):
+            if "attention_kernelIDF16_" + vm in name or "attention_kernelIDF16b" + vm in name:
+                return f"attention_kernel ({label})"
+        return "attention_kernel"
     return None
 
 
