@@ -55,6 +55,9 @@ struct GemmParams {
   // (K = 576, 86 % zero work).
   int c16;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
+#ifdef LR_GEMM_STAGGER
+  int stagger;   // developer build only: shader-clock cycles the SECOND co-resident block of a CU waits before it starts (env LR_GEMM_STAGGER)
+#endif
 #ifdef LR_GEMM_TRACE
   unsigned long long* trace;   // developer build only: per-block shader-clock stamps [block][8] (tools/trace_gemm.py)
 #endif
@@ -465,6 +468,18 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const int lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 1, wn = w & 1;
+#ifdef LR_GEMM_STAGGER
+  // Two co-resident 4-wave blocks start together and stay in lockstep: both load, both multiply, both store.  Experiment: the block
+  // whose waves sit in the odd wave slot of their SIMD (HW_ID.wave_id bit 0) starts P.stagger cycles late, so that its memory phases
+  // fall into the other block's matrix phase.  Measured (profiles/r04_stagger_experiment.txt): no shape gets faster, the delay only adds its length.
+  if (P.stagger) {
+    const unsigned slot_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_REG_HW_ID, bits [3:0] = wave_id
+    if (slot_id & 1) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < (unsigned long long)P.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
 
   // XCD-aware bijective remap: consecutive logical tiles run on the same XCD (shared A rows / halos stay in its L2)
   int bid = blockIdx.x;
@@ -1336,6 +1351,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
 #endif
   if (a->dtype != LR_DTYPE_F16 && a->dtype != LR_DTYPE_BF16) return LR_E_ARG;
   P.bf16 = a->dtype == LR_DTYPE_BF16;
+#ifdef LR_GEMM_STAGGER
+  { const char* e = getenv("LR_GEMM_STAGGER"); P.stagger = e ? atoi(e) : 0; }
+#endif
   if (P.bf16 && P.gelu) return LR_E_UNSUPPORTED;
   P.gs_out = a->gn_stats_out;
   if (P.gs_out && (P.geglu || ((uintptr_t)P.gs_out & 15))) return LR_E_ARG;
