@@ -28,6 +28,36 @@ def compose_prediction(out, mask_nhwc, test_size=None, metric_size=None):
     return pred, origin
 
 
+def compose_prediction_multiview(out, mask_flat_nhwc, batch_size, global_view_num=0, test_size=None, metric_size=None):
+    """The multi-view harness' composition (reference test_multiview_inpainting.py:141-170).  out: dict from
+    multiview_ref_inpainting_ldm.RefInpaintLDM.log_images (pred / origin_image [b, 3, h, w]: the target view only);
+    mask_flat_nhwc: batch['mask'] AFTER log_images flattened it in place to [(b v), H, W, 1] (reference get_input, 100-105);
+    batch_size: the loader's batch size.  Returns (pred, origin, global_view_num):
+      view_num = rows / batch_size, remembered from the FIRST batch (`global_view_num`, 146-148: a last, smaller batch is split by it);
+      mask = the mask of canvas 0 of every sample (149-151); a non-square canvas keeps the columns from H on (152-153: the target half
+      of a [reference | target] canvas);  pred = pred * mask + origin * (1 - mask) (155);  h != w -> keep columns w//2: (156-158);
+      float32 (160-162);  metric_size < test_size -> F.interpolate(mode='area') (164-168)."""
+    mask = mask_flat_nhwc.permute(0, 3, 1, 2)
+    view_num = int(mask.shape[0] / batch_size)
+    if global_view_num == 0:
+        global_view_num = view_num
+    real_bs = int(mask.shape[0] / global_view_num)
+    mask = mask.reshape(real_bs, global_view_num, *mask.shape[1:])[:, 0]
+    if mask.shape[3] != mask.shape[2]:
+        mask = mask[:, :, :, mask.shape[2]:]
+    h, w = out["pred"].shape[2], out["pred"].shape[3]
+    mask = mask.to(out["pred"].dtype)
+    pred = out["pred"] * mask + out["origin_image"].to(out["pred"].dtype) * (1 - mask)
+    origin = out["origin_image"]
+    if h != w:
+        pred, origin = pred[:, :, :, w // 2:], origin[:, :, :, w // 2:]
+    pred, origin = pred.float(), origin.float()
+    if metric_size is not None and test_size is not None and metric_size < test_size:
+        pred = F.interpolate(pred, size=(metric_size, metric_size), mode="area")
+        origin = F.interpolate(origin, size=(metric_size, metric_size), mode="area")
+    return pred, origin, global_view_num
+
+
 def psnr01(pred, origin):
     """Per-image PSNR of (x + 1) / 2 with data_range 1.0, as torchmetrics.functional.peak_signal_noise_ratio computes it
     for one image at a time (158): 10 log10(1 / mse); no clamping."""

@@ -137,6 +137,43 @@ def test_harness_composition_hand_derived_fixture():
     assert torch.allclose(evalglue.rgb_to_gray01(p[0])[0], torch.tensor(fx["expected_gray_pred_metric_row"]), atol=1e-6)
 
 
+def test_multiview_harness_composition_hand_derived():
+    """The multi-view harness' composition (reference test_multiview_inpainting.py:141-170) on hand-derived numbers; the reference
+    script cannot run here (its dataset module and metric packages are absent), so this pins the RESTATEMENT against a derivation:
+      loader batch size 2, 3 canvases per sample, canvases [reference | target] of 2 x 4 pixels (concat_target);
+      batch['mask'] after log_images flattened it: [(b v) = 6, 2, 4, 1]; canvas 0 of sample s has mask = 1 at target column 1 (canvas
+      column 3) for s = 0 and at target column 0 (canvas column 2) for s = 1; the masks of canvases 1, 2 are all ones and must be IGNORED
+      (149-151 take canvas 0); non-square canvas -> columns 2.. (152-153);
+      log_images returns the target halves: pred = 0.75 everywhere, origin = -0.25 -> pasted rows: sample 0 [-0.25, 0.75], sample 1
+      [0.75, -0.25] (155); square already, so no second crop (156-158);
+      a LAST batch with one sample (3 rows) is split by the view count of the FIRST batch (146-148: 3 / 3 = 1 sample), not by
+      rows / batch_size = 1.5."""
+    from leftrefill_amd import evalglue
+    b, v, h = 2, 3, 2
+    mask = torch.ones(b * v, h, 2 * h, 1)
+    mask[0] = 0
+    mask[0, :, 3] = 1
+    mask[3] = 0
+    mask[3, :, 2] = 1
+    out = {"pred": torch.full((b, 3, h, h), 0.75), "origin_image": torch.full((b, 3, h, h), -0.25)}
+    pred, origin, gv = evalglue.compose_prediction_multiview(out, mask, batch_size=2)
+    assert gv == 3 and pred.shape == (b, 3, h, h) and pred.dtype == torch.float32
+    assert torch.equal(pred[0, 1], torch.tensor([[-0.25, 0.75]] * h)) and torch.equal(pred[1, 2], torch.tensor([[0.75, -0.25]] * h))
+    assert torch.equal(origin, out["origin_image"])
+    # PSNR on (x + 1) / 2: half of the pixels differ by 0.5 -> mse = 0.125 -> 10 log10(8) = 9.0309 dB
+    assert abs(evalglue.psnr01(pred, origin)[0].item() - 9.0309) < 1e-3
+    # last, smaller batch of the same loader: one sample = 3 canvases
+    out1 = {"pred": out["pred"][:1], "origin_image": out["origin_image"][:1]}
+    p1, _, gv1 = evalglue.compose_prediction_multiview(out1, mask[:3], batch_size=2, global_view_num=gv)
+    assert gv1 == 3 and torch.equal(p1, pred[:1])
+    # square views (no concat_target): the mask of view 0 applies as it is; area down-sampling 2 -> 1 averages the pasted tile
+    m2 = torch.zeros(2 * 2, h, h, 1)
+    m2[0, 0, 0] = 1
+    out2 = {"pred": torch.full((2, 3, h, h), 1.0), "origin_image": torch.full((2, 3, h, h), 0.0)}
+    p2, o2, _ = evalglue.compose_prediction_multiview(out2, m2, batch_size=2, test_size=2, metric_size=1)
+    assert p2.shape == (2, 3, 1, 1) and abs(p2[0, 0, 0, 0].item() - 0.25) < 1e-7 and p2[1].abs().max().item() == 0.0 and o2.abs().max().item() == 0.0
+
+
 def test_lpips_alex_restatement_structure_and_properties():
     """LPIPS(alex) of the harness (test_inpainting.py:159): `evalglue.LPIPSAlex` against a sequential restatement written with the
     lpips package's own state-dict key spelling (`net.slice{k}.{idx}.*`, `lin{k}.model.1.weight`), on random weights --

@@ -16,6 +16,13 @@ directories with source / target / mask files) and torch's DataLoader, exactly l
 (no dataset ships with the reference) `--synthetic N` builds N batches with the same batch contract
 (dataloaders/test_dataset.py:91-105): image [B,512,1024,3] in [-1,1] (left reference | right target), mask [B,512,1024,1]
 (left half 0), masked_image = image*(mask<0.5), txt = "<special-token0> ... <special-token49>".
+
+--multiview: the call sequence of the reference's test_multiview_inpainting.py (77-233) for the multi-view task model
+(inpainting_ldm.multiview_ref_inpainting_ldm.RefInpaintLDM over MultiViewUnetModel): 5-D batches [B, v, H, W, 3], log_images samples all
+(b v) canvases jointly and returns the target view; the mask of canvas 0 of every sample pastes the known pixels back, a
+[reference | target] canvas keeps its target half (`evalglue.compose_prediction_multiview`, reference 141-170).  Its dataset
+(dataloaders/inpainting_crossview_dataset.py) is outside this build, so the mode runs on `--synthetic N` batches with that
+batch contract: one prompt list per view, txt[view][batch].
 """
 import argparse
 import glob
@@ -38,6 +45,28 @@ def synthetic_batches(n, batch_size, size, sp_token="<special-token>", repeat=50
         blocks = (torch.rand(batch_size, size // 32, size // 32, 1, generator=g) < 0.5).float()
         mask[:, :, size:, :] = blocks.repeat_interleave(32, 1).repeat_interleave(32, 2)
         yield {"image": img, "mask": mask, "masked_image": img * (mask < 0.5), "txt": [txt] * batch_size}
+
+
+def synthetic_mv_batches(n, batch_size, size, views, concat, view_token_len, sp_token="<special-token>", repeat=50, seed=0):
+    """Multi-view batches: `views` canvases per sample; concat_target: canvas i = [reference_i | target] (size x 2 size), the mask marks a
+    block pattern inside the target half; otherwise square views, view 0 is the (masked) target."""
+    g = torch.Generator().manual_seed(seed)
+    base = " ".join(f"{sp_token[:-1]}{i}>" for i in range(repeat))
+    txt = [[base + " " + " ".join(f"<view_direct-{j}-{l}" for l in range(view_token_len))] * batch_size for j in range(views)]
+    wc = 2 * size if concat else size
+    for _ in range(n):
+        img = torch.rand(batch_size, views, size, wc, 3, generator=g) * 2 - 1
+        if concat:
+            img[:, :, :, size:] = img[:, :1, :, size:]        # every canvas carries the same target on its right half
+        mask = torch.zeros(batch_size, views, size, wc, 1)
+        blocks = (torch.rand(batch_size, size // 32, size // 32, 1, generator=g) < 0.5).float()
+        blocks[:, 0, 0] = 1.0                                 # never an empty mask (a tiny --test_size has only a few blocks)
+        blocks = blocks.repeat_interleave(32, 1).repeat_interleave(32, 2)
+        if concat:
+            mask[:, :, :, size:, :] = blocks[:, None]
+        else:
+            mask[:, 0] = blocks
+        yield {"image": img, "mask": mask, "masked_image": img * (mask < 0.5), "txt": [list(t) for t in txt]}
 
 
 def dataset_batches(path, batch_size, size, model):
@@ -67,7 +96,10 @@ def main():
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--pretrained", type=str, default="pretrained_models/512-inpainting-ema.ckpt")
     ap.add_argument("--lpips_weights", type=str, default=None, help="comma-separated state-dict files for LPIPS(alex)")
+    ap.add_argument("--multiview", action="store_true", help="multi-view task model: the call sequence of test_multiview_inpainting.py")
     a = ap.parse_args()
+    if a.multiview and a.test_path:
+        raise SystemExit("--multiview reads --synthetic batches only: the cross-view dataset loader is outside this build (SURVEY 2a)")
 
     import leftrefill_amd.dropin as dropin
     dropin.install()
@@ -82,8 +114,17 @@ def main():
         print(model.load_state_dict(load_state_dict(a.pretrained), strict=False))
     model = model.to("cuda").eval()
     os.makedirs(a.output_path, exist_ok=True)
-    batches = dataset_batches(a.test_path, a.batch_size, a.test_size, model) if a.test_path else \
-        synthetic_batches(max(1, a.synthetic), a.batch_size, a.test_size)
+    if a.multiview:
+        concat = bool(getattr(model, "concat_target", False))
+        views = model.view_num - 1 if concat else model.view_num
+        vlen = int((getattr(model, "cond_cfg", None) or {}).get("view_token_len", 0)) if (getattr(model, "cond_cfg", None) or {}).get("view_prompt", True) else 0
+        dc = getattr(model, "data_cfg", None) or {}
+        batches = synthetic_mv_batches(max(1, a.synthetic), a.batch_size, a.test_size, views, concat, vlen,
+                                       sp_token=dc.get("sp_token", "<special-token>"), repeat=int(dc.get("repeat_sp_token", 50)))
+    else:
+        batches = dataset_batches(a.test_path, a.batch_size, a.test_size, model) if a.test_path else \
+            synthetic_batches(max(1, a.synthetic), a.batch_size, a.test_size)
+    global_view_num = 0
     lpips_fn = None
     if a.lpips_weights:
         lpips_fn = evalglue.LPIPSAlex().load_weights(*[torch.load(f, map_location="cpu") for f in a.lpips_weights.split(",")]).cuda()
@@ -95,7 +136,11 @@ def main():
             if not torch.isfinite(out["pred"]).all():
                 bad = (~torch.isfinite(out["pred"])).float().mean().item()
                 print(f"WARNING: {100 * bad:.2f} % of the decoded prediction is not finite (batch {bi})")
-            pred, origin = evalglue.compose_prediction(out, batch["mask"], a.test_size, a.metric_size)
+            if a.multiview:      # batch["mask"] was flattened to (b v) canvases by log_images, like the reference (100-105)
+                pred, origin, global_view_num = evalglue.compose_prediction_multiview(out, batch["mask"], a.batch_size, global_view_num,
+                                                                                      a.test_size, a.metric_size)
+            else:
+                pred, origin = evalglue.compose_prediction(out, batch["mask"], a.test_size, a.metric_size)
             psnrs.extend(evalglue.psnr01(pred, origin).tolist())
             if lpips_fn is not None:
                 with torch.autocast("cuda", enabled=False):
