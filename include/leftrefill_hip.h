@@ -182,6 +182,14 @@ typedef struct lr_gemm_args {
    * K-step 1, ... (lr packing: w.reshape(N, K / 64, 64).permute(1, 0, 2)).  Same arithmetic, same K order; a tile's weight slice of one
    * K-step is then one contiguous run instead of tile_n pieces 2 K bytes apart.  Not with wt_bstride. */
   int32_t wt_pm;
+  /* skip1 != NULL (ABI 22): pointwise K extension -- out = conv3x3([p1 | p2]) + W_s [skip1 | skip2] in ONE accumulation:
+   *   wt = [N][9 (C1 + C2) + Cs1 + Cs2] (the 3x3 part first, then the pointwise weights over skip1's, then skip2's channels),
+   *   bias = the sum of the two layers' biases.  skip1 / skip2: [B*H*W, Cs1 / Cs2] at the OUTPUT resolution (virtual channel concat).
+   * replaces: `self.skip_connection(x) + h` of ResBlock._forward (openaimodel.py:274) where skip_connection is the 1x1 conv of a block
+   *           whose width changes (253-259): the separate GEMM, its [M, N] output and the residual read of this conv's epilogue.
+   * taps == 9, stride 1, no upsample, no GEGLU / LayerNorm fold / per-sample weights; pipelined tiles only (tile_m 256, or 128 with the
+   * 4-stage ring): anything else LR_E_UNSUPPORTED.  resid / rowvec / statistics outputs work as without it. */
+  const lr_half* skip1; const lr_half* skip2; int32_t Cs1, Cs2;
 } lr_gemm_args;
 /* row tiles per sample of gn_group_out for this call, 0 if the plan cannot produce per-group sums */
 int lr_gemm_gn_group_chunks(const lr_gemm_args* args);

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -42,6 +42,7 @@ class GemmArgs(ctypes.Structure):
         ("gn_group_out", c_void_p), ("gn_hw", ctypes.c_int32),
         ("wt_bstride", ctypes.c_int32), ("bias_bstride", ctypes.c_int32),
         ("wt_pm", ctypes.c_int32),
+        ("skip1", c_void_p), ("skip2", c_void_p), ("Cs1", ctypes.c_int32), ("Cs2", ctypes.c_int32),
     ]
 
 

@@ -54,6 +54,12 @@ struct GemmParams {
   // 4 kt + (c >> 1), half c & 1, so the per-lane gather offset changes every K-step.  Replaces the 64-channel padding of round 1-3
   // (K = 576, 86 % zero work).
   int c16;
+  // K extension by a pointwise term over a second (virtually concatenated) pair of sources with the output's resolution:
+  //   out = conv3x3([p1 | p2]) + W_s [p3 | p4],   wt = [N][taps (C1 + C2) + C3 + C4]  (the 3x3 part first)
+  // -- the ResBlock's skip_connection (a 1x1 conv of the block input) accumulated into the block's last conv instead of running as its
+  // own GEMM whose output travels through HBM to this conv's residual epilogue.  The extra K-steps gather tap (0, 0) of p3 / p4.
+  // Pipelined instances only; stride 1, no upsample.
+  const f16* p3; const f16* p4; int C3, C4;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_STAGGER
   int stagger;   // developer build only: shader-clock cycles the SECOND co-resident block of a CU waits before it starts (env LR_GEMM_STAGGER)
@@ -725,7 +731,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
   const int cpt = P.c16 ? 1 : (P.C1 + P.C2) >> 6;
   const int cpt1 = P.c16 ? 1 : P.C1 >> 6;
-  const int nk_all = P.c16 ? 3 : P.taps * cpt;
+  const int nk_main = P.c16 ? 3 : P.taps * cpt;
+  const int cpt3 = P.C3 >> 6;                           // K-steps of the pointwise extension (GemmParams.p3 / p4): source 3, then 4
+  const int nk_all = nk_main + ((P.C3 + P.C4) >> 6);
   const int k_per = (nk_all + P.splits - 1) / P.splits;
   const int k_begin = blockIdx.y * k_per;
   const int nk = min(nk_all, k_begin + k_per);
@@ -735,6 +743,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   // per-lane address arithmetic, and padding / tails need no zero page: an out-of-range voffset reads as 0.
   const size_t a1_bytes = (size_t)P.Hs * P.Ws * P.C1 * 2 * (P.M / HW);
   const size_t a2_bytes = P.p2 ? (size_t)P.Hs * P.Ws * P.C2 * 2 * (P.M / HW) : 0;
+  const size_t a3_bytes = (size_t)P.Hs * P.Ws * P.C3 * 2 * (P.M / HW);
+  const size_t a4_bytes = (size_t)P.Hs * P.Ws * P.C4 * 2 * (P.M / HW);
   setup_tile(tl);
   // A K-step's staging is split in two: stage_prepare (wave-uniform control flow: new gather offsets when the tap or
   // the concat source changes; the descriptor / scalar offsets of the step) and stage_issue (a straight line of
@@ -769,14 +779,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       coff = 0;
       koff = (unsigned)kt * (P.wt_pm ? (unsigned)P.N * 128u : 128u);
     } else {
-    const int tap = kt / cpt, cc = kt - tap * cpt;
-    const int srcsel = cc < cpt1 ? 0 : 1;
+    int tap, cc, srcsel;
+    if (kt < nk_main) { tap = kt / cpt; cc = kt - tap * cpt; srcsel = cc < cpt1 ? 0 : 1; }
+    else { tap = 16; cc = kt - nk_main; srcsel = cc < cpt3 ? 2 : 3; }      // pointwise extension: tap (0, 0) of sources 3 / 4
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform
       seg_tap = tap; seg_src = srcsel;
       int dy = 0, dx = 0;
-      if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
-      const int cs = srcsel ? P.C2 : P.C1;
-      rsA = uniform_rsrc(srcsel ? (const void*)P.p2 : (const void*)P.p1, srcsel ? a2_bytes : a1_bytes);
+      if (P.taps == 9 && tap < 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
+      const int cs = srcsel == 0 ? P.C1 : srcsel == 1 ? P.C2 : srcsel == 2 ? P.C3 : P.C4;
+      rsA = srcsel == 0 ? uniform_rsrc((const void*)P.p1, a1_bytes) : srcsel == 1 ? uniform_rsrc((const void*)P.p2, a2_bytes)
+          : srcsel == 2 ? uniform_rsrc((const void*)P.p3, a3_bytes) : uniform_rsrc((const void*)P.p4, a4_bytes);
       // (sample, y, x) of each gathered row are re-derived here (a few dozen VALU ops per tap) rather than kept in 3 * NA
       // registers for the whole tile: the persistent loop keeps the next tile's gather state live across the epilogue
 #pragma unroll
@@ -793,7 +805,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
         avo[i] = ok ? (unsigned)(((size_t)((int)b * P.Hs * P.Ws + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
       }
     }
-    coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
+    coff = (unsigned)((srcsel == 1 ? cc - cpt1 : srcsel == 3 ? cc - cpt3 : cc) * 128);
     koff = (unsigned)kt * (P.wt_pm ? (unsigned)P.N * 128u : 128u);
     }
     if (B_TAIL && w < TAIL_WAVES)     // the odd weight rows (first waves only): issued here, ahead of the step's other loads
@@ -1207,7 +1219,7 @@ static int tile_wnw(int tm, int tn, int geglu) {
 extern "C" int lr_gemm_plan(const lr_gemm_args* a, int32_t* plan) {
   if (!a || !plan) return LR_E_ARG;
   const int M = a->B * a->H * a->W;
-  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0)) + (a->skip1 ? a->Cs1 + (a->skip2 ? a->Cs2 : 0) : 0);
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
   plan[0] = tm; plan[1] = tn;
@@ -1229,7 +1241,7 @@ extern "C" int lr_gemm_gn_rows(const lr_gemm_args* a) {
   int tn = a->tile_n, tm = a->tile_m;
   const int M = a->B * a->H * a->W;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
-  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0)) + (a->skip1 ? a->Cs1 + (a->skip2 ? a->Cs2 : 0) : 0);
   const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
   if (splits > 1) return RED_ROWS;     // the statistics come out of the split-K reduce kernel
   return tile_wave_rows(tm, tn, a->geglu == 1, a->pipe);
@@ -1254,7 +1266,7 @@ extern "C" int lr_gemm_gn_group_chunks(const lr_gemm_args* a) {
   int tn = a->tile_n, tm = a->tile_m;
   const int M = a->B * a->H * a->W;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
-  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0)) + (a->skip1 ? a->Cs1 + (a->skip2 ? a->Cs2 : 0) : 0);
   const int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
   return gn_group_chunks(a, tm, tn, splits);
 }
@@ -1269,7 +1281,7 @@ extern "C" int lr_gemm_stats_parts(const lr_gemm_args* a) {
 extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   if (!a) return 0;
   const int M = a->B * a->H * a->W;
-  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0));
+  const int K = a->taps * (a->C1 + (a->p2 ? a->C2 : 0)) + (a->skip1 ? a->Cs1 + (a->skip2 ? a->Cs2 : 0) : 0);
   int tn = a->tile_n, tm = a->tile_m;
   choose_tile(M, a->N, a->geglu != 0, &tm, &tn);
   int splits = a->splits ? a->splits : choose_splits(M, a->N, K, tm, tn, a->geglu == 1, a->pipe);
@@ -1294,11 +1306,20 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.pad = a->asym ? 0 : 1;   // asym: F.pad(x, (0,1,0,1)) + conv padding 0 (VAE Downsample)
   P.wt = (const f16*)a->wt; P.N = a->N; P.bias = a->bias;
   P.M = a->B * a->H * a->W;
-  P.K = P.c16 ? 192 : a->taps * (P.C1 + P.C2);      // c16: wt is [N][192] (k = tap * 16 + c, taps 9..11 zero)
+  P.p3 = (const f16*)a->skip1; P.C3 = a->skip1 ? a->Cs1 : 0;
+  P.p4 = a->skip1 ? (const f16*)a->skip2 : nullptr; P.C4 = P.p4 ? a->Cs2 : 0;
+  if (P.p3) {      // pointwise K extension (the ResBlock's skip_connection inside its last conv): see GemmParams.p3
+    if (P.c16 || a->taps != 9 || a->stride != 1 || a->up != 0 || a->asym || a->geglu || a->ln_stats || a->wt_bstride || a->wt_pm ||
+        a->Hs != a->H || a->Ws != a->W)
+      return LR_E_UNSUPPORTED;
+    if (P.C3 <= 0 || P.C3 % 64 || P.C4 % 64 || (((uintptr_t)P.p3 | (uintptr_t)P.p4) & 15)) return LR_E_ALIGN;
+  }
+  P.K = P.c16 ? 192 : a->taps * (P.C1 + P.C2) + P.C3 + P.C4;      // c16: wt is [N][192] (k = tap * 16 + c, taps 9..11 zero)
   // 32-bit byte offsets in the gather (bit 31 marks out-of-range): every operand must stay below 2 GiB
   const int64_t lim = (int64_t)1 << 31;
   const int64_t src_rows = (int64_t)a->B * a->Hs * a->Ws;
-  if (src_rows * P.C1 * 2 >= lim || src_rows * P.C2 * 2 >= lim || (int64_t)P.N * P.K * 2 >= lim ||
+  if (src_rows * P.C1 * 2 >= lim || src_rows * P.C2 * 2 >= lim || src_rows * P.C3 * 2 >= lim || src_rows * P.C4 * 2 >= lim ||
+      (int64_t)P.N * P.K * 2 >= lim ||
       (int64_t)a->B * a->H * a->W >= lim / 2)
     return LR_E_UNSUPPORTED;
   P.rowvec = (const f16*)a->rowvec; P.ld_rowvec = a->ld_rowvec;
@@ -1381,6 +1402,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
   if (a->pipe != 0 && a->pipe != choose_stages(tm, tn, a->pipe)) return LR_E_UNSUPPORTED;
   const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
+  if (P.p3 && !(tm == 256 || deep)) return LR_E_UNSUPPORTED;      // only the pipelined instances gather the extension
   if (mode == 0) {
     if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 0>(P, st);
     else if (deep && tn == 160) rc = launch_pipe<128, 8, 160, 4, 4, 0>(P, st);

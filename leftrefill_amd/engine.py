@@ -125,10 +125,24 @@ class PackedRes:
         self.n2 = PackedNorm(blk.out_layers[0])
         self.c2 = PackedConv(blk.out_layers[3])
         self.skip = None
+        self.c2s = None
         sk = blk.skip_connection
         if isinstance(sk, torch.nn.Conv2d):
             self.skip = PackedConv(sk)
+            if sk.kernel_size == (1, 1) and self.c2.taps == 9 and self.c2.stride == 1 and self.skip.w.shape[0] == self.c2.w.shape[0]:
+                # `skip_connection(x) + h` (openaimodel.py:274) as extra K-steps of the last conv: weights [N][9 C | C_in], summed biases
+                self.c2s = FusedSkipConv(self.c2, self.skip)
         self.cout = self.c1.cout
+
+
+class FusedSkipConv:
+    """The ResBlock's last 3x3 conv with its 1x1 skip_connection appended along K (lr_gemm_args.skip1): one accumulation, one rounding."""
+
+    def __init__(self, c2, skip):
+        self.w = torch.cat([c2.w, skip.w], dim=1).contiguous()
+        b2 = c2.b if c2.b is not None else torch.zeros(c2.w.shape[0], device=c2.w.device)
+        self.b = (b2 + skip.b) if skip.b is not None else c2.b
+        self.cout, self.taps, self.stride = c2.cout, 9, 1
 
 
 class PackedAttn:
@@ -220,15 +234,18 @@ def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear):
 
 # GroupNorm statistics out of the producing GEMM's epilogue (inference path); LEFTREFILL_GN_FUSE=0 runs the statistics pass.
 GN_FUSE = __import__("os").environ.get("LEFTREFILL_GN_FUSE", "1") != "0"
+# a ResBlock's 1x1 skip_connection as extra K-steps of its last conv (lr_gemm_args.skip1); 0 = separate GEMM + residual epilogue
+SKIP_FUSED = __import__("os").environ.get("LEFTREFILL_SKIP_FUSED", "1") != "0"
 
 
 def gn_fuse_ok(x):
     return GN_FUSE and not (torch.is_grad_enabled() and x.requires_grad)
 
 
-def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False):
+def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False, skip=None):
     """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample; asym: pad bottom/right only) or 1x1 conv over an Act.
-    gn_stats: the output feeds a GroupNorm -- let the epilogue produce its statistics (Act.gs)."""
+    gn_stats: the output feeds a GroupNorm -- let the epilogue produce its statistics (Act.gs).
+    skip = (tok, tok2 | None): pointwise K extension (pc is a FusedSkipConv), see ops.gemm_conv."""
     if pc.taps == 9:
         if up:
             H, W = act.H * 2, act.W * 2
@@ -240,7 +257,7 @@ def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn
         H, W = act.H, act.W
     want = gn_stats and gn_fuse_ok(act.tok) and pc.cout == pc.w.shape[0]
     y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
-                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want)
+                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want, skip=skip)
     y, gs = y if want else (y, None)
     return Act(y, act.N, H, W, gs=gs)
 
@@ -266,6 +283,9 @@ def resblock(act: Act, pr: PackedRes, emb_out):
     h = gn(act, pr.n1, True)
     h = conv(h, pr.c1, rowvec=emb_out, gn_stats=True)
     h = gn(h, pr.n2, True)
+    if pr.c2s is not None and SKIP_FUSED and gn_fuse_ok(act.tok):
+        # inference: the 1x1 skip_connection of a width-changing block rides on the last conv's K loop (no separate GEMM, no residual pass)
+        return conv(h, pr.c2s, gn_stats=True, skip=(act.tok, act.tok2))
     if pr.skip is not None:
         resid = conv(act, pr.skip).tok
     else:

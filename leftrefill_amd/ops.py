@@ -242,8 +242,12 @@ def linear_small_m(a, w, bias, act_in=False, act_out=False):
 
 def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym=False, x2=None, bias=None, rowvec=None,
               resid=None, geglu=False, gelu=False, out=None, tile_n=0, tile_m=0, splits=0, pipe=0, ln=None,
-              want_stats=False, want_gn_stats=False, gn_hw=0, per_sample=False, wt_pm=False):
+              want_stats=False, want_gn_stats=False, gn_hw=0, per_sample=False, wt_pm=False, skip=None):
     """Implicit-GEMM conv / linear (see lr_gemm_conv_f16).  x1 [B*Hs*Ws, C1] fp16, wt [N, taps*(C1+C2)] fp16.
+
+    skip = (s1, s2 | None): pointwise K extension over the virtual concat [s1 | s2] at the output resolution -- wt is
+    [N, 9 (C1 + C2) + Cs1 + Cs2], out = conv3x3([x1 | x2]) + W_s [s1 | s2] in one accumulation (lr_gemm_args.skip1: a ResBlock's
+    skip_connection inside its last conv); bias must be the sum of the two layers' biases.
 
     ln = (stats [M, parts, 2] fp32, eps, colsum [N] fp32): LayerNorm folded into the GEMM (x1 is the raw input, wt / bias
     are the gamma / beta folded weights, see lr_gemm_args).  want_stats: also return the per-row (sum, sumsq) partials of
@@ -271,7 +275,16 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     else:
         Nw, Kw = wt.shape[-2], wt.shape[-1]
     c16 = C1 == 16 and C2 == 0 and taps == 9 and Kw == 192      # 16-channel 3x3 source: K = 144 zero-padded to three K-steps
-    assert c16 or Kw == taps * (C1 + C2), (wt.shape, taps, C1, C2)
+    Cs1 = Cs2 = 0
+    if skip is not None:
+        s1, s2 = skip
+        _chk16(s1, "skip1")
+        Cs1 = s1.shape[-1]
+        if s2 is not None:
+            _chk16(s2, "skip2")
+            Cs2 = s2.shape[-1]
+        assert taps == 9 and stride == 1 and not up and s1.shape[0] == B * H * W and (s2 is None or s2.shape[0] == s1.shape[0])
+    assert c16 or Kw == taps * (C1 + C2) + Cs1 + Cs2, (wt.shape, taps, C1, C2, Cs1, Cs2)
     if c16 and tile_m == 0 and tile_n == 0:
         # only the pipelined 256-row instances gather 16-channel taps
         tile_m, tile_n, splits = 256, (320 if Nw % 320 == 0 else 160 if Nw % 160 == 0 else 128), 1
@@ -304,6 +317,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.gn_group_out, a.gn_hw = 0, int(gn_hw)
     a.wt_bstride, a.bias_bstride = (Nw * Kw, Nw if bias is not None else 0) if per_sample else (0, 0)
     a.wt_pm = int(bool(wt_pm))
+    a.skip1, a.skip2, a.Cs1, a.Cs2 = (_p(skip[0]), _p(skip[1]), Cs1, Cs2) if skip is not None else (0, 0, 0, 0)
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
     a.dtype = int(x1.dtype == torch.bfloat16)      # LR_DTYPE_F16 | LR_DTYPE_BF16
     if ln is not None:
@@ -314,7 +328,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     st = _stream()
     if tile_m == 0 and tile_n == 0 and splits == 0:
         scale = _PLAN_BATCH_SCALE[0]
-        key = tile_key(M * scale, Nw, Kw, taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
+        # (a conv with the pointwise extension is planned like the plain conv: the table knows that shape)
+        key = tile_key(M * scale, Nw, Kw - Cs1 - Cs2, taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
         if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
             a.B = B * scale
@@ -330,6 +345,12 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
             a.pipe = best[3] if len(best) > 3 else 0
+        if skip is not None and best is None:      # static heuristic: ask the library, then make sure the tile is a pipelined one
+            plan = (ctypes.c_int32 * 4)()
+            lib.lr_gemm_plan(a, plan)
+            a.tile_m, a.tile_n, a.splits, a.pipe = plan[0], plan[1], plan[2], plan[3]
+        if skip is not None and a.tile_m == 128 and a.pipe != 4:      # only the pipelined instances gather the extension
+            a.tile_n, a.pipe = (a.tile_n if a.tile_n in (128, 160) else (160 if Nw % 160 == 0 else 128)), 4
     stats = None
     if want_stats:
         if a.splits == 0:

@@ -305,6 +305,54 @@ def test_conv_golden_cases(golden):
         report("golden " + name, from_tok(y, N, H, W), torch.from_numpy(g[name]), rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("tile,splits", [((256, 320), 1), ((256, 160), 1), ((256, 128), 1), ((256, 256), 1), ((128, 160, 4), 1), ((128, 128, 4), 1),
+                                         ((256, 160), 3), ((256, 128), 4)], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"s{v}")
+def test_conv_with_fused_skip_connection(tile, splits):
+    """lr_gemm_args.skip1: `skip_connection(x) + conv3x3(h)` of a width-changing ResBlock (reference openaimodel.py:253-259, 274) in ONE
+    accumulation -- 3x3 part over [h] or a virtual concat [h1 | h2], then the 1x1 part over the virtual concat [x1 | x2] -- against
+    F.conv2d + F.conv2d in fp32 on the same 16-bit operands, on every pipelined tile, with split-K, image borders and an M tail; the
+    result also agrees with the two-launch path (separate skip GEMM + residual epilogue) to its extra fp16 rounding; the GroupNorm
+    partials of the epilogue describe the stored tensor; tiles of the non-pipelined kernel are refused."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W = 3, 16, 24                      # M = 1152 = 4.5 x 256: a tail tile; H W = 384 rows per sample
+    Ch, Cx1, Cx2, Cout = 320, 320, 640, 320
+    name = f"skipf.{'x'.join(map(str, tile))}.{splits}"
+    hx = h16(G.T(name + ".h", (N, Ch, H, W)))
+    x1 = h16(G.T(name + ".x1", (N, Cx1, H, W)))
+    x2 = h16(G.T(name + ".x2", (N, Cx2, H, W)))
+    w3 = h16(torch.from_numpy(weights.fill_like(name + ".w3", (Cout, Ch, 3, 3))))
+    ws = h16(torch.from_numpy(weights.fill_like(name + ".ws", (Cout, Cx1 + Cx2, 1, 1))) * 2.0)
+    b3 = torch.from_numpy(weights.fill_like(name + ".b3", (Cout,)))
+    bs = torch.from_numpy(weights.fill_like(name + ".bs", (Cout,))) + 0.2
+    ref = F.conv2d(hx, w3, b3, padding=1) + F.conv2d(torch.cat([x1, x2], 1), ws, bs)
+    wf = torch.cat([packing.pack_conv(w3), packing.pack_conv(ws)], dim=1).half().contiguous().to(d)
+    bf = packing.pack_bias(b3 + bs).to(d)
+    th, t1, t2 = to_tok(hx), to_tok(x1), to_tok(x2)
+    kw = dict(B=N, H=H, W=W, taps=9, bias=bf, splits=splits, **tile_kw(tile))
+    y, gs = ops.gemm_conv(th, wf, skip=(t1, t2), want_gn_stats=True, **kw)
+    report(f"conv + fused skip {tile} s{splits}", from_tok(y, N, H, W), ref, rtol=3e-3, atol=3e-3)
+    assert torch.equal(y, ops.gemm_conv(th, wf, skip=(t1, t2), **kw))
+    if gs is not None:
+        part, R, gp, chunks = gs
+        yf = y.float()
+        rows = torch.arange(yf.shape[0], device=d) // R
+        sums = torch.zeros(part.shape[0], Cout, device=d).index_add_(0, rows, yf)
+        assert torch.allclose(part[..., 0], sums, rtol=1e-5, atol=5e-3)
+    # two launches: skip GEMM -> fp16 -> residual of the 3x3 conv
+    r2 = ops.gemm_conv(t1, packing.pack_conv(ws).half().to(d), B=N, H=H, W=W, taps=1, x2=t2, bias=packing.pack_bias(bs).to(d))
+    y2 = ops.gemm_conv(th, packing.pack_conv(w3).half().to(d), B=N, H=H, W=W, taps=9, bias=packing.pack_bias(b3).to(d), resid=r2)
+    assert (y.float() - y2.float()).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    # the 3x3 part over a virtual concat as well (an output block whose conv input is a concat does not occur in the UNet, the kernel allows it)
+    ha, hb = hx[:, :128].contiguous(), hx[:, 128:].contiguous()      # (per tap the K order is [x1 channels | x2 channels]: the same weights)
+    assert torch.equal(ops.gemm_conv(to_tok(ha), wf, x2=to_tok(hb), skip=(t1, t2), **kw), y)
+    # a single skip source
+    y1 = ops.gemm_conv(th, torch.cat([packing.pack_conv(w3), packing.pack_conv(ws[:, :Cx1])], 1).half().contiguous().to(d), skip=(t1, None), **kw)
+    report("conv + fused skip, one source", from_tok(y1, N, H, W), F.conv2d(hx, w3, b3, padding=1) + F.conv2d(x1, ws[:, :Cx1], bs), rtol=3e-3, atol=3e-3)
+    with pytest.raises(RuntimeError):
+        ops.gemm_conv(th, wf, skip=(t1, t2), B=N, H=H, W=W, taps=9, bias=bf, tile_m=128, tile_n=64, splits=1)
+
+
 # (tile_m, tile_n[, pipe]): every GEMM instance; pipe 4 = the 8-wave 4-stage 128-row kernel
 ALL_TILES = [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320), (128, 128, 4), (128, 160, 4)]
 
