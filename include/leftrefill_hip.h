@@ -187,8 +187,11 @@ typedef struct lr_gemm_args {
    *   bias = the sum of the two layers' biases.  skip1 / skip2: [B*H*W, Cs1 / Cs2] at the OUTPUT resolution (virtual channel concat).
    * replaces: `self.skip_connection(x) + h` of ResBlock._forward (openaimodel.py:274) where skip_connection is the 1x1 conv of a block
    *           whose width changes (253-259): the separate GEMM, its [M, N] output and the residual read of this conv's epilogue.
-   * taps == 9, stride 1, no upsample, no GEGLU / LayerNorm fold / per-sample weights; pipelined tiles only (tile_m 256, or 128 with the
-   * 4-stage ring): anything else LR_E_UNSUPPORTED.  resid / rowvec / statistics outputs work as without it. */
+   * With taps == 1 the main part is pointwise too: out = W_a [p1 | p2] + W_s [skip1 | skip2] (wt = [N][C1 + C2 + Cs1 + Cs2]) -- used for
+   * SpatialTransformer.proj_out composed with the last feed-forward Linear (attention.py:75-77, 412-419): proj_out(ff2(g) + x) + x_in =
+   * (Wp W2) g + Wp x + (Wp b2 + bp) + x_in, one GEMM with resid = x_in.
+   * stride 1, no upsample, no GEGLU / LayerNorm fold / per-sample weights: anything else LR_E_UNSUPPORTED.  resid / rowvec / statistics
+   * outputs work as without it. */
   const lr_half* skip1; const lr_half* skip2; int32_t Cs1, Cs2;
 } lr_gemm_args;
 /* row tiles per sample of gn_group_out for this call, 0 if the plan cannot produce per-group sums */

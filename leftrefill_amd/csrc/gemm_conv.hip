@@ -58,7 +58,7 @@ struct GemmParams {
   //   out = conv3x3([p1 | p2]) + W_s [p3 | p4],   wt = [N][taps (C1 + C2) + C3 + C4]  (the 3x3 part first)
   // -- the ResBlock's skip_connection (a 1x1 conv of the block input) accumulated into the block's last conv instead of running as its
   // own GEMM whose output travels through HBM to this conv's residual epilogue.  The extra K-steps gather tap (0, 0) of p3 / p4.
-  // Pipelined instances only; stride 1, no upsample.
+  // Stride 1, no upsample; the main part may itself be pointwise (taps == 1): out = W_a [p1 | p2] + W_s [p3 | p4].
   const f16* p3; const f16* p4; int C3, C4;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
 #ifdef LR_GEMM_STAGGER
@@ -518,7 +518,9 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const int Hlim = P.Hs << P.up, Wlim = P.Ws << P.up;
   const int cpt = (P.C1 + P.C2) >> 6;   // 64-channel chunks per tap
   const int cpt1 = P.C1 >> 6;
-  const int nk_all = P.taps * cpt;
+  const int nk_main = P.taps * cpt;
+  const int cpt3 = P.C3 >> 6;           // K-steps of the pointwise extension (GemmParams.p3 / p4) behind the taps
+  const int nk_all = nk_main + ((P.C3 + P.C4) >> 6);
   const int k_per = (nk_all + P.splits - 1) / P.splits;
   const int k_begin = blockIdx.y * k_per;
   const int nk = min(nk_all, k_begin + k_per);   // this block runs K-steps [k_begin, nk)
@@ -528,6 +530,8 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const unsigned OOB = 0x80000000u;
   const size_t a1_bytes = (size_t)P.Hs * P.Ws * P.C1 * 2 * (P.M / HW);
   const size_t a2_bytes = P.p2 ? (size_t)P.Hs * P.Ws * P.C2 * 2 * (P.M / HW) : 0;
+  const size_t a3_bytes = (size_t)P.Hs * P.Ws * P.C3 * 2 * (P.M / HW);
+  const size_t a4_bytes = (size_t)P.Hs * P.Ws * P.C4 * 2 * (P.M / HW);
   const int smp = P.wt_bstride ? m0 / P.rows_per_batch : 0;     // per-sample weights: the tile lies inside one sample
   const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.wt + (size_t)smp * P.wt_bstride, (size_t)P.N * P.K * 2);
   unsigned wvo[BN / 32];
@@ -544,13 +548,14 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   auto stage = [&](int buf, int kt) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
-    const int tap = kt / cpt, cc = kt - tap * cpt;
-    const int srcsel = cc < cpt1 ? 0 : 1;
-    if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing the concat boundary
+    int tap, cc, srcsel;
+    if (kt < nk_main) { tap = kt / cpt; cc = kt - tap * cpt; srcsel = cc < cpt1 ? 0 : 1; }
+    else { tap = 16; cc = kt - nk_main; srcsel = cc < cpt3 ? 2 : 3; }      // pointwise extension: tap (0, 0) of sources 3 / 4
+    if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing a source boundary
       seg_tap = tap; seg_src = srcsel;
       int dy = 0, dx = 0;
-      if (P.taps == 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
-      const int cs = srcsel ? P.C2 : P.C1;
+      if (P.taps == 9 && tap < 9) { dy = tap / 3 - P.pad; dx = tap - (tap / 3) * 3 - P.pad; }
+      const int cs = srcsel == 0 ? P.C1 : srcsel == 1 ? P.C2 : srcsel == 2 ? P.C3 : P.C4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (i * 4 + w) * 8 + (lane >> 3);
@@ -561,9 +566,10 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
         avo[i] = ok ? (unsigned)(((size_t)(rb[i] + sy * P.Ws + sx) * cs + chunk * 8) * 2) : OOB;
       }
     }
-    const unsigned coff = (unsigned)((srcsel ? cc - cpt1 : cc) * 128);
-    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(srcsel ? (const void*)P.p2 : (const void*)P.p1,
-                                                    srcsel ? a2_bytes : a1_bytes);
+    const unsigned coff = (unsigned)((srcsel == 1 ? cc - cpt1 : srcsel == 3 ? cc - cpt3 : cc) * 128);
+    const __amdgpu_buffer_rsrc_t rsA =
+        srcsel == 0 ? uniform_rsrc((const void*)P.p1, a1_bytes) : srcsel == 1 ? uniform_rsrc((const void*)P.p2, a2_bytes)
+      : srcsel == 2 ? uniform_rsrc((const void*)P.p3, a3_bytes) : uniform_rsrc((const void*)P.p4, a4_bytes);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * 4 + w) * 8) * 128), 16, avo[i], coff, 0, 0);
@@ -1309,7 +1315,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.p3 = (const f16*)a->skip1; P.C3 = a->skip1 ? a->Cs1 : 0;
   P.p4 = a->skip1 ? (const f16*)a->skip2 : nullptr; P.C4 = P.p4 ? a->Cs2 : 0;
   if (P.p3) {      // pointwise K extension (the ResBlock's skip_connection inside its last conv): see GemmParams.p3
-    if (P.c16 || a->taps != 9 || a->stride != 1 || a->up != 0 || a->asym || a->geglu || a->ln_stats || a->wt_bstride || a->wt_pm ||
+    if (P.c16 || a->stride != 1 || a->up != 0 || a->asym || a->geglu || a->ln_stats || a->wt_bstride || a->wt_pm ||
         a->Hs != a->H || a->Ws != a->W)
       return LR_E_UNSUPPORTED;
     if (P.C3 <= 0 || P.C3 % 64 || P.C4 % 64 || (((uintptr_t)P.p3 | (uintptr_t)P.p4) & 15)) return LR_E_ALIGN;
@@ -1402,7 +1408,6 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
   if (a->pipe != 0 && a->pipe != choose_stages(tm, tn, a->pipe)) return LR_E_UNSUPPORTED;
   const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
-  if (P.p3 && !(tm == 256 || deep)) return LR_E_UNSUPPORTED;      // only the pipelined instances gather the extension
   if (mode == 0) {
     if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 0>(P, st);
     else if (deep && tn == 160) rc = launch_pipe<128, 8, 160, 4, 4, 0>(P, st);

@@ -209,6 +209,22 @@ class PackedST:
         if self.proj_out.w.shape == (ops.FFN_C, ops.FFN_C) and self.proj_out.b is not None:
             w_ = st.proj_out.weight.detach()
             self.proj_out_x = packing.pack_pieces(w_.reshape(w_.shape[0], w_.shape[1]), compute_dtype())      # fused behind the last block's feed-forward
+        # proj_out composed with the last block's second feed-forward Linear (attention.py:75-77, 282, 412-419): two linear maps in a row,
+        #   proj_out(ff2(g) + b2 + x) + bp + x_in = (Wp W2) g + Wp x + (Wp b2 + bp) + x_in,
+        # run as ONE GEMM over [g | x] (lr_gemm_args.skip1 with taps == 1) where no fused feed-forward kernel exists (C > 320): the product
+        # Wp W2 is formed in fp32 and rounded once, x3 = ff(..) + x is never rounded or written, a K = C launch per SpatialTransformer is gone
+        self.ff_proj_w = self.ff_proj_b = None
+        ff2 = st.transformer_blocks[-1].ff.net[2]
+        wp = st.proj_out.weight.detach().float()
+        wp = wp.reshape(wp.shape[0], wp.shape[1])
+        if self.proj_out_x is None and wp.shape[0] == wp.shape[1] == ff2.weight.shape[0] and wp.shape[1] % 64 == 0:
+            # (formed once at pack time, in fp64 on the host: no GPU BLAS on any path of this package, and no dependence on a summation order)
+            dev_ = wp.device
+            wp64, w2_64 = wp.double().cpu(), ff2.weight.detach().double().cpu()
+            self.ff_proj_w = torch.cat([(wp64 @ w2_64).float(), wp64.float()], dim=1).to(device=dev_, dtype=compute_dtype()).contiguous()
+            b2 = ff2.bias.detach().double().cpu() if ff2.bias is not None else torch.zeros(w2_64.shape[0], dtype=torch.float64)
+            bp = st.proj_out.bias.detach().double().cpu() if st.proj_out.bias is not None else torch.zeros(wp64.shape[0], dtype=torch.float64)
+            self.ff_proj_b = (wp64 @ b2 + bp).float().to(dev_).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -236,6 +252,8 @@ def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear):
 GN_FUSE = __import__("os").environ.get("LEFTREFILL_GN_FUSE", "1") != "0"
 # a ResBlock's 1x1 skip_connection as extra K-steps of its last conv (lr_gemm_args.skip1); 0 = separate GEMM + residual epilogue
 SKIP_FUSED = __import__("os").environ.get("LEFTREFILL_SKIP_FUSED", "1") != "0"
+# SpatialTransformer.proj_out composed with the last feed-forward Linear into one GEMM (levels without the fused feed-forward kernel)
+FF_PROJ = __import__("os").environ.get("LEFTREFILL_FF_PROJ", "1") != "0"
 
 
 def gn_fuse_ok(x):
@@ -437,7 +455,10 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
     post = (proj_out pieces, bias, x_in, want_gn): when the fused kernel runs, SpatialTransformer.proj_out (+ x_in) rides behind it in
     the same launch and the result is ("post", out, GroupNorm statistics | None) instead."""
     fused = ffn_fused(x, pt) if fused is None else fused
-    if post is not None and FFN_POST and fused:
+    compose = post is not None and post[0] == "compose"
+    if compose and fused:
+        compose, post = False, None
+    if post is not None and not compose and FFN_POST and fused:
         pw, pb, x_in, want_gn, hw = post
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, post=(pw, pb, x_in), want_gn_stats=want_gn,
                           gn_hw=hw)
@@ -453,6 +474,11 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
     else:
         n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
         g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
+    if compose:
+        # SpatialTransformer.proj_out behind the block: (Wp W2) g + Wp x + b' + x_in in one GEMM over [g | x] (PackedST.ff_proj_w)
+        _, wc, bc, x_in, hw = post
+        y, gs = ops.gemm_conv(g, wc, B=1, H=1, W=g.shape[0], taps=1, bias=bc, resid=x_in, skip=(x, None), want_gn_stats=True, gn_hw=hw)
+        return ("post", y, gs)
     ws = want_stats and fold_ok(x)
     y = linear(g, pt.ff2, resid=x, want_stats=ws)
     return y if ws else (y, None)
@@ -550,7 +576,11 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
         last = i + 1 == len(ps.blocks)
-        post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW) if last and ps.proj_out_x is not None else None
+        post = None
+        if last and ps.proj_out_x is not None:
+            post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW)
+        elif last and ps.ff_proj_w is not None and FF_PROJ and want:
+            post = ("compose", ps.ff_proj_w, ps.ff_proj_b, x_in, act.HW)      # proj_out composed with the last feed-forward Linear
         r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post)
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
             return Act(r[1], act.N, act.H, act.W, gs=r[2])

@@ -283,7 +283,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if s2 is not None:
             _chk16(s2, "skip2")
             Cs2 = s2.shape[-1]
-        assert taps == 9 and stride == 1 and not up and s1.shape[0] == B * H * W and (s2 is None or s2.shape[0] == s1.shape[0])
+        assert stride == 1 and not up and s1.shape[0] == B * H * W and (s2 is None or s2.shape[0] == s1.shape[0])
     assert c16 or Kw == taps * (C1 + C2) + Cs1 + Cs2, (wt.shape, taps, C1, C2, Cs1, Cs2)
     if c16 and tile_m == 0 and tile_n == 0:
         # only the pipelined 256-row instances gather 16-channel taps
@@ -349,8 +349,6 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             plan = (ctypes.c_int32 * 4)()
             lib.lr_gemm_plan(a, plan)
             a.tile_m, a.tile_n, a.splits, a.pipe = plan[0], plan[1], plan[2], plan[3]
-        if skip is not None and a.tile_m == 128 and a.pipe != 4:      # only the pipelined instances gather the extension
-            a.tile_n, a.pipe = (a.tile_n if a.tile_n in (128, 160) else (160 if Nw % 160 == 0 else 128)), 4
     stats = None
     if want_stats:
         if a.splits == 0:

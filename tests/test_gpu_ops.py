@@ -349,8 +349,20 @@ def test_conv_with_fused_skip_connection(tile, splits):
     # a single skip source
     y1 = ops.gemm_conv(th, torch.cat([packing.pack_conv(w3), packing.pack_conv(ws[:, :Cx1])], 1).half().contiguous().to(d), skip=(t1, None), **kw)
     report("conv + fused skip, one source", from_tok(y1, N, H, W), F.conv2d(hx, w3, b3, padding=1) + F.conv2d(x1, ws[:, :Cx1], bs), rtol=3e-3, atol=3e-3)
-    with pytest.raises(RuntimeError):
-        ops.gemm_conv(th, wf, skip=(t1, t2), B=N, H=H, W=W, taps=9, bias=bf, tile_m=128, tile_n=64, splits=1)
+    # the 2-stage 128-row kernel gathers the extension too
+    y64 = ops.gemm_conv(th, wf, skip=(t1, t2), B=N, H=H, W=W, taps=9, bias=bf, tile_m=128, tile_n=64, splits=1)
+    report("conv + fused skip 128x64", from_tok(y64, N, H, W), ref, rtol=3e-3, atol=3e-3)
+    # pointwise main part: out = W_a g + W_s x + b + resid (SpatialTransformer.proj_out composed with the last feed-forward Linear)
+    M = N * H * W
+    g = h16(G.T(name + ".g", (M, 1280)))
+    xs = h16(G.T(name + ".xs", (M, 320)))
+    rs = h16(G.T(name + ".rs", (M, 320)))
+    wa = h16(torch.from_numpy(weights.fill_like(name + ".wa", (320, 1280))))
+    wsx = h16(torch.from_numpy(weights.fill_like(name + ".wsx", (320, 320))))
+    refp = g @ wa.t() + xs @ wsx.t() + b3 + rs
+    yp = ops.gemm_conv(g.half().to(d), torch.cat([wa, wsx], 1).half().contiguous().to(d), B=1, H=1, W=M, taps=1, bias=packing.pack_bias(b3).to(d)[:320].contiguous(),
+                       resid=rs.half().to(d), skip=(xs.half().to(d), None), splits=splits, **tile_kw(tile))
+    report(f"pointwise + extension {tile} s{splits}", yp.float().cpu(), refp, rtol=3e-3, atol=3e-3)
 
 
 # (tile_m, tile_n[, pipe]): every GEMM instance; pipe 4 = the 8-wave 4-stage 128-row kernel
