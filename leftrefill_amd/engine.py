@@ -301,7 +301,7 @@ def resblock(act: Act, pr: PackedRes, emb_out):
     h = gn(act, pr.n1, True)
     h = conv(h, pr.c1, rowvec=emb_out, gn_stats=True)
     h = gn(h, pr.n2, True)
-    if pr.c2s is not None and SKIP_FUSED and gn_fuse_ok(act.tok):
+    if pr.c2s is not None and SKIP_FUSED and gn_fuse_ok(act.tok) and gn_fuse_ok(h.tok) and (act.tok2 is None or gn_fuse_ok(act.tok2)):
         # inference: the 1x1 skip_connection of a width-changing block rides on the last conv's K loop (no separate GEMM, no residual pass)
         return conv(h, pr.c2s, gn_stats=True, skip=(act.tok, act.tok2))
     if pr.skip is not None:
@@ -456,7 +456,7 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
     the same launch and the result is ("post", out, GroupNorm statistics | None) instead."""
     fused = ffn_fused(x, pt) if fused is None else fused
     compose = post is not None and post[0] == "compose"
-    if compose and fused:
+    if compose and (fused or (torch.is_grad_enabled() and x.requires_grad)):      # (the composed GEMM has no backward: training keeps two layers)
         compose, post = False, None
     if post is not None and not compose and FFN_POST and fused:
         pw, pb, x_in, want_gn, hw = post

@@ -93,8 +93,11 @@ class _GemmConv(torch.autograd.Function):
 
 
 def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
-    if not _needs_grad(x1, x2, resid):
+    sk = kw.get("skip") or ()
+    if not _needs_grad(x1, x2, resid, *[t for t in sk if t is not None]):
         return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
+    if sk:
+        raise NotImplementedError("the K-extended GEMM (skip=) is an inference kernel; differentiate the two layers separately")
     if kw.get("ln") is not None:
         raise NotImplementedError("the LayerNorm-folded GEMM is an inference kernel; differentiate layer_norm + gemm_conv")
     if kw.pop("want_stats", False) or kw.pop("want_gn_stats", False):   # epilogue statistics feed inference-only fusions
