@@ -141,7 +141,9 @@ __device__ __forceinline__ vec8<T> load_q(const T* p, const float c) {
 //      c ^ (4 ((r >> 1) & 1)): the four rows of a read (128 bytes apart) then cover 64 distinct banks per half-wave.
 // CAUSAL = true: key j is visible to query i only if j <= i (the text tower's attn_mask); every tile takes the masked path.
 // EXACT = true: unscaled Q, softmax_block<FOLD = false> (the training forward with its log-sum-exp output).
-template <typename T, int VM, bool CAUSAL = false, bool EXACT = false>
+// NQB = 32-query blocks per wave: 2 (256 queries per block, every K / V fragment feeds both) or 1 (128 queries per block: twice the
+//       blocks at about half the registers, for shapes whose 256-query blocks leave the chip a badly filled last round).
+template <typename T, int VM, bool CAUSAL = false, bool EXACT = false, int NQB = 2>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams<T> P) {
   constexpr bool VT = VM == 1, TR = VM == 2;
 #ifdef LR_ATTN_NOFOLD      // developer A/B build (tools/build_variant.sh nofold -DLR_ATTN_NOFOLD)
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 
   const int ql = lane & 31, hi = lane >> 5;
   // each wave owns 64 queries as two 32-query blocks that share every K / V fragment read from LDS
-  int qrow[2];
-  vec8<T> qf[2][4];   // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
+  int qrow[NQB];
+  vec8<T> qf[NQB][4];   // Q^T fragments: B-operand of mfma(K, Q^T): lane holds Q[q][s*16 + hi*8 .. +8]
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    qrow[qb] = qt * ATT_QB + w * 64 + qb * 32 + ql;
+  for (int qb = 0; qb < NQB; ++qb) {
+    qrow[qb] = qt * (128 * NQB) + w * (32 * NQB) + qb * 32 + ql;
     const int qc = min(qrow[qb], P.Nq - 1);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
@@ -250,16 +252,20 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
     }
   };
 
-  f32x16 oacc[2][2];
+  f32x16 oacc[NQB][2];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
-  float m_run[2] = {FOLD ? 0.f : -INFINITY, FOLD ? 0.f : -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[NQB], l_run[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = FOLD ? 0.f : -INFINITY; l_run[qb] = 0.f; }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  f32x16 minit[2] = {zero16, zero16};      // FOLD: -m_run of the query, the C operand of the first QK^T MFMA of every tile
+  f32x16 minit[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) minit[qb] = zero16;      // FOLD: -m_run of the query, the C operand of the first QK^T MFMA of every tile
 
   stage_k(0, 0);
   if constexpr (VT) {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 
     // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: four independent accumulator chains (2 query blocks x 2 key blocks),
     // every K fragment read from LDS feeds both query blocks
-    f32x16 sacc[2][2];
+    f32x16 sacc[NQB][2];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -300,13 +306,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
         const int kc = s4 * 2 + hi;
         const vec8<T> kf = *reinterpret_cast<const vec8<T>*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
           sacc[qb][kb] = lr_mfma32(kf, qf[qb][s4], s4 == 0 ? (FOLD ? minit[qb] : zero16) : sacc[qb][kb]);
       }
 
-    vec8<T> pf[2][2][2];
+    vec8<T> pf[NQB][2][2];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
       // ---- mask the tail tile: accumulator reg r of block kb is key kb*32 + (r&3) + 8*(r>>2) + 4*hi
       if constexpr (TAIL) {
 #pragma unroll
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
             vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
           }
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb)
+          for (int qb = 0; qb < NQB; ++qb)
             oacc[qb][db] = lr_mfma32(vf, pf[qb][kb][tt], oacc[qb][db]);
         }
     if constexpr (VM == 0) {
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
     float lt = l_run[qb];
     {
       const unsigned u = __builtin_bit_cast(unsigned, lt);
@@ -641,6 +647,12 @@ static int attn_pp_mode() {
   return v ? atoi(v) : 0;
 }
 
+// LR_ATTN_NQB = 1 | 2 forces 128- / 256-query blocks for lr_attention_f16 on natural V; unset: the rule in launch_attention
+static int attn_nqb_mode() {
+  const char* v = getenv("LR_ATTN_NQB");
+  return v ? atoi(v) : 0;
+}
+
 // developer switch: LR_ATTN_TR=0 sends natural-layout V through the register transpose (VM = 0) instead of the LDS transpose read
 static bool attn_tr_mode() {
   const char* v = getenv("LR_ATTN_TR");
@@ -681,7 +693,27 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
     if (vt) return LR_E_UNSUPPORTED;
     hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   } else if (vt) hipLaunchKernelGGL((attention_kernel<T, 1>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
-  else if (attn_tr_mode()) hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+  else if (attn_tr_mode()) {
+    // 256-query blocks (two 32-query blocks per wave) run two per CU, 128-query blocks three per CU (142 registers).  The kernel is
+    // VALU-bound: a CU delivers about the same throughput with one, two or three resident blocks (a block alone runs ~1.8x faster than
+    // one of a pair), so what costs time is a last round that leaves CUs EMPTY for a whole block time.  Small cost model in units of the
+    // time of a paired 256-query block (measured shapes: profiles/r04_attn_nqb.txt): the block size with the shorter estimate wins,
+    // 128-query blocks only with a 5 % margin (they share no K / V fragment between query blocks: +8 % work).
+    auto tail = [](int r, int per_cu, float full, float two, float one) {      // cost of a partial round of r blocks
+      return r == 0 ? 0.f : r <= 256 ? one : (per_cu == 2 || r <= 512) ? two : full;
+    };
+    const int nb2 = P.nblocks, nb1 = ((Nq + 127) / 128) * heads * B;
+    const float t2 = (float)(nb2 / 512) + tail(nb2 % 512, 2, 1.f, 1.f, 0.556f);
+    const float t1 = 1.08f * (0.75f * (float)(nb1 / 768) + tail(nb1 % 768, 3, 0.75f, 0.5f, 0.28f));
+    const int mode = attn_nqb_mode();
+    const bool small = mode == 1 || (mode == 0 && t1 < 0.95f * t2);
+    if (small) {
+      P.nqt = (Nq + 127) / 128; P.nblocks = P.nqt * heads * B;
+      hipLaunchKernelGGL((attention_kernel<T, 2, false, false, 1>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+    } else {
+      hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+    }
+  }
   else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
   return lr_launch_status();
 }

@@ -815,6 +815,17 @@ def test_attention_pretransposed_v(B, heads, Nq, Nkv):
             outs[mode] = ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5)
     assert torch.equal(outs["tr"], outs["vt"]) and torch.equal(outs["tr"], outs["reg"])
     assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt), outs["tr"])
+    # 128- and 256-query blocks (LR_ATTN_NQB; the library picks by grid size) run the same arithmetic per query
+    old_nqb = os.environ.get("LR_ATTN_NQB")
+    try:
+        for nqb in ("1", "2"):
+            os.environ["LR_ATTN_NQB"] = nqb
+            assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5), outs["tr"]), nqb
+    finally:
+        if old_nqb is None:
+            os.environ.pop("LR_ATTN_NQB", None)
+        else:
+            os.environ["LR_ATTN_NQB"] = old_nqb
 
 
 def test_attention_online_softmax_rescale():
