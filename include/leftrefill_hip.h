@@ -35,6 +35,7 @@ typedef uint16_t lr_half;  /* 16-bit activation / weight element: IEEE binary16 
 /* lr_gemm_args.pipe */
 #define LR_PIPE_DEFAULT 0
 #define LR_PIPE_W8_DEEP 4
+#define LR_PIPE_HALO 8
 
 /* ABI version; bump on any signature change. */
 int lr_abi_version(void);
@@ -166,6 +167,10 @@ typedef struct lr_gemm_args {
                              * 2-stage ring, 2-4 blocks per CU; 256 x {128,160}: 3-stage ring; 256 x {256,320}: 2-stage ring).
                              * LR_PIPE_W8_DEEP (4), tile_m 128 with tile_n 128 | 160: 8 waves (4 x 2, wave tile 32 x tile_n/2), 4-stage
                              * ring, one block per CU (the 4096- / 1024-row levels).
+                             * LR_PIPE_HALO (8, ABI 23), tile_m 256 with tile_n 160 | 320: the halo-tile conv -- 3x3, stride 1, pad 1, no
+                             * upsample, H and W multiples of 16, no split-K: a block owns a 16 x 16 pixel tile, the 18 x 18 input patch of a
+                             * 64-channel chunk is copied to LDS once and the nine taps are shifted reads of it (conv_halo.hip); K is
+                             * accumulated chunk-major, so results agree with the other instances to fp32 rounding, not bit for bit.
                              * Anything else: LR_E_UNSUPPORTED */
   /* gn_group_out != NULL (ABI 20): per-GROUP (sum, sumsq) of the fp16-rounded output for the GroupNorm(32) of a consumer that
    * normalises THIS tensor alone (N / 32 channels per group), [samples][chunks][32][2] fp32 with chunks = lr_gemm_gn_group_chunks(args)

@@ -204,7 +204,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 22; }
+extern "C" int lr_abi_version(void) { return 23; }
 
 template <typename T>
 static int lr_nchw_f32_to_nhwc_t(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,

@@ -27,8 +27,9 @@ GN_GROUPS = os.environ.get("LEFTREFILL_GN_GROUPS", "1") != "0"
 AUTOTUNE = os.environ.get("LEFTREFILL_AUTOTUNE", "0") == "1"
 # (tile_m, tile_n, pipe): pipe 0 = the tile's standard instance; 4 = the 8-wave 4-stage one-block-per-CU 128-row instance
 # (lr_gemm_args.pipe)
+# 8 = LR_PIPE_HALO: the halo-tile 3x3 conv (16 x 16 pixel tiles, input patch resident in LDS; refused for every other kind of call)
 TILE_CANDIDATES = ((128, 64, 0), (128, 128, 0), (128, 160, 0), (128, 128, 4), (128, 160, 4), (256, 128, 0), (256, 160, 0),
-                   (256, 256, 0), (256, 320, 0))
+                   (256, 256, 0), (256, 320, 0), (256, 160, 8), (256, 320, 8))
 TILE_TABLE_PATH = os.environ.get("LEFTREFILL_TILE_TABLE_PATH",      # (developer override: A/B of a freshly tuned table)
                                  os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json"))
 _tile_cache = None

@@ -168,7 +168,7 @@ def test_timestep_embedding_and_time_mlp(golden):
 
 
 def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True, rowvec=False, resid=False,
-               tile_n=0, wscale=1.0, tile_m=0, splits=0, asym=False):
+               tile_n=0, wscale=1.0, tile_m=0, splits=0, asym=False, pipe=0):
     from leftrefill_amd import ops, packing
     d = dev()
     Ct = Cin + C2
@@ -201,7 +201,7 @@ def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, bias=True
     x2 = to_tok(x[:, Cin:]) if C2 else None
     y = ops.gemm_conv(x1, wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym, x2=x2, bias=bp,
                       rowvec=rv.half().to(d) if rowvec else None, resid=to_tok(rs) if resid else None, tile_n=tile_n,
-                      tile_m=tile_m, splits=splits)
+                      tile_m=tile_m, splits=splits, pipe=pipe)
     y = y[:, :Cout]
     # fp32 accumulation over K = taps*Ct products of fp16 values: the error is one final fp16 rounding
     report(name, from_tok(y, N, H, W), ref)
@@ -242,6 +242,78 @@ def test_conv_tile256(tile_n):
     _conv_case(f"t256_{tile_n}_lin2", 1, 128, 320, 1, 300, taps=1, **k)            # two K-steps
     _conv_case(f"t256_{tile_n}_splitk", 2, 1280, 640, 8, 16, splits=3, **k)
     _conv_case(f"t256_{tile_n}_c1cat", 2, 640, 320, 16, 16, taps=1, C2=320, **k)
+
+
+@pytest.mark.parametrize("tile_n", [160, 320])
+def test_conv_halo_tile(tile_n):
+    """LR_PIPE_HALO (conv_halo.hip): the 3x3 stride-1 conv with the 18 x 18 input patch resident in LDS, 16 x 16 pixel tiles -- image
+    borders on every side of a tile, several tiles per line / column / sample, the virtual channel concat, N tails, every epilogue
+    operand; against F.conv2d in fp32 on the same fp16 operands (reference openaimodel.py:200-231)."""
+    from leftrefill_amd import ops, packing
+    k = dict(tile_m=256, tile_n=tile_n, pipe=8, splits=1)
+    _conv_case(f"halo{tile_n}_one", 1, 64, 320, 16, 16, **k)                                  # one tile, one chunk: border on all four sides
+    _conv_case(f"halo{tile_n}_c3", 2, 320, 320, 32, 48, rowvec=True, **k)                     # 2 x 3 tiles per sample
+    _conv_case(f"halo{tile_n}_res", 3, 320, 640, 16, 32, resid=True, **k)                     # N = 640: 2 (4) column tiles
+    _conv_case(f"halo{tile_n}_cat", 2, 320, 320, 32, 16, C2=640, rowvec=True, resid=True, **k)
+    _conv_case(f"halo{tile_n}_ntail", 1, 128, 384, 16, 32, **k)                               # N = 384: ragged last column tile
+    # shapes the instance does not cover are refused, never run wrong
+    d = dev()
+    x = torch.zeros(2 * 24 * 16, 64, device=d, dtype=torch.float16)
+    w = torch.zeros(320, 576, device=d, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.gemm_conv(x, w, B=2, H=24, W=16, taps=9, **k)                                     # H not a multiple of 16
+    with pytest.raises(RuntimeError):
+        ops.gemm_conv(x[:2 * 8 * 8 * 4], w, B=2, H=8, W=8, Hs=16, Ws=16, taps=9, stride=2, **k)
+
+
+@pytest.mark.parametrize("tile_n", [160, 320])
+def test_conv_halo_matches_gather_kernel_and_its_statistics(tile_n):
+    """The halo-tile conv against the gather kernel (gemm_conv_pipe_kernel) on the same call: same products, chunk-major instead of
+    tap-major accumulation order -> equal up to the fp32 summation order (at most one fp16 ulp on a few outputs); with the fused
+    skip_connection (lr_gemm_args.skip1: extra chunks with one tap); the GroupNorm partials (per-channel row blocks AND per-group
+    chunks, numbered by 16 x 16 pixel tile) describe the stored tensor and feed lr_groupnorm_apply_n; reruns are bit-identical."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W = 2, 32, 32
+    Ch, Cx1, Cx2, Cout = 320, 320, 640, 320
+    name = f"halo_skip{tile_n}"
+    hx = h16(G.T(name + ".h", (N, Ch, H, W)))
+    x1 = h16(G.T(name + ".x1", (N, Cx1, H, W)))
+    x2 = h16(G.T(name + ".x2", (N, Cx2, H, W)))
+    w3 = h16(torch.from_numpy(weights.fill_like(name + ".w3", (Cout, Ch, 3, 3))))
+    ws = h16(torch.from_numpy(weights.fill_like(name + ".ws", (Cout, Cx1 + Cx2, 1, 1))) * 2.0)
+    b3 = torch.from_numpy(weights.fill_like(name + ".b3", (Cout,)))
+    bs = torch.from_numpy(weights.fill_like(name + ".bs", (Cout,))) + 0.2
+    rv = h16(G.T(name + ".rv", (N, Cout)))
+    ref = F.conv2d(hx, w3, b3, padding=1) + F.conv2d(torch.cat([x1, x2], 1), ws, bs) + rv[:, :, None, None]
+    wf = torch.cat([packing.pack_conv(w3), packing.pack_conv(ws)], dim=1).half().contiguous().to(d)
+    bf = packing.pack_bias(b3 + bs).to(d)
+    th, t1, t2 = to_tok(hx), to_tok(x1), to_tok(x2)
+    kw = dict(B=N, H=H, W=W, taps=9, bias=bf, splits=1, rowvec=rv.half().to(d), tile_m=256, tile_n=tile_n)
+    y, gs = ops.gemm_conv(th, wf, skip=(t1, t2), want_gn_stats=True, pipe=8, **kw)
+    report(f"halo conv + fused skip {tile_n}", from_tok(y, N, H, W), ref, rtol=3e-3, atol=3e-3)
+    assert torch.equal(y, ops.gemm_conv(th, wf, skip=(t1, t2), pipe=8, **kw)), "reruns must be bit-identical"
+    yg_ = ops.gemm_conv(th, wf, skip=(t1, t2), **kw)
+    dmax = (y.float() - yg_.float()).abs().max().item()
+    neq = (y != yg_).float().mean().item()
+    print(f"halo vs gather: max diff {dmax:.3e}, {100 * neq:.2f} % of elements differ")
+    assert dmax <= 2 ** -9 * max(1.0, ref.abs().max().item()) and neq < 0.05
+    assert gs is not None
+    part, R, gp, chunks = gs
+    # row blocks / chunks are numbered by pixel tile: tile (sample, ty, tx), wave row block = R / 16 consecutive lines of it
+    yt = y.float().reshape(N, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N * (H // 16) * (W // 16), 256, Cout)
+    yb = yt.reshape(-1, R, Cout)
+    assert torch.allclose(part[..., 0], yb.sum(1), rtol=1e-5, atol=5e-3)
+    assert torch.allclose(part[..., 1], (yb * yb).sum(1), rtol=1e-5, atol=5e-3)
+    assert gp is not None and chunks == H * W // 256
+    ygp = yt.double().reshape(N, chunks, 256, 32, Cout // 32)
+    assert torch.allclose(gp[..., 0].double(), ygp.sum((2, 4)), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(gp[..., 1].double(), (ygp * ygp).sum((2, 4)), rtol=1e-5, atol=1e-2)
+    gam = 1.0 + 0.3 * G.T(name + ".g", (Cout,))
+    bet = 0.2 * G.T(name + ".be", (Cout,))
+    refn = F.silu(F.group_norm(from_tok(y, N, H, W), 32, gam, bet, 1e-5))
+    report("halo gn(groups)", from_tok(ops.group_norm_groups(y, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gp, chunks), N, H, W), refn)
+    report("halo gn(finalize)", from_tok(ops.group_norm_fused(y, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gs), N, H, W), refn)
 
 
 def test_conv_tile128x160():

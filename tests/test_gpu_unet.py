@@ -151,17 +151,13 @@ def measure_unet(case, cname, N, H, W, ts, ref=None, multiview=None, bisect=Fals
 
 
 def assert_unet_row(row):
-    """Whole-network criterion (no slack factors beyond the measured noise band below).  Against the fp32 reference the HIP path is at least as
-    accurate as the reference's own fp16-autocast numerics (oracle emulation) in relative L2 and in the fraction of elements
-    outside the north-star tolerance; its largest error stays within 2x the emulation's (a max over ~1e5..1e6 elements is a
-    noisy statistic); and HIP against the emulation is bounded too (two fp16 pipelines around the same fp32 answer differ by
-    at most the sum of their errors)."""
+    """Whole-network criterion, no slack factors (restored in round 5 after VERDICT r4 #2 / ADVICE r4).  Against the fp32
+    reference the HIP path is at least as accurate as the reference's own fp16-autocast numerics (oracle emulation) in relative L2
+    and in the fraction of elements outside the north-star tolerance; its largest error stays within 2x the emulation's (a max over
+    ~1e5..1e6 elements is a noisy statistic); and HIP against the emulation is bounded too (two fp16 pipelines around the same fp32
+    answer differ by at most the sum of their errors).  A change that needs a band on the first line again is a parity regression."""
     rel, rel_e = row["rel"], row["rel_emu"]
-    # (round 4: a 3 % band on the relative-L2 comparison.  The two numbers are realisations of the same fp16 rounding noise: switching
-    # between equally exact summation orders inside the HIP path -- e.g. the GroupNorm statistics as per-group instead of per-channel
-    # partials -- moves rel-L2 of a case by -3 .. +6 % (profiles/r04_parity_toggles.txt), so "<= the emulation to the last digit"
-    # would test the dice, not the kernels; the violation-fraction criterion below stays exact.)
-    assert rel <= min(1.03 * rel_e, 4e-3), (rel, rel_e)
+    assert rel <= min(rel_e, 4e-3), (rel, rel_e)
     assert row["max_abs"] <= max(2.0 * row["max_abs_emu"], 5e-3), (row["max_abs"], row["max_abs_emu"])
     assert row["viol"] <= row["viol_emu"], (row["viol"], row["viol_emu"])
     assert row["rel_hip_vs_emu"] <= rel + rel_e, (row["rel_hip_vs_emu"], rel, rel_e)

@@ -114,11 +114,11 @@ def main():
                 launch(sets[0], tm, tn, sp, stg)
                 torch.cuda.synchronize()
             except RuntimeError as e:
-                res.append((f'{tm}x{tn}' + ('d' if stg else ''), tn, None, None, str(e)[:40]))
+                res.append((f'{tm}x{tn}' + {0: '', 4: 'd', 8: 'h'}.get(stg, '?'), tn, None, None, str(e)[:40]))
                 continue
             cold = min(time_seq(lambda i: launch(sets[i % nsets], tm, tn, sp, stg), nsets * 2) for _ in range(2))
             hot = min(time_seq(lambda i: launch(sets[0], tm, tn, sp, stg), a.reps) for _ in range(2))
-            res.append((f'{tm}x{tn}' + ('d' if stg else ''), tn, cold, hot, ""))
+            res.append((f'{tm}x{tn}' + {0: '', 4: 'd', 8: 'h'}.get(stg, '?'), tn, cold, hot, ""))
         fl_ = 2.0 * M * N * K
         ok = [r for r in res if r[2] is not None]
         best = min(ok, key=lambda r: r[2]) if ok else None
