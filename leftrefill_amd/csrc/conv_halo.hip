@@ -28,6 +28,9 @@
 // * Epilogue: the register epilogue of the GEMM family (gemm_common.h) with row tile i = 16 pixels of image line i of the wave.
 #include "gemm_common.h"
 
+#ifndef HALO_EXP       // developer experiments (timing only, wrong results): 1 = never reload the patch, 3 = never reload the weights
+#define HALO_EXP 0
+#endif
 #define HALO_PW 18          // patch width / height in pixels (16 + 2)
 #define HALO_NPX 324
 #define HALO_NQ 41          // LDS-DMA instructions per patch (8 pixel rows of 128 B each): 328 rows, the last 4 unused
@@ -201,14 +204,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
     read_frags(xa, wa, cur, 0, ky, kx);
     __builtin_amdgcn_sched_barrier(0);
     // (past the end of K the weights go through a zero-length descriptor: same instruction count in every step, constant waits)
-    rsW = pf_w ? rsB : rsZ;
+    rsW = (pf_w && HALO_EXP != 3) ? rsB : rsZ;
     issue_weights(wslot, wkoff(wci, wtap));
     advance(wci, wtap);
     mma(xa, wa);
     spread(integral_constant<int, NB_FULL>{});
     __builtin_amdgcn_sched_barrier(0);
     read_frags(xa, wa, cur, 1, ky, kx);
-    if (pf_p) {
+    if (pf_p && HALO_EXP != 1) {
       // every wave's last reads of this patch are in registers -> the buffer is free for the next chunk
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

@@ -346,6 +346,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
             a.pipe = best[3] if len(best) > 3 else 0
+            if a.pipe == 8 and (H % 16 or W % 16):      # the table is keyed by M: the halo-tile instance needs 16 x 16 pixel tiles,
+                a.pipe = 0                              # any other latent of the same size takes the tile's gather instance
         if skip is not None and best is None:      # static heuristic: ask the library, then make sure the tile is a pipelined one
             plan = (ctypes.c_int32 * 4)()
             lib.lr_gemm_plan(a, plan)

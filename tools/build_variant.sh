@@ -1,12 +1,16 @@
 #!/bin/bash
-# Build a variant of the library for a same-box A/B:  tools/build_variant.sh NAME [extra hipcc flags, e.g. -DXA_SPREAD=0]
+# Build a variant of the library for a same-box A/B:  [VARIANT_SRCS="conv_halo gemm_conv"] tools/build_variant.sh NAME [extra hipcc flags]
 # -> leftrefill_amd/lib/variants/libleftrefill_hip_NAME.so ; run with LEFTREFILL_LIB_PATH=<that file>.
+# VARIANT_SRCS: recompile only these sources with the extra flags and link the product build's objects for the rest (run
+# `python -m leftrefill_amd.build` first); default: every source.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 out=leftrefill_amd/lib/variants; mkdir -p $out /tmp/lrv_$name
+all=$(python -c "from leftrefill_amd import build; print(' '.join(s[:-4] for s in build.SOURCES))")
 objs=""
-for s in norm elementwise gemm_conv attention attention_bwd xattn_block ffn_block conv_out; do
+for s in $all; do
+  if [ -n "$VARIANT_SRCS" ] && ! echo " $VARIANT_SRCS " | grep -q " $s "; then objs="$objs leftrefill_amd/build/$s.o"; continue; fi
   extra=""
   case $s in attention|attention_bwd|xattn_block|ffn_block) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $extra "$@" -c leftrefill_amd/csrc/$s.hip -o /tmp/lrv_$name/$s.o &

@@ -39,10 +39,15 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table.json"))
     ap.add_argument("--workloads", default="single,cfg0,mv5,train,vae")
     ap.add_argument("--fresh", action="store_true", help="ignore the committed table (re-tune every shape)")
+    ap.add_argument("--retune-conv", action="store_true",
+                    help="re-time only the 3x3 stride-1 entries (all tile candidates incl. the halo-tile instances), keep the rest of the table")
     a = ap.parse_args()
     assert ops.AUTOTUNE
     if a.fresh:
         ops.tile_cache().clear()
+    if a.retune_conv:
+        for k in [k for k in ops.tile_cache() if k.split(",")[3:6] == ["9", "1", "0"]]:
+            del ops.tile_cache()[k]
     device = torch.device("cuda:0")
     wl = a.workloads.split(",")
     model = None
