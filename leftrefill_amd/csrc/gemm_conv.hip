@@ -881,7 +881,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.p3 = (const f16*)a->skip1; P.C3 = a->skip1 ? a->Cs1 : 0;
   P.p4 = a->skip1 ? (const f16*)a->skip2 : nullptr; P.C4 = P.p4 ? a->Cs2 : 0;
   if (P.p3) {      // pointwise K extension (the ResBlock's skip_connection inside its last conv): see GemmParams.p3
-    if (P.c16 || a->stride != 1 || a->up != 0 || a->asym || a->geglu || a->ln_stats || a->wt_bstride || a->wt_pm ||
+    if (P.c16 || a->stride != 1 || a->up != 0 || a->asym || a->geglu || a->ln_stats || a->wt_bstride ||
         a->Hs != a->H || a->Ws != a->W)
       return LR_E_UNSUPPORTED;
     if (P.C3 <= 0 || P.C3 % 64 || P.C4 % 64 || (((uintptr_t)P.p3 | (uintptr_t)P.p4) & 15)) return LR_E_ALIGN;

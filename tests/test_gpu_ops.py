@@ -293,7 +293,10 @@ def test_conv_halo_matches_gather_kernel_and_its_statistics(tile_n):
     y, gs = ops.gemm_conv(th, wf, skip=(t1, t2), want_gn_stats=True, pipe=8, **kw)
     report(f"halo conv + fused skip {tile_n}", from_tok(y, N, H, W), ref, rtol=3e-3, atol=3e-3)
     assert torch.equal(y, ops.gemm_conv(th, wf, skip=(t1, t2), pipe=8, **kw)), "reruns must be bit-identical"
+    # piece-major weights [K / 64][N][64] (lr_gemm_args.wt_pm): same products in the same order, on both kernels, incl. the extension
+    assert torch.equal(y, ops.gemm_conv(th, packing.pack_pm(wf), wt_pm=True, skip=(t1, t2), pipe=8, **kw)), "piece-major weights change bits"
     yg_ = ops.gemm_conv(th, wf, skip=(t1, t2), **kw)
+    assert torch.equal(yg_, ops.gemm_conv(th, packing.pack_pm(wf), wt_pm=True, skip=(t1, t2), **kw))
     dmax = (y.float() - yg_.float()).abs().max().item()
     neq = (y != yg_).float().mean().item()
     print(f"halo vs gather: max diff {dmax:.3e}, {100 * neq:.2f} % of elements differ")

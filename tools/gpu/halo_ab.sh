@@ -1,5 +1,5 @@
-for v in "" exp1 exp3; do
-  if [ -n "$v" ]; then export LEFTREFILL_LIB_PATH=leftrefill_amd/lib/variants/libleftrefill_hip_$v.so; else unset LEFTREFILL_LIB_PATH; fi
+for v in ${VARIANTS:-cur v1}; do
+  if [ "$v" != cur ]; then export LEFTREFILL_LIB_PATH=leftrefill_amd/lib/variants/libleftrefill_hip_$v.so; else unset LEFTREFILL_LIB_PATH; fi
   echo "== variant [$v]"
   for sh in "65536 320 2880 9 256 320" "16384 640 5760 9 256 160"; do
     python - $sh <<'PY'

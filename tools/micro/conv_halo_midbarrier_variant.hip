@@ -11,10 +11,11 @@
 // (324 x 128 B = 41.5 KB instead of 9 x 32 KB) and the nine taps are shifted fragment reads of that patch; only the weights keep
 // streaming per tap.  L2 -> LDS bytes per chunk of a 256 x 320 tile: 664 KB -> 410 KB; of a 256 x 160 tile: 472 KB -> 226 KB.
 //
-// * K order: chunk-major (chunk, tap) -- the weights stay in the packed [N][tap][Cin] layout, a K-step reads the 128-byte piece
-//   k = tap * Cin + 64 chunk of every row.  (gemm_conv_pipe_kernel walks (tap, chunk): the two kernels add the same products in a
+// * K order: chunk-major (chunk, tap) -- the weights stay in the packed [N][tap][Cin] K order, a K-step reads the 128-byte piece
+//   k = tap * Cin + 64 chunk of every row.  With row-major weights [N][K] those pieces lie 2 K bytes apart and every CU of an XCD asks
+//   its L2 for the same strided lines at the same time; piece-major weights [K / 64][N][64] (lr_gemm_args.wt_pm) make a tile's K-step
+//   ONE contiguous run of BN x 128 bytes -- supported, bit-identical, and measured to make no difference here (the L2 serves both).  (gemm_conv_pipe_kernel walks (tap, chunk): the two kernels add the same products in a
 //   different order, so they agree to fp32 rounding, not bit for bit; the plan is static per shape, reruns are bit-identical.)
-//   Piece-major weights [K / 64][N][64] (lr_gemm_args.wt_pm) are accepted and bit-identical; measured to make no difference here.
 // * Patch layout: pixel p = line * 18 + column owns the 128-byte LDS row p; the 16-byte slot of channel chunk c in row p is
 //   c ^ (column & 6).  A fragment read is 16 CONSECUTIVE pixels (one output line segment shifted by the tap) at an arbitrary base, and
 //   the 16-lane groups of ds_read_b128 mix two k-chunks (c, c ^ 1): with the swizzle on the 32-byte PAIR index every group touches 16
@@ -23,15 +24,7 @@
 //   segments of a wave differ by immediate offsets (18 rows) and a tap's ky by a scalar.  LDS-DMA writes lane-linear, so the
 //   permutation sits on the per-lane source address.
 // * Zero padding = out-of-range buffer offsets (hardware returns zeros); no branches in the loader.
-// * Pipeline: ONE patch buffer + an NSTAGE-slot weight ring.  The weights of step s + NSTAGE - 1 are issued between the MFMAs of the first
-//   half of step s; at the last tap of a chunk the patch is dead once every wave has read its second-half fragments, the next chunk's
-//   patch is issued behind a mid-step barrier and lands under the second half's MFMAs.
-//   Measured and NOT kept (profiles/r05_conv_halo_proto.txt): (a) a rolling fragment schedule (line-major MFMAs, every fragment
-//   register refilled for the next half step as soon as its line is done; no bulk "read 13, multiply 40"): 102.3 vs 100.4 us at
-//   BN = 320, 107.6 vs 110.6 at BN = 160; (b) ONE barrier per K-step in the middle of the step with a whole step for the weights to
-//   land: 109 vs 103 us / 114 vs 112 us.  Ablations of this kernel (65536 x 320 x 2880, 100 us): weight stream with zero-length
-//   descriptors (instructions issued, no bytes) 88 us, no patch reload 96 us, MFMAs + barriers only 81.6 us, without the barriers 81.1 us
-//   -- what separates the kernel from its matrix-pipe time is bytes moved, not where the waits sit.
+// * Pipeline: ONE patch buffer + an NSTAGE-slot weight ring, one barrier per K-step placed in the middle of the step (see the main loop).
 // * Epilogue: the register epilogue of the GEMM family (gemm_common.h) with row tile i = 16 pixels of image line i of the wave.
 #include "gemm_common.h"
 
@@ -54,6 +47,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   constexpr bool B_TAIL = (BN % (NW * 8)) != 0;
   constexpr int TAIL_WAVES = (BN % (NW * 8)) / 8;
   constexpr int PAR_LD = ((BN + 63) / 64) * 64;
+  constexpr bool ROLL = TM * TN <= 20;      // rolling fragment schedule (needs a second fragment set's worth of registers in flight)
   static_assert(NSTAGE == 2 || NSTAGE == 3, "weight ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const patch = smem;
@@ -80,18 +74,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   const int n0 = tile_n * BN;
   const int m_org = (smp * P.H + y0) * P.W + x0;
 
-  // ---- patch loader state: source pixel of each of this lane's (up to 6) patch rows, -1 = outside the image (or row >= 324)
-  // (bit 30 of a valid entry's complement is free: the channel chunk of the lane's LDS slot, (lane & 7) ^ (column & 6), rides in bits 28-30)
-  int pix[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int px = (w + 8 * k) * 8 + (lane >> 3);
-    const int pl = (px * 3641) >> 16, pc = px - pl * HALO_PW;        // px / 18 for px < 328
-    const int y = y0 - 1 + pl, x = x0 - 1 + pc;
-    const bool ok = px < HALO_NPX && (unsigned)y < (unsigned)P.H && (unsigned)x < (unsigned)P.W;
-    const int c = (lane & 7) ^ (pc & 6);
-    pix[k] = ok ? (((smp * P.H + y) * P.W + x) | (c << 28)) : -1;
-  }
+  // ---- patch loader: piece q = w + 8 k of the patch = LDS rows 8 q .. 8 q + 7; lane l fills slot l & 7 of row 8 q + (l >> 3) with channel
+  // chunk (l & 7) ^ (column & 6) of the row's source pixel (out of the image / row >= 324: out-of-range offset -> zeros).  The addresses
+  // are re-derived per chunk (~15 VALU per piece, 9 K-steps apart) instead of living in 6 registers through the MFMA loop.
   const int Ctot = P.C1 + P.C2;
   const int cpt1 = P.C1 >> 6, ncm = Ctot >> 6, cpt3 = P.C3 >> 6;
   const int nch = ncm + ((P.C3 + P.C4) >> 6);                        // chunks: the 3x3 part, then the pointwise extension (one tap each)
@@ -104,11 +89,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
     else { src = P.p4; cs = P.C4; ch = ci - ncm - cpt3; }
     const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc((const void*)src, (size_t)P.M * cs * 2);
     const unsigned coff = (unsigned)ch * 128u;
+    int l = lane;
+    asm volatile("" : "+v"(l));      // opaque: keeps the address arithmetic below inside the loop (not hoisted into registers)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int q = w + 8 * k;
       if (q < HALO_NQ) {      // wave-uniform (only wave 0 has a sixth piece)
-        const unsigned vo = pix[k] >= 0 ? (unsigned)((pix[k] & 0x0FFFFFFF) * cs + (pix[k] >> 28) * 8) * 2u : OOB;
+        const int px = q * 8 + (l >> 3);
+        const int pl = (px * 3641) >> 16, pc = px - pl * HALO_PW;        // px / 18 for px < 328
+        const int y = y0 - 1 + pl, x = x0 - 1 + pc;
+        const bool ok = px < HALO_NPX && (unsigned)y < (unsigned)P.H && (unsigned)x < (unsigned)P.W;
+        const int c = (l & 7) ^ (pc & 6);
+        const unsigned vo = ok ? (unsigned)(((smp * P.H + y) * P.W + x) * cs + c * 8) * 2u : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(patch + q * 1024), 16, vo, coff, 0, 0);
       }
     }
@@ -118,14 +110,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc((const void*)P.wt, (size_t)P.N * P.K * 2);
   const __amdgpu_buffer_rsrc_t rsZ = uniform_rsrc((const void*)P.wt, 0);
   __amdgpu_buffer_rsrc_t rsW = rsB;
-  unsigned wvo[NB_FULL + 1];
-#pragma unroll
-  for (int i = 0; i < NB_FULL + 1; ++i) {
-    const int row = (i * NW + w) * 8 + (lane >> 3);
-    const int n = n0 + row;
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    wvo[i] = (row < BN && n < P.N) ? (unsigned)(((size_t)n * (P.wt_pm ? 64 : P.K) + chunk * 8) * 2) : OOB;
-  }
+  // (N is a multiple of BN here, so no row is out of range; rows 64 i + .. of the tile differ by a scalar offset: ONE address register.
+  //  The swizzle key (row >> 1) & 7 = 4 (w & 1) + (lane >> 4) does not depend on i.)
+  const unsigned wvo0 = (unsigned)(((size_t)(n0 + w * 8 + (lane >> 3)) * (P.wt_pm ? 64 : P.K) + (((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) & 7) * 8) * 2);
+  const unsigned wrow64 = P.wt_pm ? 64u * 128u : (unsigned)P.K * 128u;      // bytes between weight rows n and n + 64
   // byte offset of the K-step (chunk ci, tap) inside a weight row
   auto wkoff = [&](const int ci, const int tap) -> unsigned {
     // piece-major weights [K / 64][N][64] (lr_gemm_args.wt_pm): the K-step's piece index is its position in the packed K order
@@ -135,10 +123,19 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   auto issue_weights = [&](const int slot, const unsigned koff) __attribute__((always_inline)) {
     char* Bs = wring + slot * B_BYTES;
     if (B_TAIL && w < TAIL_WAVES)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((NB_FULL * NW + w) * 8) * 128), 16, wvo[NB_FULL], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((NB_FULL * NW + w) * 8) * 128), 16, wvo0, koff + NB_FULL * wrow64, 0, 0);
 #pragma unroll
     for (int i = 0; i < NB_FULL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * NW + w) * 8) * 128), 16, wvo[i], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * NW + w) * 8) * 128), 16, wvo0, koff + i * wrow64, 0, 0);
+  };
+  // piece i of a K-step's weights (i < NB_FULL: rows 64 i .. of the tile; i == NB_FULL: the tail rows, first waves only)
+  static_assert(NB_FULL + (B_TAIL ? 1 : 0) <= TM, "one LDS-DMA piece per line group");
+  auto issue_weight_piece = [&](const int slot, const unsigned koff, const int i) __attribute__((always_inline)) {
+    char* Bs = wring + slot * B_BYTES;
+    if (i < NB_FULL)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((i * NW + w) * 8) * 128), 16, wvo0, koff + i * wrow64, 0, 0);
+    else if (i == NB_FULL && B_TAIL && w < TAIL_WAVES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + ((NB_FULL * NW + w) * 8) * 128), 16, wvo0, koff + NB_FULL * wrow64, 0, 0);
   };
   auto advance = [&](int& ci, int& tap) __attribute__((always_inline)) {
     const int nt = ci < ncm ? 9 : 1;
@@ -146,38 +143,21 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   };
 
   // ---- fragments: activation = 16 consecutive patch pixels of line (wave line i + ky) starting at column kx; weights as the GEMM
+  // (the swizzle keys do not depend on the line / the weight tile: one address per operand and k-half, everything else immediates)
   const int pb0 = wm * TM * HALO_PW + fr;
-  auto read_frags = [&](vec8<T> (&xf)[TM], vec8<T> (&wf)[TN], const int slot, const int ks, const int ky, const int kx) {
-    const char* Bs = wring + slot * B_BYTES;
+  auto x_addr = [&](const int ks, const int ky, const int kx) -> const char* {
     const int kc = ks * 4 + fq;
-    const int col = fr + kx;
-    const char* xs = patch + (pb0 + kx) * 128 + ((kc ^ (col & 6)) << 4) + ky * (HALO_PW * 128);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const vec8<T>*>(xs + i * (HALO_PW * 128));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = weight_tile<TN, WNW, false>(wn, j) * 16 + fr;
-      wf[j] = *reinterpret_cast<const vec8<T>*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-    }
+    return patch + (pb0 + kx) * 128 + ((kc ^ ((fr + kx) & 6)) << 4) + ky * (HALO_PW * 128);
+  };
+  auto rx = [&](const char* xs, const int i) -> vec8<T> { return *reinterpret_cast<const vec8<T>*>(xs + i * (HALO_PW * 128)); };
+  auto w_addr = [&](const int slot, const int ks) -> const char* {
+    const int kc = ks * 4 + fq;
+    return wring + slot * B_BYTES + fr * 128 + ((kc ^ ((fr >> 1) & 7)) << 4);
+  };
+  auto rw = [&](const char* ws, const int j) -> vec8<T> {
+    return *reinterpret_cast<const vec8<T>*>(ws + weight_tile<TN, WNW, false>(wn, j) * (16 * 128));
   };
   f32x4 acc[TN][TM];
-  auto mma = [&](const vec8<T> (&xf)[TM], const vec8<T> (&wf)[TN]) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
-  };
-  // spread NDMA just-issued LDS-DMA instructions between the MFMAs that follow them in program order
-  auto spread = [&](auto ndma) __attribute__((always_inline)) {
-    constexpr int ND = decltype(ndma)::value;
-    constexpr int PER = (TM * TN) / ND > 0 ? (TM * TN) / ND : 1;
-#pragma unroll
-    for (int g = 0; g < ND; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x8, PER, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
-    }
-  };
   using std::integral_constant;
 
   LR_STAMP(0);
@@ -185,57 +165,146 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   issue_patch(0);
   int wci = 0, wtap = 0;                 // K-step whose weights are issued next
 #pragma unroll
-  for (int sidx = 0; sidx < NSTAGE - 1; ++sidx) {
-    if (sidx < nsteps) { issue_weights(sidx, wkoff(wci, wtap)); advance(wci, wtap); }
+  for (int sidx = 0; sidx < NSTAGE; ++sidx) {      // the whole ring up front
+    rsW = sidx < nsteps ? rsB : rsZ;
+    issue_weights(sidx, wkoff(wci, wtap));
+    advance(wci, wtap);
   }
   LR_STAMP(1);
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (NSTAGE == 3 && nsteps > 1) {       // patch + step 0 landed; step 1's weights may still be in flight
-    if (B_TAIL && w < TAIL_WAVES) wait_vmcnt<NB_FULL + 1>(); else wait_vmcnt<NB_FULL>();
-  } else {
-    wait_vmcnt<0>();
-  }
+  wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   LR_STAMP(2);
 
+  // ONE barrier per K-step, in the MIDDLE of the step, and a rolling fragment schedule (one fragment set; the MFMAs run line-major, so
+  // the x fragment of line i is dead after TN MFMAs and its registers take what the next half step needs while the matrix pipe works):
+  //   half A (k 0..31):  [TN MFMAs of line i | read x(i) of half B] ...; in the last line every MFMA is followed by the reload of the
+  //                      weight fragment it just used (half B's).  After it nobody reads the step's weight slot or (at the last tap
+  //                      of a chunk) the patch any more.
+  //   barrier:           every wave's fragment reads are in registers and its LDS-DMA of step s + 1 (issued one whole step ago) has
+  //                      landed -> the slot of step s is refilled with step s + NSTAGE; behind the last tap the patch is reloaded too.
+  //   half B (k 32..63): [TN MFMAs of line i | read x(i) of the NEXT tap, half A -- the patch does not change inside a chunk]; in the
+  //                      last line the weight fragments of step s + 1, half A (landed before the barrier above).
+  // So a K-step's weights have a full step to arrive (the 2-slot ring of gemm_conv_pipe_kernel<256, 8, 320> issues them during the
+  // first half of the step that precedes their use and waits for them at its end), the step boundary has no barrier and no bulk
+  // fragment read, and only a patch reload (every 9th step) costs a second barrier.
   int ci = 0, tap = 0, cur = 0;
-  vec8<T> xa[TM], wa[TN];
+  vec8<T> xf[TM], wf[TN];
+  if constexpr (ROLL) {
+    const char* xs = x_addr(0, ncm > 0 ? 0 : 1, ncm > 0 ? 0 : 1);
+    const char* ws = w_addr(0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wf[j] = rw(ws, j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xf[i] = rx(xs, i);
+  }
   for (int s = 0; s < nsteps; ++s) {
     const bool main_part = ci < ncm;
     const int ky = main_part ? (tap * 11) >> 5 : 1, kx = main_part ? tap - 3 * ky : 1;      // (tap * 11) >> 5 = tap / 3 for tap < 12
     const bool last_tap = !main_part || tap == 8;
-    const bool pf_w = s + NSTAGE - 1 < nsteps;          // weights to prefetch in this step
+    const bool pf_w = s + NSTAGE < nsteps;              // weights to prefetch in this step
     const bool pf_p = last_tap && ci + 1 < nch;         // patch to reload in this step
-    int wslot = cur + NSTAGE - 1; if (wslot >= NSTAGE) wslot -= NSTAGE;
-    read_frags(xa, wa, cur, 0, ky, kx);
-    __builtin_amdgcn_sched_barrier(0);
-    // (past the end of K the weights go through a zero-length descriptor: same instruction count in every step, constant waits)
-    rsW = (pf_w && HALO_EXP != 3) ? rsB : rsZ;
-    issue_weights(wslot, wkoff(wci, wtap));
-    advance(wci, wtap);
-    mma(xa, wa);
-    spread(integral_constant<int, NB_FULL>{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(xa, wa, cur, 1, ky, kx);
-    if (pf_p && HALO_EXP != 1) {
-      // every wave's last reads of this patch are in registers -> the buffer is free for the next chunk
+    const int nxt = cur + 1 == NSTAGE ? 0 : cur + 1;
+    if constexpr (ROLL) {
+      // first tap of the following step (x fragments are prefetched one half step ahead; behind a patch reload they are read again)
+      const int ntap = last_tap ? 0 : tap + 1;
+      const bool nmain = last_tap ? ci + 1 < ncm : true;
+      const int nky = nmain ? (ntap * 11) >> 5 : 1, nkx = nmain ? ntap - 3 * nky : 1;
+      const char* ws1 = w_addr(cur, 1);
+      const char* xs1 = x_addr(1, ky, kx);
+      // ---- half A  (sched_barrier(0) after every line group pins the order [TN MFMAs | refill])
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
+          if (i == TM - 1) { wf[j] = rw(ws1, j); __builtin_amdgcn_sched_barrier(0); }
+        }
+        xf[i] = rx(xs1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- the step's barrier
+      if (NSTAGE == 3) { if (B_TAIL && w < TAIL_WAVES) wait_vmcnt<NB_FULL + 1>(); else wait_vmcnt<NB_FULL>(); }
+      else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      issue_patch(ci + 1);
-    }
-    mma(xa, wa);
-    if (NSTAGE == 3 && !pf_p) {                            // the weights issued in this step stay in flight
-      if (B_TAIL && w < TAIL_WAVES) wait_vmcnt<NB_FULL + 1>(); else wait_vmcnt<NB_FULL>();
+      // (past the end of K the weights go through a zero-length descriptor: same instruction count in every step, constant waits)
+      rsW = (pf_w && HALO_EXP != 3) ? rsB : rsZ;
+      const unsigned koff = wkoff(wci, wtap);
+      advance(wci, wtap);
+      if (pf_p && HALO_EXP != 1) issue_patch(ci + 1);
+      const char* ws0n = w_addr(nxt, 0);
+      const char* xsn = x_addr(0, nky, nkx);
+      // ---- half B  ([TN MFMAs | refill | one LDS-DMA piece])
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
+          if (i == TM - 1) { wf[j] = rw(ws0n, j); __builtin_amdgcn_sched_barrier(0); }
+        }
+        xf[i] = rx(xsn, i);
+        issue_weight_piece(cur, koff, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (pf_p) {      // the prefetched x fragments came from the patch that was being replaced: wait for the new one and read them again
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = rx(xsn, i);
+      }
     } else {
+      // 40 accumulator tiles leave no room for fragments in flight: bulk reads per half step, the same mid-step barrier
+      auto read_frags = [&](const int ks) __attribute__((always_inline)) {
+        const char* xs = x_addr(ks, ky, kx);
+        const char* ws = w_addr(cur, ks);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = rx(xs, i);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = rw(ws, j);
+      };
+      auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
+      };
+      read_frags(0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(1);
       wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      rsW = (pf_w && HALO_EXP != 3) ? rsB : rsZ;
+      const unsigned koff = wkoff(wci, wtap);
+      advance(wci, wtap);
+      if (pf_p && HALO_EXP != 1) issue_patch(ci + 1);
+#pragma unroll
+      for (int i = 0; i <= NB_FULL; ++i) issue_weight_piece(cur, koff, i);
+      mma();
+#pragma unroll
+      for (int g = 0; g < NB_FULL; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x8, (TM * TN) / NB_FULL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (pf_p) {      // the next chunk's patch has to land before its first fragment reads
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
     }
-    __builtin_amdgcn_s_barrier();
-    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    cur = nxt;
     advance(ci, tap);
   }
+  // (the epilogue reuses the patch buffer for its column sums: every wave's trailing zero-length LDS-DMA and fragment reads are done)
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   LR_STAMP(3);
   LR_STAMP(4);
 
@@ -277,7 +346,7 @@ static int launch_halo_t(const GemmParams& P0, hipStream_t st) {
 // the LR_PIPE_HALO instances of lr_gemm_conv_f16 (called from gemm_conv.hip after its argument checks)
 int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
   if (P.taps != 9 || P.stride != 1 || P.up || P.zins || P.pad != 1 || P.c16 || P.splits != 1 || P.geglu || P.gelu || P.ln_part ||
-      P.wt_bstride || P.st_out || (P.H & 15) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
+      P.wt_bstride || P.st_out || (P.H & 15) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W || P.N % tile_n)
     return LR_E_UNSUPPORTED;
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);
