@@ -478,14 +478,17 @@ def host_cpu():
 
 
 def cpu_baseline():
-    """Oracle (fp32 torch CPU restatement of the reference, oracle/unet_ref.py + oracle/ddim_ref.py) on the host cores, SURVEY 8d,
-    one torch thread per PHYSICAL core: configs[0] in full through the oracle's sampler (256x512 canvas = latent 32x64, B = 1,
-    10 DDIM steps under CFG 2.5 = 10 UNet forwards at batch 2 + the guided updates) and ONE CFG step of configs[1] (latent
-    64x128, batch 2), after a warm-up forward (thread pool, allocator)."""
+    """Oracle (fp32 torch CPU restatement of the reference, oracle/unet_ref.py + oracle/ddim_ref.py) on the host cores, SURVEY 8d.
+    (1) thread sweep: one CFG UNet step (batch 2) at latent 32x64 for 16 / 32 / 64 / 128 torch threads (capped at the physical
+    cores) -- all cores are NOT the fastest on a 128-core host; (2) with the fastest count: ONE CFG step of
+    configs[1] (latent 64x128, batch 2) in both attention forms of the reference -- "naive" (CrossAttention.forward with
+    materialised logits, attention.py:165-196) and "sdpa" (the fused form the reference runs with xformers, 199-250) -- `value` takes
+    the FASTER of the two; (3) configs[0] in full through the oracle's sampler (latent 32x64, B = 1, 10 DDIM steps under CFG 2.5)
+    with that count and form.  Every timing after one warm-up forward (thread pool, allocator)."""
     from oracle import ddim_ref, unet_ref
     cpu_model, phys, logical = host_cpu()
     prev_threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, phys))
+    prev_impl = unet_ref.ATTENTION_IMPL
     try:
         cfg = unet_ref.FULL
         g = torch.Generator().manual_seed(0)
@@ -502,26 +505,50 @@ def cpu_baseline():
                 sd[k] = 0.02 * torch.randn(shp, generator=g)
         ctx = torch.randn(2, 77, 1024, generator=g)
         t = torch.tensor([501, 501])
-        unet_ref.unet_forward(sd, cfg, torch.randn(2, 9, 32, 64, generator=g), t, ctx)      # warm-up (not timed)
+        x_small = torch.randn(2, 9, 32, 64, generator=g)
+        x = torch.randn(2, 9, 64, 128, generator=g)
+
+        def timed(fn):
+            t0 = time.time()
+            fn()
+            return time.time() - t0
+
+        torch.set_num_threads(max(1, min(phys, 32)))
+        unet_ref.unet_forward(sd, cfg, x_small, t, ctx)      # warm-up (not timed)
+        sweep = {}
+        for nt in sorted({min(n_, max(1, phys)) for n_ in (16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            unet_ref.unet_forward(sd, cfg, x_small[:, :, :8, :16], t, ctx)      # respawn the pool at this size (not timed)
+            sweep[nt] = timed(lambda: unet_ref.unet_forward(sd, cfg, x_small, t, ctx))
+        best_t = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_t)
+        per_impl = {}
+        for impl in ("naive", "sdpa"):
+            unet_ref.ATTENTION_IMPL = impl
+            per_impl[impl] = timed(lambda: unet_ref.unet_forward(sd, cfg, x, t, ctx))
+        best_impl = min(per_impl, key=per_impl.get)
+        unet_ref.ATTENTION_IMPL = best_impl
+        dt = per_impl[best_impl]
         # configs[0] exactly as stated: the oracle's DDIM / CFG sampler, eta = 1 noise drawn per step like the reference
         x_T = torch.randn(1, 4, 32, 64, generator=g)
         c_concat = torch.randn(1, 5, 32, 64, generator=g)
-        t0 = time.time()
-        ddim_ref.ddim_sample(lambda xc, tt, cc: unet_ref.unet_forward(sd, cfg, xc, tt, cc), 10, x_T, c_concat, ctx[:1], ctx[1:], CFG,
-                             eta=ETA, noises=[torch.randn(1, 4, 32, 64, generator=g) for _ in range(10)])
-        dt0 = time.time() - t0
-        x = torch.randn(2, 9, 64, 128, generator=g)
-        t0 = time.time()
-        unet_ref.unet_forward(sd, cfg, x, t, ctx)
-        dt = time.time() - t0
+        noises = [torch.randn(1, 4, 32, 64, generator=g) for _ in range(10)]
+        dt0 = timed(lambda: ddim_ref.ddim_sample(lambda xc, tt, cc: unet_ref.unet_forward(sd, cfg, xc, tt, cc), 10, x_T, c_concat,
+                                                 ctx[:1], ctx[1:], CFG, eta=ETA, noises=noises))
     finally:
         torch.set_num_threads(prev_threads)
-    return {"value": 1.0 / (50 * dt), "unit": "images/s", "cores": phys, "kind": "port",
-            "cpu_model": cpu_model, "physical_cores": phys, "logical_cpus": logical, "torch_threads": phys,
-            "sample": f"{cpu_model}, {phys} physical cores ({logical} logical), torch threads = {phys}; after one warm-up forward: "
-                      f"configs[0] in full through oracle/ddim_ref.ddim_sample (latent 32x64, B=1, 10 DDIM steps, cfg 2.5, eta 1) "
-                      f"{dt0:.2f} s = {1.0 / dt0:.4f} images/s; configs[1]: 1 CFG UNet step (batch 2) at latent 64x128 {dt:.2f} s/step, "
-                      f"extrapolated x50 steps per image for `value`",
+        unet_ref.ATTENTION_IMPL = prev_impl
+    sw = ", ".join(f"{n_} threads {v_:.2f} s" for n_, v_ in sorted(sweep.items()))
+    return {"value": 1.0 / (50 * dt), "unit": "images/s", "cores": best_t, "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": phys, "logical_cpus": logical, "torch_threads": best_t,
+            "thread_sweep_s_per_cfg_step_latent32x64": {str(k_): v_ for k_, v_ in sorted(sweep.items())},
+            "s_per_unet_step_b2_naive": per_impl["naive"], "s_per_unet_step_b2_sdpa": per_impl["sdpa"], "attention_impl": best_impl,
+            "images_per_s_naive": 1.0 / (50 * per_impl["naive"]), "images_per_s_sdpa": 1.0 / (50 * per_impl["sdpa"]),
+            "sample": f"{cpu_model}, {phys} physical cores ({logical} logical); thread sweep on one CFG UNet step (batch 2) at latent "
+                      f"32x64: {sw} -> {best_t} threads; configs[1]: 1 CFG UNet step (batch 2) at latent 64x128 with {best_t} threads: "
+                      f"naive attention {per_impl['naive']:.2f} s, fused (SDPA) attention {per_impl['sdpa']:.2f} s -> `value` = the faster "
+                      f"({best_impl}), extrapolated x50 steps per image; configs[0] in full through oracle/ddim_ref.ddim_sample (latent "
+                      f"32x64, B=1, 10 DDIM steps, cfg 2.5, eta 1, {best_impl} attention, {best_t} threads) {dt0:.2f} s = {1.0 / dt0:.4f} images/s",
             "s_per_unet_step_b2": dt, "config0_full_s": dt0, "config0_images_per_s": 1.0 / dt0}
 
 

@@ -94,8 +94,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   }
   const int Ctot = P.C1 + P.C2;
   const int cpt1 = P.C1 >> 6, ncm = Ctot >> 6, cpt3 = P.C3 >> 6;
-  const int nch = ncm + ((P.C3 + P.C4) >> 6);                        // chunks: the 3x3 part, then the pointwise extension (one tap each)
-  const int nsteps = 9 * ncm + (nch - ncm);
+  const int nch_all = ncm + ((P.C3 + P.C4) >> 6);                    // chunks: the 3x3 part, then the pointwise extension (one tap each)
+  // split-K (blockIdx.y): whole chunks [c_begin, nch) per slice, fp32 partial tiles to P.ws, epilogue in splitk_reduce_kernel
+  const int c_per = (nch_all + P.splits - 1) / P.splits;
+  const int c_begin = blockIdx.y * c_per;
+  const int nch = min(nch_all, c_begin + c_per);
+  const int nsteps = (min(nch, ncm) - min(c_begin, ncm)) * 9 + (max(nch, ncm) - max(c_begin, ncm));
   auto issue_patch = [&](const int ci) __attribute__((always_inline)) {
     const f16* src; int cs, ch;
     if (ci < cpt1) { src = P.p1; cs = P.C1; ch = ci; }
@@ -182,8 +186,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
 
   LR_STAMP(0);
   stage_params<BN, PAR_LD>(P, par, n0, w, lane, 0);
-  issue_patch(0);
-  int wci = 0, wtap = 0;                 // K-step whose weights are issued next
+  issue_patch(c_begin);
+  int wci = c_begin, wtap = 0;           // K-step whose weights are issued next
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE - 1; ++sidx) {
     if (sidx < nsteps) { issue_weights(sidx, wkoff(wci, wtap)); advance(wci, wtap); }
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   __builtin_amdgcn_s_barrier();
   LR_STAMP(2);
 
-  int ci = 0, tap = 0, cur = 0;
+  int ci = c_begin, tap = 0, cur = 0;
   vec8<T> xa[TM], wa[TN];
   for (int s = 0; s < nsteps; ++s) {
     const bool main_part = ci < ncm;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
 
   // ---- epilogue straight from the accumulators (the loop ended with vmcnt(0) + barrier: the patch buffer is free for the sums)
   float* gsl = reinterpret_cast<float*>(smem);
-  const bool gp = P.gp_out != nullptr;
+  const bool gp = P.gp_out != nullptr && P.splits == 1;
   epilogue_units<TM, TN, 0, PAR_LD, WNW, T, true>(P, acc, m_org + wm * TM * P.W, n0, wn, lane, par, par, tile_n * WNW + wn,
                                                   gsl + wm * (BN * 2), tile * WMW + wm);
   if (gp) {
@@ -270,13 +274,13 @@ static int launch_halo_t(const GemmParams& P0, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<BN, WMW, NSTAGE, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)smem);
   }
-  hipLaunchKernelGGL((conv_halo_kernel<BN, WMW, NSTAGE, T>), dim3(P.nblocks, 1), dim3(512), smem, st, P);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, WMW, NSTAGE, T>), dim3(P.nblocks, P.splits), dim3(512), smem, st, P);
   return lr_launch_status();
 }
 
 // the LR_PIPE_HALO instances of lr_gemm_conv_f16 (called from gemm_conv.hip after its argument checks)
 int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
-  if (P.taps != 9 || P.stride != 1 || P.up || P.zins || P.pad != 1 || P.c16 || P.splits != 1 || P.geglu || P.gelu || P.ln_part ||
+  if (P.taps != 9 || P.stride != 1 || P.up || P.zins || P.pad != 1 || P.c16 || P.splits < 1 || P.geglu || P.gelu || P.ln_part ||
       P.wt_bstride || P.st_out || (P.H & 15) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
     return LR_E_UNSUPPORTED;
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);

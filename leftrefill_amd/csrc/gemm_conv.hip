@@ -760,7 +760,14 @@ static int choose_splits(int M, int N, int K, int tm, int tn, int geglu, int sta
   if (geglu) return 1;
   const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
   const int nk = K / BK;
-  if (stages == LR_PIPE_HALO) return 1;                       // the halo-tile conv never splits K
+  if (stages == LR_PIPE_HALO) {                               // the halo-tile conv splits by whole 64-channel chunks (9 K-steps each)
+    const int t_ = ((M + 255) / 256) * ((N + tn - 1) / tn), chunks = K / 576;
+    if (t_ * 10 > 256 * 6 || chunks < 8) return 1;
+    int s_ = (256 + t_ / 2) / t_;
+    if (s_ > 8) s_ = 8;
+    if (s_ > chunks / 4) s_ = chunks / 4;
+    return s_ < 1 ? 1 : s_;
+  }
   const int slots = (tm == 256 || stages == 4) ? 256 : 512;   // resident blocks on the chip
   if (tiles * 10 > slots * 6 || nk < 32) return 1;   // > 60 % of the resident slots filled: do not split
   int s = (slots + tiles / 2) / tiles;               // round to the nearest whole number of waves
@@ -976,7 +983,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
   if (a->pipe == LR_PIPE_HALO) {      // 3x3 stride-1 conv with the input patch resident in LDS (conv_halo.hip)
     if (mode != 0 || a->asym) return LR_E_UNSUPPORTED;
-    return lr_launch_conv_halo(P, tn, st);
+    rc = lr_launch_conv_halo(P, tn, st);
+    if (rc || P.splits == 1) return rc;
+    return launch_reduce(P, st);
   }
   if (mode == 0) {
     if (deep && tn == 128) rc = launch_pipe<128, 8, 128, 4, 4, 0>(P, st);

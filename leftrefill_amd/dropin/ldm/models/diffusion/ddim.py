@@ -91,13 +91,10 @@ class DDIMSampler(object):
                 img = self.model.q_sample(x0, ts) * mask + (1. - mask) * img
             if ucg_schedule is not None:
                 unconditional_guidance_scale = ucg_schedule[i]
-            self._step_hint(step)
-            try:
-                img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
-                                                  unconditional_guidance_scale=unconditional_guidance_scale,
-                                                  unconditional_conditioning=unconditional_conditioning)
-            finally:
-                self._step_hint(None)
+            # t_host: the timestep of `ts` as a host integer -- p_sample_ddim names it to the UNet around its own model calls
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning, t_host=int(step))
             if callback:
                 callback(i)
             if img_callback:
@@ -137,15 +134,11 @@ class DDIMSampler(object):
             if ucg_schedule is not None:
                 unconditional_guidance_scale = ucg_schedule[i]
             new_img = []
-            self._step_hint(step)
-            try:
-                for img_, cond_, uc_ in zip(img, cond, ucs):
-                    x_prev, _ = self.p_sample_ddim(img_, cond_, ts, index=index, temperature=temperature,
-                                                   unconditional_guidance_scale=unconditional_guidance_scale,
-                                                   unconditional_conditioning=uc_)
-                    new_img.append(x_prev)
-            finally:
-                self._step_hint(None)
+            for img_, cond_, uc_ in zip(img, cond, ucs):
+                x_prev, _ = self.p_sample_ddim(img_, cond_, ts, index=index, temperature=temperature,
+                                               unconditional_guidance_scale=unconditional_guidance_scale,
+                                               unconditional_conditioning=uc_, t_host=int(step))
+                new_img.append(x_prev)
             order = list(range(K))
             random.shuffle(order)                 # same RNG consumption and same pick as shuffling the K tensors
             half = new_img[0].shape[-1] // 2
@@ -196,7 +189,20 @@ class DDIMSampler(object):
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, dynamic_threshold=None,
-                      **kwargs):
+                      t_host=None, **kwargs):
+        """t_host: the timestep every entry of `t` holds, as a host integer (the sampling loops pass it; None = unknown).  It is named
+        to the UNet only around this method's own apply_model calls (precomputed embedding rows, UNetModel.prepare_timesteps)."""
+        self._step_hint(t_host)
+        try:
+            return self._p_sample_ddim(x, c, t, index, repeat_noise, use_original_steps, quantize_denoised, temperature, noise_dropout,
+                                       score_corrector, corrector_kwargs, unconditional_guidance_scale, unconditional_conditioning,
+                                       dynamic_threshold)
+        finally:
+            self._step_hint(None)
+
+    def _p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                       unconditional_guidance_scale=1., unconditional_conditioning=None, dynamic_threshold=None):
         if use_original_steps or quantize_denoised or score_corrector is not None or dynamic_threshold is not None:
             raise NotImplementedError
         if self.model.parameterization != "eps":

@@ -405,10 +405,16 @@ class UNetModel(nn.Module):
                 for j, s_ in enumerate(chunk):
                     table[s_] = rows[j]
         self._emb_table = table
+        self._emb_table_plan = self._plan      # rows belong to THIS packing: a re-pack (changed weights) drops them (see _emb_rows)
 
     def _emb_rows(self, timesteps, N, out=None):
         """[N, sum Cout] embedding of this call: the precomputed row of the host-named timestep, else computed from `timesteps`."""
+        # the hint is set by DDIMSampler.p_sample_ddim around ITS OWN apply_model calls only, with the host timestep its caller (the
+        # sampling loop) named; any other caller of the UNet -- a corrector, a second model evaluation, another sampler sharing the
+        # model -- runs with no hint and gets the embedding computed from its `timesteps` tensor
         hint = self.__dict__.get("_t_host")
+        if self.__dict__.get("_emb_table_plan") is not self._plan:      # prepare() re-packed since the table was built: stale rows
+            self._emb_table = {}
         row = self.__dict__.get("_emb_table", {}).get(hint) if hint is not None else None
         if row is not None and row.dtype == self.compute_dtype:
             rows = row.unsqueeze(0).expand(N, -1)

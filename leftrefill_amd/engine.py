@@ -125,14 +125,21 @@ class PackedRes:
         self.n2 = PackedNorm(blk.out_layers[0])
         self.c2 = PackedConv(blk.out_layers[3])
         self.skip = None
-        self.c2s = None
+        self._c2s = None      # built on first inference use (a training step re-packs every time the weights change and never
+        self._c2s_ok = False  # runs the fused form -- the concatenated copy would be rebuilt per optimizer step for nothing)
         sk = blk.skip_connection
         if isinstance(sk, torch.nn.Conv2d):
             self.skip = PackedConv(sk)
-            if sk.kernel_size == (1, 1) and self.c2.taps == 9 and self.c2.stride == 1 and self.skip.w.shape[0] == self.c2.w.shape[0]:
-                # `skip_connection(x) + h` (openaimodel.py:274) as extra K-steps of the last conv: weights [N][9 C | C_in], summed biases
-                self.c2s = FusedSkipConv(self.c2, self.skip)
+            # `skip_connection(x) + h` (openaimodel.py:274) as extra K-steps of the last conv: weights [N][9 C | C_in], summed biases
+            self._c2s_ok = (sk.kernel_size == (1, 1) and self.c2.taps == 9 and self.c2.stride == 1
+                            and self.skip.w.shape[0] == self.c2.w.shape[0])
         self.cout = self.c1.cout
+
+    @property
+    def c2s(self):
+        if self._c2s is None and self._c2s_ok:
+            self._c2s = FusedSkipConv(self.c2, self.skip)
+        return self._c2s
 
 
 class FusedSkipConv:
@@ -213,18 +220,38 @@ class PackedST:
         #   proj_out(ff2(g) + b2 + x) + bp + x_in = (Wp W2) g + Wp x + (Wp b2 + bp) + x_in,
         # run as ONE GEMM over [g | x] (lr_gemm_args.skip1 with taps == 1) where no fused feed-forward kernel exists (C > 320): the product
         # Wp W2 is formed in fp32 and rounded once, x3 = ff(..) + x is never rounded or written, a K = C launch per SpatialTransformer is gone
-        self.ff_proj_w = self.ff_proj_b = None
+        # Formed on first inference use: ~110 GFLOP of host fp64 matmuls for an SD-size UNet, inference-only, and a training
+        # step re-packs whenever the weights change.
+        self._ff_proj = None
+        self._ff_src = None
         ff2 = st.transformer_blocks[-1].ff.net[2]
-        wp = st.proj_out.weight.detach().float()
-        wp = wp.reshape(wp.shape[0], wp.shape[1])
+        wp = st.proj_out.weight
         if self.proj_out_x is None and wp.shape[0] == wp.shape[1] == ff2.weight.shape[0] and wp.shape[1] % 64 == 0:
-            # (formed once at pack time, in fp64 on the host: no GPU BLAS on any path of this package, and no dependence on a summation order)
+            self._ff_src = (st.proj_out, ff2, compute_dtype())
+
+    def _build_ff_proj(self):
+        if self._ff_proj is None and self._ff_src is not None:
+            proj_out, ff2, dt = self._ff_src
+            wp = proj_out.weight.detach().float()
+            wp = wp.reshape(wp.shape[0], wp.shape[1])
+            # (in fp64 on the host: no GPU BLAS on any path of this package, and no dependence on a summation order)
             dev_ = wp.device
             wp64, w2_64 = wp.double().cpu(), ff2.weight.detach().double().cpu()
-            self.ff_proj_w = torch.cat([(wp64 @ w2_64).float(), wp64.float()], dim=1).to(device=dev_, dtype=compute_dtype()).contiguous()
+            w = torch.cat([(wp64 @ w2_64).float(), wp64.float()], dim=1).to(device=dev_, dtype=dt).contiguous()
             b2 = ff2.bias.detach().double().cpu() if ff2.bias is not None else torch.zeros(w2_64.shape[0], dtype=torch.float64)
-            bp = st.proj_out.bias.detach().double().cpu() if st.proj_out.bias is not None else torch.zeros(wp64.shape[0], dtype=torch.float64)
-            self.ff_proj_b = (wp64 @ b2 + bp).float().to(dev_).contiguous()
+            bp = proj_out.bias.detach().double().cpu() if proj_out.bias is not None else torch.zeros(wp64.shape[0], dtype=torch.float64)
+            self._ff_proj = (w, (wp64 @ b2 + bp).float().to(dev_).contiguous())
+        return self._ff_proj
+
+    @property
+    def ff_proj_w(self):
+        p_ = self._build_ff_proj()
+        return None if p_ is None else p_[0]
+
+    @property
+    def ff_proj_b(self):
+        p_ = self._build_ff_proj()
+        return None if p_ is None else p_[1]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -537,8 +564,11 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
 
 
 # GroupNorm of the SpatialTransformer folded into proj_in through per-sample weights (levels where the activation is much larger
-# than N copies of the weights); LEFTREFILL_ST_GN_FOLD=0 keeps GroupNorm-apply -> proj_in
-ST_GN_FOLD = __import__("os").environ.get("LEFTREFILL_ST_GN_FOLD", "1") != "0"
+# than N copies of the weights).  OFF by default since round 5: its own A/B is noise (18.43 vs 18.41 ms per step, round 4) and the
+# folded weights W gamma rstd carry no range guard for near-constant groups (rstd up to 1e3 at eps 1e-6) -- the default
+# path is GroupNorm-apply -> proj_in, whose normalised activations are bounded.  LEFTREFILL_ST_GN_FOLD=1 enables the fold (the
+# kernel lr_gn_fold_weights_f16 and its parity test stay).
+ST_GN_FOLD = __import__("os").environ.get("LEFTREFILL_ST_GN_FOLD", "0") != "0"
 
 
 def st_gn_fold_ok(x_in, act: Act, gs_in, ps: PackedST):
@@ -579,7 +609,7 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
         post = None
         if last and ps.proj_out_x is not None:
             post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW)
-        elif last and ps.ff_proj_w is not None and FF_PROJ and want:
+        elif last and FF_PROJ and want and ps.ff_proj_w is not None:
             post = ("compose", ps.ff_proj_w, ps.ff_proj_b, x_in, act.HW)      # proj_out composed with the last feed-forward Linear
         r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post)
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward

@@ -46,8 +46,9 @@ def compose_prediction_multiview(out, mask_flat_nhwc, batch_size, global_view_nu
     if mask.shape[3] != mask.shape[2]:
         mask = mask[:, :, :, mask.shape[2]:]
     h, w = out["pred"].shape[2], out["pred"].shape[3]
-    mask = mask.to(out["pred"].dtype)
-    pred = out["pred"] * mask + out["origin_image"].to(out["pred"].dtype) * (1 - mask)
+    # composited in fp32 like the reference (the float32 mask promotes the product, test_multiview_inpainting.py:159-162)
+    mask = mask.float()
+    pred = out["pred"].float() * mask + out["origin_image"].float() * (1 - mask)
     origin = out["origin_image"]
     if h != w:
         pred, origin = pred[:, :, :, w // 2:], origin[:, :, :, w // 2:]

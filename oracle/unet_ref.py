@@ -217,6 +217,13 @@ def group_norm(x, w, b, eps, groups=32):
     return F.group_norm(x, groups, w, b, eps)
 
 
+# "naive": the vanilla CrossAttention.forward (attention.py:165-196: materialised logits, here in query chunks).  "sdpa": the fused form
+# the reference actually runs when xformers is installed (MemoryEfficientCrossAttention, attention.py:199-250) -- the same function
+# of (q, k, v), evaluated by torch's fused CPU kernel without materialising the logits.  Only bench.py's cpu_baseline switches it (to
+# report both); the parity tests keep "naive", whose intermediate `p` is where the fp16-autocast emulation rounds.
+ATTENTION_IMPL = "naive"
+
+
 def attention(q, k, v, heads, m: _Mode):
     """softmax(q k^T / sqrt(d)) v per head; q [B,Nq,H*d], k/v [B,Nk,H*d]  (attention.py:165-196)."""
     B, Nq, C = q.shape
@@ -224,6 +231,9 @@ def attention(q, k, v, heads, m: _Mode):
     qh = q.reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
     kh = k.reshape(B, k.shape[1], heads, d).permute(0, 2, 1, 3)
     vh = v.reshape(B, v.shape[1], heads, d).permute(0, 2, 1, 3)
+    if ATTENTION_IMPL == "sdpa" and not m.ac:      # (fp32 mode only: the emulation modes round the probabilities)
+        o = F.scaled_dot_product_attention(qh, kh, vh, scale=d ** -0.5)
+        return o.permute(0, 2, 1, 3).reshape(B, Nq, C)
     out = torch.empty_like(qh)
     scale = d ** -0.5
     # chunk over queries so the N x N logits never exceed a few hundred MB

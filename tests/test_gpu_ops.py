@@ -256,6 +256,9 @@ def test_conv_halo_tile(tile_n):
     _conv_case(f"halo{tile_n}_res", 3, 320, 640, 16, 32, resid=True, **k)                     # N = 640: 2 (4) column tiles
     _conv_case(f"halo{tile_n}_cat", 2, 320, 320, 32, 16, C2=640, rowvec=True, resid=True, **k)
     _conv_case(f"halo{tile_n}_ntail", 1, 128, 384, 16, 32, **k)                               # N = 384: ragged last column tile
+    for sp in (2, 3, 7):                                                                      # split-K by whole chunks (20 chunks: 10 | 7,7,6 | 3,3,3,3,3,3,2)
+        _conv_case(f"halo{tile_n}_splitk{sp}", 2, 1280, 640, 16, 32, rowvec=True, resid=True, **dict(k, splits=sp))
+    _conv_case(f"halo{tile_n}_splitk_empty", 1, 128, 320, 16, 16, **dict(k, splits=3))        # 2 chunks over 3 slices: one slice has no work
     # shapes the instance does not cover are refused, never run wrong
     d = dev()
     x = torch.zeros(2 * 24 * 16, 64, device=d, dtype=torch.float16)

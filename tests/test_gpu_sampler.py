@@ -136,6 +136,28 @@ def test_sampler_timestep_table_is_bit_identical(monkeypatch):
         unet._emb_table = {}
         e2 = unet(xin, torch.full((2,), 321, device=dev), ctx)
         assert torch.equal(e1, e2)
+        # a UNet call made DURING a sampling, outside p_sample_ddim (a callback, a corrector, a second sampler sharing the
+        # model), with a timestep of its own must not pick up the step's precomputed row: the hint is scoped to p_sample_ddim's calls
+        seen = []
+
+        def cb(pred_x0, i):
+            assert unet._t_host is None
+            seen.append(unet(xin, torch.full((2,), 321, device=dev), ctx))
+
+        torch.manual_seed(7)
+        out_cb, _ = m.sample_log(cond=cond, batch_size=B, ddim=True, ddim_steps=20, eta=1.0, x_T=x_T, unconditional_guidance_scale=2.5,
+                                 unconditional_conditioning=uc, img_callback=cb)
+        assert len(seen) == 20 and all(torch.equal(e_, e1) for e_ in seen)
+        assert torch.equal(out_cb, ref)
+        # a re-pack (weights changed) drops the rows of the old packing
+        unet.prepare_timesteps([999, 500])
+        unet.prepare(force=True)
+        unet._t_host = 999
+        try:
+            unet._emb_rows(torch.full((2,), 999, device=dev), 2)
+            assert unet._emb_table == {}
+        finally:
+            unet._t_host = None
     finally:
         unet.use_hip_graph = True
         unet._emb_table = {}

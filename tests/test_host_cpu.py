@@ -123,7 +123,11 @@ def test_gemm_plan_is_a_pure_function_of_the_shape():
     valid = {(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)}
     for key, plan in table.items():
         assert len(key.split(",")) == 12 and (plan[0], plan[1]) in valid and plan[2] >= 1, (key, plan)
-        assert (plan[3] if len(plan) > 3 else 0) in (0, 4) and (len(plan) < 4 or plan[3] == 0 or (plan[0] == 128 and plan[1] in (128, 160)))
+        pipe = plan[3] if len(plan) > 3 else 0
+        # 4 = the 8-wave 4-stage 128-row instance; 8 = the halo-tile conv (3x3, stride 1, no upsample; 256 x {160, 320})
+        assert pipe in (0, 4, 8)
+        assert pipe != 4 or (plan[0] == 128 and plan[1] in (128, 160))
+        assert pipe != 8 or (plan[0] == 256 and plan[1] in (160, 320) and key.split(",")[3:6] == ["9", "1", "0"])
         M, N, K, taps, stride, up, geglu, cat, asym, gelu, ln, stats = map(int, key.split(","))
         got = ops.gemm_plan(M, N, K, taps=taps, stride=stride, up=up, geglu=bool(geglu), concat=bool(cat), asym=bool(asym),
                             gelu=bool(gelu), ln=bool(ln), stats=bool(stats))

@@ -195,3 +195,23 @@ def test_autocast16_emulation_is_close_to_fp32():
     b = unet_ref.unet_forward(sd, cfg, x, t, ctx, mode="autocast16")
     rel = ((a - b).norm() / a.norm()).item()
     assert 1e-5 < rel < 1e-2
+
+
+def test_oracle_attention_fused_form_matches_materialised_form():
+    """oracle.unet_ref.ATTENTION_IMPL = "sdpa" (the reference's xformers path, attention.py:199-250) is the same function as the
+    materialised-logits form (165-196) that pins the parity tests: bench.py's cpu_baseline may time either."""
+    import torch
+    from oracle import unet_ref
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(2, n_, 5 * 64, generator=g) for n_ in (300, 77, 77))
+    m = unet_ref._Mode("fp32")
+    ref = unet_ref.attention(q, k, v, 5, m)
+    prev = unet_ref.ATTENTION_IMPL
+    try:
+        unet_ref.ATTENTION_IMPL = "sdpa"
+        out = unet_ref.attention(q, k, v, 5, m)
+        emu = unet_ref.attention(q, k, v, 5, unet_ref._Mode("autocast16"))      # the emulation keeps the materialised form
+    finally:
+        unet_ref.ATTENTION_IMPL = prev
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(emu, unet_ref.attention(q, k, v, 5, unet_ref._Mode("autocast16")))
