@@ -526,14 +526,20 @@ MV_LN_FOLD = __import__("os").environ.get("LEFTREFILL_MV_LN_FOLD", "1") != "0"
 MV_SHARDED = False
 
 
+# target query rows split over the ranks of a sharded multi-view job (one all-gather of the new target rows per block) instead of
+# replicated on every rank
+MV_SPLIT_TARGET = __import__("os").environ.get("LEFTREFILL_MV_SPLIT_TARGET", "1") != "0"
+
+
 def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
-    """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (leftrefill_amd.dist:
-    all-gather of the reference halves + broadcast of rank 0's target half per block).  x [N*L, C] = this rank's canvas
-    for each of its N local samples.  K / V are built for the whole sequence, Q / attention / out-projection only for the
-    rows this rank owns ([target, ref_rank]); the target rows are replicated, bit-identical work on every rank.
-    st: per-row (sum, sumsq) partials of x from its producer.  With them the LayerNorm is folded into the K|V and Q projections
-    (round 4): the statistics travel with the rows (8 bytes x parts per row next to 2 C bytes), no normalised sequence is written,
-    and the rank's own rows are formed ONCE (a view on rank 0) instead of one copy for the normalised and one for the raw rows."""
+    """Re-arranged cross-view self-attention with the canvases of a sample spread over the ranks (leftrefill_amd.dist).
+    x [N*L, C] = this rank's canvas for each of its N local samples.  ONE all-gather delivers every rank's canvas rows together with
+    their LayerNorm partial sums (mv_exchange_canvases); K / V are built for the whole sequence [target of canvas 0, ref_0 ..
+    ref_{v-1}], Q / attention / out-projection only for the rows this rank owns:
+      * MV_SPLIT_TARGET (default): slice `rank` of the target rows + ref_rank; the new target slices are all-gathered behind the
+        out-projection (second collective), so every rank writes the same target half;
+      * else: [target, ref_rank] -- the target rows are replicated, bit-identical work on every rank, no second exchange.
+    st: per-row (sum, sumsq) partials of x from its producer; with them the LayerNorm is folded into the K|V and Q projections."""
     from . import dist as lrd
     C = x.shape[1]
     s = int(math.sqrt(L / 2))
@@ -542,24 +548,33 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
     world = lrd.mv_group_size()
     assert world == v, f"multi-view sharding needs world_size == view_num - 1 ({world} vs {v})"
     rank = lrd.mv_rank()
-    Ls = (v + 1) * s * s
+    s2 = s * s
+    Ls = (v + 1) * s2
     pq = pt.attn1.qkv                                                         # rows [Wq; Wk; Wv] of the fused projection
-    seq = lrd.mv_gather_sequence(x.reshape(N, L, C), s)                       # [N, Ls, C]
-    own_x = lrd.mv_own_rows(seq, rank, s).reshape(N * L, C)                   # rows [target, ref_rank] (a view on rank 0, N = 1)
-    if st is not None and pq.wf is not None and fold_ok(x) and MV_LN_FOLD:
-        parts = st.shape[1]
-        st_seq = lrd.mv_gather_sequence(st.reshape(N, L, parts * 2), s)       # [N, Ls, parts * 2] fp32
-        own_st = lrd.mv_own_rows(st_seq, rank, s).reshape(N * L, parts, 2).contiguous()
+    fold = st is not None and pq.wf is not None and fold_ok(x) and MV_LN_FOLD
+    parts = st.shape[1] if fold else 0
+    x_all, st_all = lrd.mv_exchange_canvases(x.reshape(N, L, C), st.reshape(N, L, parts * 2) if fold else None)
+    seq = lrd.mv_sequence_from_canvases(x_all, s)                             # [N, Ls, C] (one copy out of the receive buffer)
+    split = MV_SPLIT_TARGET and world > 1 and s2 % world == 0
+    own = (lambda t_: lrd.mv_own_rows_split(t_, rank, s, world)) if split else (lambda t_: lrd.mv_own_rows(t_, rank, s))
+    Lo = s2 // world + s2 if split else L
+    own_x = own(seq).reshape(N * Lo, C)
+    if fold:
+        st_seq = lrd.mv_sequence_from_canvases(st_all, s)                     # [N, Ls, parts * 2] fp32
+        own_st = own(st_seq).reshape(N * Lo, parts, 2).contiguous()
         kv = ops.gemm_conv(seq.reshape(N * Ls, C), pq.wf[C:], B=1, H=1, W=N * Ls, taps=1, bias=pq.bf[C:],
                            ln=(st_seq.reshape(N * Ls, parts, 2), pq.eps, pq.cs[C:]))
-        q = ops.gemm_conv(own_x, pq.wf[:C], B=1, H=1, W=N * L, taps=1, bias=pq.bf[:C], ln=(own_st, pq.eps, pq.cs[:C]))
+        q = ops.gemm_conv(own_x, pq.wf[:C], B=1, H=1, W=N * Lo, taps=1, bias=pq.bf[:C], ln=(own_st, pq.eps, pq.cs[:C]))
     else:
         n_seq = ops.layer_norm(seq.reshape(N * Ls, C), pt.n1.g, pt.n1.b, pt.n1.eps)
         kv = ops.gemm_conv(n_seq, pq.w[C:], B=1, H=1, W=N * Ls, taps=1)       # K | V for every row of the sequence
-        own_n = lrd.mv_own_rows(n_seq.reshape(N, Ls, C), rank, s).reshape(N * L, C)
-        q = ops.gemm_conv(own_n, pq.w[:C], B=1, H=1, W=N * L, taps=1)         # Q only for the rows this rank owns
-    a = ops.attention(q, kv[:, :C], kv[:, C:], N, pt.attn1.heads, L, Ls, pt.attn1.dim_head ** -0.5)
-    y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target', ref_rank']
+        q = ops.gemm_conv(own(n_seq.reshape(N, Ls, C)).reshape(N * Lo, C), pq.w[:C], B=1, H=1, W=N * Lo, taps=1)
+    a = ops.attention(q, kv[:, :C], kv[:, C:], N, pt.attn1.heads, Lo, Ls, pt.attn1.dim_head ** -0.5)
+    y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target' (slice), ref_rank']
+    if split:
+        y = y.reshape(N, Lo, C)
+        tgt = lrd.mv_gather_target(y[:, :s2 // world])                        # [N, s2, C]: the whole new target block
+        y = torch.cat([tgt, y[:, s2 // world:]], dim=1).reshape(N * L, C)
     return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
 
 

@@ -520,11 +520,29 @@ def _mv_worker(rank, world, port, q):
     a = unet_ref.attention(lrd.mv_own_rows(qq, rank, s), kk, vv, heads, mode)
     y = torch.nn.functional.linear(a, sd["m.attn1.to_out.0.weight"], sd["m.attn1.to_out.0.bias"]) + lrd.mv_own_rows(sq, rank, s)
     out = lrd.mv_canvas_from_own(y, s)
-    q.put((rank, float((out - ref).abs().max())))
+    err = float((out - ref).abs().max())
+    # round 5: ONE collective for the inputs (whole canvases + a per-row fp32 payload packed into the same message) ...
+    extra = G.T("mvd.extra", (b * v, L, 6)).reshape(b, v, L, 6)
+    xa, ea = lrd.mv_exchange_canvases(x_local.half(), extra[:, rank].contiguous())
+    assert xa.shape == (b, v, L, C) and torch.equal(xa, x_full.reshape(b, v, L, C).half()) and torch.equal(ea, extra)
+    assert torch.equal(lrd.mv_sequence_from_canvases(xa, s), seq.half())
+    assert lrd.mv_exchange_canvases(x_local.half())[1] is None
+    # ... and the target query rows split over the ranks, the new target slices all-gathered behind the out-projection
+    n_t = s * s // world
+    a2 = unet_ref.attention(lrd.mv_own_rows_split(qq, rank, s, world), kk, vv, heads, mode)
+    y2 = torch.nn.functional.linear(a2, sd["m.attn1.to_out.0.weight"], sd["m.attn1.to_out.0.bias"]) + lrd.mv_own_rows_split(sq, rank, s, world)
+    tgt = lrd.mv_gather_target(y2[:, :n_t].contiguous())
+    assert tgt.shape == (b, s * s, C)
+    out2 = lrd.mv_canvas_from_own(torch.cat([tgt, y2[:, n_t:]], dim=1), s)
+    q.put((rank, max(err, float((out2 - ref).abs().max()))))
     dist.destroy_process_group()
 
 
-def test_multiview_canvas_sharding_gloo_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_multiview_canvas_sharding_gloo(world):
+    """Exchange / row-ownership / write-back logic of the canvas-sharded multi-view attention on world_size-2 and -4 gloo groups:
+    the minimal exchange of round 3 (reference halves + rank 0's target), the one-message exchange of round 5 (whole canvases with
+    the LayerNorm statistics packed behind each row) and the split of the target rows with its all-gather of the results."""
     import socket
     import torch.multiprocessing as mp
     sk = socket.socket()
@@ -533,11 +551,11 @@ def test_multiview_canvas_sharding_gloo_world2():
     sk.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mv_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_mv_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in range(2))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(60)
-    assert [r for r, _ in res] == [0, 1]
+    assert [r for r, _ in res] == list(range(world))
     assert all(err < 1e-5 for _, err in res), res
