@@ -851,16 +851,20 @@ def main():
             res["metric"] = "PER-RANK cost of the sharded multi-view step (rank %s of %d, peers simulated by local copies: no wire time)" % (
                 os.environ.get("LEFTREFILL_MV_SIM_RANK", "0"), views_)
             res["unit"] = "samples/s if the collectives were free"
-            res["config"]["parallelism"] = (f"mv-shard x{views_} simulated on one GPU: one canvas per rank; per transformer block the rows an "
-                                            "all_gather_into_tensor of the reference halves + a broadcast of the target half would deliver are "
-                                            "written from local data (same kernels, same bytes)")
+            from leftrefill_amd import engine as _eng
+            res["config"]["parallelism"] = (f"mv-shard x{views_} simulated on one GPU: one canvas per rank; per transformer block the rows ONE "
+                                            "all_gather_into_tensor of the ranks' canvases (+ LayerNorm statistics, same message) would deliver are "
+                                            "written from local data (same kernels, same bytes); "
+                                            + ("target query rows split over the ranks, their results all-gathered behind the out-projection "
+                                               "(second collective, simulated the same way)" if _eng.MV_SPLIT_TARGET else
+                                               "target rows replicated on every rank (LEFTREFILL_MV_SPLIT_TARGET=0)"))
             res["per_rank_unet_step_ms"] = unet_step_ms
         elif a.mv_shard:
             res["scaling"] = "strong"
             res["metric"] = "multi-view samples/sec (4-ref, 5 x 4096-token cross-view self-attention) @ 50 DDIM steps, cfg=2.5; canvases sharded over ranks"
             res["unit"] = "samples/s"
             res["config"]["parallelism"] = (f"mv-shard x{world}: one canvas per rank; per transformer block one all_gather_into_tensor of the "
-                                            f"reference halves + one broadcast of rank 0's target half ({backend}), "
+                                            f"ranks' canvases with their LayerNorm statistics and one of the new target-row slices ({backend}), "
                                             + ("captured in the hipGraph" if backend == "nccl" else "eager (gloo test hook)"))
     if a.split_cfg:
         res["config"]["parallelism"] = (f"split-cfg x{world}: {replicas} pair(s) of ranks, uncond pass on rank 2j / cond pass on 2j+1 at UNet "

@@ -1,7 +1,7 @@
 """Developer tool (MI355X only): time every (tile, split-K) plan for every GEMM shape of the shipped workloads and write
 the table that `leftrefill_amd/tile_table.json` ships in-tree.
 
-    LEFTREFILL_AUTOTUNE=1 python tools/tune_tiles.py [--out gpurun_out/tile_table.json] [--workloads single,cfg0,mv5,train,vae]
+    LEFTREFILL_AUTOTUNE=1 python tools/tune_tiles.py [--out gpurun_out/tile_table.json] [--workloads single,cfg0,mv5,mv5shard,train,vae]
 
 The product never times anything: ops.gemm_conv looks the plan up in the committed table (a pure function of the shape).
 """
@@ -71,6 +71,19 @@ def main():
         unet_pass(mv, 4, 64, 128, device)
         del mv
         print("mv5:", len(ops.tile_cache()), "shapes", flush=True)
+    if "mv5shard" in wl:      # one rank of the 4-rank canvas-sharded multi-view job (peers simulated): UNet batch 2, own-row attention shapes
+        torch.cuda.empty_cache()
+        os.environ["LEFTREFILL_MV_SIM_WORLD"] = "4"
+        mv = bench.build_model(device, "mv5")
+        mv.model.diffusion_model.mv_shard = True
+        for split in ("1", "0"):
+            from leftrefill_amd import engine
+            engine.MV_SPLIT_TARGET = split == "1"
+            unet_pass(mv, 1, 64, 128, device)
+        engine.MV_SPLIT_TARGET = True
+        del mv
+        os.environ.pop("LEFTREFILL_MV_SIM_WORLD")
+        print("mv5shard:", len(ops.tile_cache()), "shapes", flush=True)
     if "vae" in wl:
         torch.cuda.empty_cache()
         bench.vae_timing(4, device)
