@@ -305,6 +305,20 @@ int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, float scale,
  *           canvas) for concat_target=True.  x [b*v][2*s*s][C] canvases (left = ref_i, right = target), seq [b][(v+1)*s*s][C].
  * (concat_target=False is a pure reshape and needs no kernel.) */
 int lr_mv_gather(const lr_half* x, lr_half* seq, int b, int v, int s, int C, lr_stream_t st);
+/* ---- row copies with index tables (ABI 23) -----------------------------------------------------------------------------------
+ * replaces: the rearranges around the cross-view self-attention when the canvases of a sample live on different ranks
+ *           (`rearrange(x, '(b v) hw c -> b (v hw) c')`, the concat_target slicing and the write-back, reference
+ *           ldm/modules/multiview_attention.py:436-462): pack rows + per-row statistics into one message, unpack a received message
+ *           into sequence order and into this rank's own rows, assemble the canvas -- up to 4 independent jobs in ONE launch.
+ * job: for r < n_rows copy row_bytes bytes  src + src_idx[r] * src_pitch + src_off  ->  dst + dst_idx[r] * dst_pitch + dst_off
+ *      (a NULL index table = the identity).  All byte counts / offsets / pitches / pointers multiples of 8. */
+typedef struct lr_row_copy_job {
+  const void* src; int64_t src_pitch, src_off;
+  void* dst; int64_t dst_pitch, dst_off;
+  int32_t row_bytes, n_rows;
+  const int32_t* src_idx; const int32_t* dst_idx;
+} lr_row_copy_job;
+int lr_row_copy(const lr_row_copy_job* jobs, int n_jobs, lr_stream_t s);
 int lr_mv_scatter(const lr_half* seq, lr_half* x, int b, int v, int s, int C, lr_stream_t st);
 
 /* ---- fused classifier-free-guidance + DDIM update ----------------------------------------------------------------

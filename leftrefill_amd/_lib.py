@@ -62,6 +62,13 @@ class XattnArgs(ctypes.Structure):
                 ("pre_a", c_void_p), ("pre_w", c_void_p), ("pre_b", c_void_p)]
 
 
+class RowCopyJob(ctypes.Structure):
+    """struct lr_row_copy_job (include/leftrefill_hip.h)."""
+    _fields_ = [("src", c_void_p), ("src_pitch", ctypes.c_int64), ("src_off", ctypes.c_int64),
+                ("dst", c_void_p), ("dst_pitch", ctypes.c_int64), ("dst_off", ctypes.c_int64),
+                ("row_bytes", ctypes.c_int32), ("n_rows", ctypes.c_int32), ("src_idx", c_void_p), ("dst_idx", c_void_p)]
+
+
 class FfnArgs(ctypes.Structure):
     """struct lr_ffn_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
@@ -118,6 +125,7 @@ SIGNATURES = {
     "lr_xattn_pack_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "lr_ffn_block_f16": [ctypes.POINTER(FfnArgs), c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "lr_row_copy": [c_void_p, c_int, c_void_p],
     "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_ddim_cfg_step": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                          c_float, c_float, c_void_p],

@@ -168,6 +168,24 @@ __global__ void mv_scatter_kernel(const uint4* __restrict__ seq, uint4* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Row copies with optional index tables (lr_row_copy): the glue of the canvas-sharded multi-view block -- packing rows + their
+// LayerNorm statistics into one message, unpacking a received message into sequence order / this rank's own rows, writing the
+// canvas back -- as ONE launch of up to four jobs instead of a dozen torch slice / cat / copy kernels.  8-byte granules.
+// ---------------------------------------------------------------------------------------------------------------
+struct RowCopyJobs { lr_row_copy_job j[4]; };
+__global__ void row_copy_kernel(const RowCopyJobs J) {
+  const lr_row_copy_job& jb = J.j[blockIdx.y];
+  const int g8 = jb.row_bytes >> 3;                       // 8-byte granules per row
+  const long long total = (long long)jb.n_rows * g8;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / g8), g = (int)(idx - (long long)r * g8);
+    const long long sr = jb.src_idx ? jb.src_idx[r] : r, dr = jb.dst_idx ? jb.dst_idx[r] : r;
+    const uint2 v = *reinterpret_cast<const uint2*>((const char*)jb.src + sr * jb.src_pitch + jb.src_off + (long long)g * 8);
+    *reinterpret_cast<uint2*>((char*)jb.dst + dr * jb.dst_pitch + jb.dst_off + (long long)g * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // CFG combine + DDIM update (ddim.py:343-381), fp32 state, 4 elements per thread.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename EpsT, typename T>
@@ -460,3 +478,20 @@ extern "C" int lr_mv_gather_bwd(const lr_half* dseq, lr_half* dx, int b, int v, 
 extern "C" int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_gather_bwd_t<bf16>(dseq, dx, b, v, s, C, st); }
 extern "C" int lr_mv_scatter_bwd(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_bwd_t<f16>(dx, dseq, b, v, s, C, st); }
 extern "C" int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st) { return lr_mv_scatter_bwd_t<bf16>(dx, dseq, b, v, s, C, st); }
+extern "C" int lr_row_copy(const lr_row_copy_job* jobs, int n_jobs, lr_stream_t st) {
+  if (!jobs || n_jobs < 1 || n_jobs > 4) return LR_E_ARG;
+  RowCopyJobs J;
+  long long mx = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const lr_row_copy_job& jb = jobs[i];
+    if (!jb.src || !jb.dst || jb.n_rows < 0 || jb.row_bytes <= 0) return LR_E_ARG;
+    if ((jb.row_bytes | jb.src_pitch | jb.dst_pitch | jb.src_off | jb.dst_off | (int64_t)(uintptr_t)jb.src | (int64_t)(uintptr_t)jb.dst) & 7) return LR_E_ALIGN;
+    J.j[i] = jb;
+    const long long t_ = (long long)jb.n_rows * (jb.row_bytes >> 3);
+    if (t_ > mx) mx = t_;
+  }
+  if (mx == 0) return 0;
+  hipLaunchKernelGGL(row_copy_kernel, dim3(grid_for(mx, 256), n_jobs), dim3(256), 0, (hipStream_t)st, J);
+  return lr_launch_status();
+}
+

@@ -150,6 +150,68 @@ def mv_gather_sequence(x_local, s, seq=None):
     return seq.reshape(b, (world + 1) * s2, C)
 
 
+def mv_all_gather_rows(send):
+    """send [R, ...] (contiguous) -> [world * R, ...] in rank order: ONE all_gather_into_tensor (RCCL on GPUs; gloo stages through the
+    host; simulated peers receive copies of the local rows -- same bytes written, no wire)."""
+    world = mv_group_size()
+    if world == 1:
+        return send
+    if _sim_world():
+        return send[None].expand((world,) + tuple(send.shape)).reshape((world * send.shape[0],) + tuple(send.shape[1:])).contiguous()
+    src = send.contiguous()
+    staged = _staged(src)
+    if staged:
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)      # concatenation form
+    dist.all_gather_into_tensor(out, src)
+    return out.to(send.device) if staged else out
+
+
+_MV_PLANS = {}
+
+
+def mv_shard_plan(b, v, s, rank, split, device):
+    """Index tables (int32, on `device`, cached per shape) of the sharded block's row copies (leftrefill_amd.ops.row_copy):
+      seq_src [b Ls]  : received row (canvas-major message [v][b][2 s^2]) of every sequence row [target of canvas 0, ref_0 .. ref_{v-1}]
+      own_src [b Lo]  : received row of every row this rank owns as a query ([target slice `rank`, ref_rank] with `split`, else
+                        [target, ref_rank])
+      and, with `split`, the write-back of the canvas [ref' | target'] from y [b Lo] (this rank's rows) and the all-gathered target
+      slices [v][b][s^2 / v]:  ref_src / ref_dst,  tgt_src / tgt_dst  (b s^2 rows each)."""
+    key = (b, v, s, rank, bool(split), str(device))
+    p = _MV_PLANS.get(key)
+    if p is not None:
+        return p
+    s2, T = s * s, 2 * s * s
+    Ls = (v + 1) * s2
+    ar = torch.arange
+    row, col = ar(s2) // s, ar(s2) % s
+    tgt_rows = row * (2 * s) + s + col          # canvas row of target pixel p
+    ref_rows = row * (2 * s) + col              # canvas row of reference pixel p
+
+    def recv(canvas, bi, crow):
+        return (canvas * b + bi) * T + crow
+
+    seq_src = torch.empty(b, v + 1, s2, dtype=torch.long)
+    for bi in range(b):
+        seq_src[bi, 0] = recv(0, bi, tgt_rows)
+        for j in range(v):
+            seq_src[bi, 1 + j] = recv(j, bi, ref_rows)
+    n = s2 // v if split else s2
+    own = torch.cat([seq_src[:, 0, rank * n:(rank + 1) * n] if split else seq_src[:, 0], seq_src[:, 1 + rank]], dim=1)
+    p = {"seq_src": seq_src.reshape(-1), "own_src": own.reshape(-1), "Lo": n + s2, "n": n}
+    if split:
+        Lo = n + s2
+        bi = ar(b)[:, None]
+        p["ref_src"] = (bi * Lo + n + ar(s2)[None]).reshape(-1)
+        p["ref_dst"] = (bi * T + ref_rows[None]).reshape(-1)
+        pp = ar(s2)[None]
+        p["tgt_src"] = (((pp // n) * b + bi) * n + pp % n).reshape(-1)
+        p["tgt_dst"] = (bi * T + tgt_rows[None]).reshape(-1)
+    p = {k: (t.to(device=device, dtype=torch.int32).contiguous() if torch.is_tensor(t) else t) for k, t in p.items()}
+    _MV_PLANS[key] = p
+    return p
+
+
 def mv_exchange_canvases(x_local, extra=None):
     """ONE collective per transformer block (round 5, VERDICT r4 #5a): all-gather of the ranks' WHOLE canvases, with an optional
     per-row fp32 payload (the rows' LayerNorm partial sums) packed behind each row's bytes so that it rides in the same message.
@@ -169,18 +231,12 @@ def mv_exchange_canvases(x_local, extra=None):
     esz = x_local.element_size()
     rb = C * esz + 4 * E
     assert esz == 2 and (C * esz) % 4 == 0
-    staged = _staged(x_local)
-    dev = torch.device("cpu") if staged else x_local.device
-    send = torch.empty(b * T, rb, dtype=torch.uint8, device=dev)
+    send = torch.empty(b * T, rb, dtype=torch.uint8, device=x_local.device)
     send[:, :C * esz].view(x_local.dtype).copy_(x_local.reshape(b * T, C))
     if E:
         assert extra.dtype == torch.float32 and extra.shape[:2] == (b, T)
         send[:, C * esz:].view(torch.float32).copy_(extra.reshape(b * T, E))
-    recv = torch.empty(world * b * T, rb, dtype=torch.uint8, device=dev)      # concatenation form (the one gloo accepts too)
-    dist.all_gather_into_tensor(recv, send)
-    if staged:
-        recv = recv.to(x_local.device)
-    recv = recv.reshape(world, b * T, rb)
+    recv = mv_all_gather_rows(send).reshape(world, b * T, rb)
     x_all = recv[:, :, :C * esz].view(x_local.dtype).reshape(world, b, T, C).transpose(0, 1)
     e_all = recv[:, :, C * esz:].view(torch.float32).reshape(world, b, T, E).transpose(0, 1) if E else None
     return x_all, e_all
@@ -202,15 +258,8 @@ def mv_gather_target(y_t):
     if world == 1:
         return y_t
     b, n, C = y_t.shape
-    if _sim_world():
-        return y_t[:, None].expand(b, world, n, C).reshape(b, world * n, C).contiguous()
-    src = y_t.contiguous()
-    staged = _staged(src)
-    if staged:
-        src = src.cpu()
-    out = torch.empty(world * b, n, C, dtype=src.dtype, device=src.device)
-    dist.all_gather_into_tensor(out, src)
-    return out.to(y_t.device).reshape(world, b, n, C).permute(1, 0, 2, 3).reshape(b, world * n, C)
+    out = mv_all_gather_rows(y_t.contiguous())
+    return out.reshape(world, b, n, C).permute(1, 0, 2, 3).reshape(b, world * n, C)
 
 
 def mv_all_gather_canvases(x_local):

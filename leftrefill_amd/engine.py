@@ -529,6 +529,8 @@ MV_SHARDED = False
 # target query rows split over the ranks of a sharded multi-view job (one all-gather of the new target rows per block) instead of
 # replicated on every rank
 MV_SPLIT_TARGET = __import__("os").environ.get("LEFTREFILL_MV_SPLIT_TARGET", "1") != "0"
+# the glue of the sharded block through lr_row_copy (three launches per block); 0: the torch slice / cat form the CPU (gloo) tests pin
+MV_ROW_COPY = __import__("os").environ.get("LEFTREFILL_MV_ROW_COPY", "1") != "0"
 
 
 def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
@@ -553,29 +555,61 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
     pq = pt.attn1.qkv                                                         # rows [Wq; Wk; Wv] of the fused projection
     fold = st is not None and pq.wf is not None and fold_ok(x) and MV_LN_FOLD
     parts = st.shape[1] if fold else 0
-    x_all, st_all = lrd.mv_exchange_canvases(x.reshape(N, L, C), st.reshape(N, L, parts * 2) if fold else None)
-    seq = lrd.mv_sequence_from_canvases(x_all, s)                             # [N, Ls, C] (one copy out of the receive buffer)
     split = MV_SPLIT_TARGET and world > 1 and s2 % world == 0
-    own = (lambda t_: lrd.mv_own_rows_split(t_, rank, s, world)) if split else (lambda t_: lrd.mv_own_rows(t_, rank, s))
     Lo = s2 // world + s2 if split else L
-    own_x = own(seq).reshape(N * Lo, C)
+    if x.is_cuda and MV_ROW_COPY:
+        # the glue as three launches of lr_row_copy with cached index tables (pack | unpack | write-back) around the collectives
+        E = 2 * parts
+        rb = 2 * C + 4 * E
+        plan = lrd.mv_shard_plan(N, v, s, rank, split, x.device)
+        send = torch.empty(N * L, rb, dtype=torch.uint8, device=x.device)
+        jobs = [dict(src=x, dst=send, row_bytes=2 * C, n_rows=N * L)]
+        if fold:
+            jobs.append(dict(src=st.reshape(N * L, E), dst=send, dst_off=2 * C, row_bytes=4 * E, n_rows=N * L))
+        ops.row_copy(jobs)
+        recv = lrd.mv_all_gather_rows(send)                                   # [v N L, rb] bytes, canvas-major: ONE collective
+        seq = torch.empty(N * Ls, C, dtype=x.dtype, device=x.device)
+        own_x = torch.empty(N * Lo, C, dtype=x.dtype, device=x.device)
+        jobs = [dict(src=recv, dst=seq, row_bytes=2 * C, n_rows=N * Ls, src_idx=plan["seq_src"]),
+                dict(src=recv, dst=own_x, row_bytes=2 * C, n_rows=N * Lo, src_idx=plan["own_src"])]
+        if fold:
+            st_seq = torch.empty(N * Ls, parts, 2, dtype=torch.float32, device=x.device)
+            own_st = torch.empty(N * Lo, parts, 2, dtype=torch.float32, device=x.device)
+            jobs += [dict(src=recv, src_off=2 * C, dst=st_seq.reshape(N * Ls, E), row_bytes=4 * E, n_rows=N * Ls, src_idx=plan["seq_src"]),
+                     dict(src=recv, src_off=2 * C, dst=own_st.reshape(N * Lo, E), row_bytes=4 * E, n_rows=N * Lo, src_idx=plan["own_src"])]
+        ops.row_copy(jobs)
+    else:
+        x_all, st_all = lrd.mv_exchange_canvases(x.reshape(N, L, C), st.reshape(N, L, parts * 2) if fold else None)
+        seq = lrd.mv_sequence_from_canvases(x_all, s).reshape(N * Ls, C)      # [N Ls, C] (one copy out of the receive buffer)
+        own = (lambda t_: lrd.mv_own_rows_split(t_, rank, s, world)) if split else (lambda t_: lrd.mv_own_rows(t_, rank, s))
+        own_x = own(seq.reshape(N, Ls, C)).reshape(N * Lo, C)
+        if fold:
+            st_seq = lrd.mv_sequence_from_canvases(st_all, s)                 # [N, Ls, parts * 2] fp32
+            own_st = own(st_seq).reshape(N * Lo, parts, 2).contiguous()
+            st_seq = st_seq.reshape(N * Ls, parts, 2)
     if fold:
-        st_seq = lrd.mv_sequence_from_canvases(st_all, s)                     # [N, Ls, parts * 2] fp32
-        own_st = own(st_seq).reshape(N * Lo, parts, 2).contiguous()
-        kv = ops.gemm_conv(seq.reshape(N * Ls, C), pq.wf[C:], B=1, H=1, W=N * Ls, taps=1, bias=pq.bf[C:],
-                           ln=(st_seq.reshape(N * Ls, parts, 2), pq.eps, pq.cs[C:]))
+        kv = ops.gemm_conv(seq, pq.wf[C:], B=1, H=1, W=N * Ls, taps=1, bias=pq.bf[C:], ln=(st_seq, pq.eps, pq.cs[C:]))
         q = ops.gemm_conv(own_x, pq.wf[:C], B=1, H=1, W=N * Lo, taps=1, bias=pq.bf[:C], ln=(own_st, pq.eps, pq.cs[:C]))
     else:
-        n_seq = ops.layer_norm(seq.reshape(N * Ls, C), pt.n1.g, pt.n1.b, pt.n1.eps)
+        n_seq = ops.layer_norm(seq, pt.n1.g, pt.n1.b, pt.n1.eps)
         kv = ops.gemm_conv(n_seq, pq.w[C:], B=1, H=1, W=N * Ls, taps=1)       # K | V for every row of the sequence
-        q = ops.gemm_conv(own(n_seq.reshape(N, Ls, C)).reshape(N * Lo, C), pq.w[:C], B=1, H=1, W=N * Lo, taps=1)
+        n_own = ops.layer_norm(own_x, pt.n1.g, pt.n1.b, pt.n1.eps)            # (row-wise: the own rows' LayerNorm again, 1 / 4 of the sequence)
+        q = ops.gemm_conv(n_own, pq.w[:C], B=1, H=1, W=N * Lo, taps=1)
     a = ops.attention(q, kv[:, :C], kv[:, C:], N, pt.attn1.heads, Lo, Ls, pt.attn1.dim_head ** -0.5)
     y = linear(a, pt.attn1.out, resid=own_x)                                  # rows [target' (slice), ref_rank']
-    if split:
-        y = y.reshape(N, Lo, C)
-        tgt = lrd.mv_gather_target(y[:, :s2 // world])                        # [N, s2, C]: the whole new target block
-        y = torch.cat([tgt, y[:, s2 // world:]], dim=1).reshape(N * L, C)
-    return ops.mv_scatter(y, N, 1, s)                                         # -> canvas [ref' | target']
+    if not split:
+        return ops.mv_scatter(y, N, 1, s)                                     # -> canvas [ref' | target']
+    n_t = s2 // world
+    tgt_all = lrd.mv_all_gather_rows(y.reshape(N, Lo, C)[:, :n_t].contiguous())          # [v N, n_t, C]: second collective
+    if x.is_cuda and MV_ROW_COPY:
+        canvas = torch.empty(N * L, C, dtype=x.dtype, device=x.device)
+        ops.row_copy([dict(src=y, dst=canvas, row_bytes=2 * C, n_rows=N * s2, src_idx=plan["ref_src"], dst_idx=plan["ref_dst"]),
+                      dict(src=tgt_all.reshape(world * N * n_t, C), dst=canvas, row_bytes=2 * C, n_rows=N * s2, src_idx=plan["tgt_src"],
+                           dst_idx=plan["tgt_dst"])])
+        return canvas
+    tgt = tgt_all.reshape(world, N, n_t, C).permute(1, 0, 2, 3).reshape(N, s2, C)
+    y = torch.cat([tgt, y.reshape(N, Lo, C)[:, n_t:]], dim=1).reshape(N * L, C)
+    return ops.mv_scatter(y, N, 1, s)
 
 
 # GroupNorm of the SpatialTransformer folded into proj_in through per-sample weights (levels where the activation is much larger

@@ -640,6 +640,25 @@ def mv_gather(x, b, v, s):
     return seq
 
 
+def row_copy(jobs):
+    """Up to four row-copy jobs in one launch (lr_row_copy).  job = dict(src, dst, row_bytes, n_rows[, src_off, dst_off, src_idx,
+    dst_idx]): tensors with contiguous rows (pitch = stride(0) in bytes); index tables int32 device tensors or None (identity)."""
+    lib = _lib.load()
+    assert 1 <= len(jobs) <= 4
+    arr = (_lib.RowCopyJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        src, dst = j["src"], j["dst"]
+        assert src.is_cuda and dst.is_cuda and src.stride(-1) == 1 and dst.stride(-1) == 1
+        a.src, a.src_pitch, a.src_off = src.data_ptr(), src.stride(0) * src.element_size(), int(j.get("src_off", 0))
+        a.dst, a.dst_pitch, a.dst_off = dst.data_ptr(), dst.stride(0) * dst.element_size(), int(j.get("dst_off", 0))
+        a.row_bytes, a.n_rows = int(j["row_bytes"]), int(j["n_rows"])
+        si, di = j.get("src_idx"), j.get("dst_idx")
+        for t_ in (si, di):
+            assert t_ is None or (t_.dtype == torch.int32 and t_.is_cuda and t_.is_contiguous() and t_.numel() >= a.n_rows)
+        a.src_idx, a.dst_idx = _p(si), _p(di)
+    _lib.check(lib.lr_row_copy(arr, len(jobs), _stream()), "row_copy")
+
+
 def mv_scatter(seq, b, v, s):
     lib = _lib.load()
     _chk16(seq, "seq")

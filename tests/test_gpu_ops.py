@@ -1017,6 +1017,28 @@ def test_attention_pingpong_kernel_matches_reference_kernel(B, heads, Nq, Nkv):
     report(f"attention pp B{B} h{heads} {Nq}x{Nkv}", outs["1"].reshape(B, Nq, C), ref, atol=8e-3)
 
 
+def test_row_copy_jobs():
+    """lr_row_copy: several gather / scatter jobs with index tables, byte offsets and different row sizes in one launch."""
+    from leftrefill_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    src = torch.randint(0, 255, (37, 104), dtype=torch.uint8, generator=g).to(d)          # 104-byte rows: 64 "x" bytes + 40 "stats" bytes
+    si = torch.randperm(37, generator=g)[:20].to(torch.int32).to(d)
+    di = torch.randperm(25, generator=g)[:20].to(torch.int32).to(d)
+    a = torch.zeros(20, 32, dtype=torch.float16, device=d)
+    b_ = torch.zeros(25, 10, dtype=torch.float32, device=d)
+    c = torch.zeros(37, 104, dtype=torch.uint8, device=d)
+    ops.row_copy([dict(src=src, dst=a, row_bytes=64, n_rows=20, src_idx=si),
+                  dict(src=src, src_off=64, dst=b_, row_bytes=40, n_rows=20, src_idx=si, dst_idx=di),
+                  dict(src=src, dst=c, row_bytes=104, n_rows=37)])
+    assert torch.equal(a.view(torch.uint8), src[si.long(), :64])
+    want = torch.zeros(25, 40, dtype=torch.uint8, device=d)
+    want[di.long()] = src[si.long(), 64:]
+    assert torch.equal(b_.view(torch.uint8), want) and torch.equal(c, src)
+    with pytest.raises(RuntimeError):
+        ops.row_copy([dict(src=src, dst=a, row_bytes=60, n_rows=20)])                     # not a multiple of 8 bytes
+
+
 def test_mv_gather_scatter():
     from leftrefill_amd import ops
     b, V, s, C = 2, 5, 4, 64

@@ -251,6 +251,32 @@ def test_multiview_canvas_sharded_path_single_rank(golden):
     assert rel < 4e-3
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["split_target", "replicated_target"])
+def test_multiview_sharded_block_row_copy_glue_equals_torch_glue(monkeypatch, split):
+    """The sharded block's glue (pack rows + LayerNorm statistics into one message, unpack into sequence order and own rows, write the
+    canvas back) as three lr_row_copy launches == the torch slice / cat form that the gloo tests pin against the oracle, bit for bit:
+    one rank of a simulated 4-rank job (LEFTREFILL_MV_SIM_WORLD: the peers' rows are copies of the local ones), every rank id, with
+    the target rows split over the ranks and replicated."""
+    from leftrefill_amd import engine
+    V = 5      # 4 ranks: the target rows (256 / 64 / 16 / 4 per level at this size) split evenly
+    m, sd, cfg = get_model("MV", (V, True))
+    x, t, ctx = G.unet_inputs("mv_glue", cfg, 2, 16, 32, [501, 501])
+    monkeypatch.setenv("LEFTREFILL_MV_SIM_WORLD", str(V - 1))
+    monkeypatch.setattr(engine, "MV_SPLIT_TARGET", split)
+    m.mv_shard = True
+    try:
+        for rank in range(V - 1):
+            monkeypatch.setenv("LEFTREFILL_MV_SIM_RANK", str(rank))
+            outs = []
+            for rc in (True, False):
+                monkeypatch.setattr(engine, "MV_ROW_COPY", rc)
+                with torch.no_grad():
+                    outs.append(m(x.to(dev()), t.to(dev()), ctx.to(dev())))
+            assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), f"rank {rank}"
+    finally:
+        m.mv_shard = False
+
+
 def test_context_kv_cache_is_invalidated_correctly():
     """The step graph caches the cross-attention K/V projections per context tensor (constant over the DDIM loop)."""
     m, sd, cfg = get_model("MID")
