@@ -33,6 +33,8 @@ TILE_CANDIDATES = ((128, 64, 0), (128, 128, 0), (128, 160, 0), (128, 128, 4), (1
 TILE_TABLE_PATH = os.environ.get("LEFTREFILL_TILE_TABLE_PATH",      # (developer override: A/B of a freshly tuned table)
                                  os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json"))
 _tile_cache = None
+PLAN_LOG = os.environ.get("LEFTREFILL_PLAN_LOG", "0") == "1"
+_untabulated = set()
 
 
 # Plan GEMMs as if the batch were `scale` times larger (the shared prefix of a CFG batch runs on half the samples but must
@@ -332,6 +334,10 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         # (a conv with the pointwise extension is planned like the plain conv: the table knows that shape)
         key = tile_key(M * scale, Nw, Kw - Cs1 - Cs2, taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
+        if best is None and PLAN_LOG and key not in _untabulated:      # developer aid: which shapes fall back to the static heuristic
+            _untabulated.add(key)
+            import sys
+            print(f"[leftrefill] untabulated GEMM shape {key} (taps {taps}, H {H}, W {W}, skip {skip is not None})", file=sys.stderr, flush=True)
         if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
             a.B = B * scale
             if ln is not None or want_stats:
