@@ -168,7 +168,8 @@ typedef struct lr_gemm_args {
                              * LR_PIPE_W8_DEEP (4), tile_m 128 with tile_n 128 | 160: 8 waves (4 x 2, wave tile 32 x tile_n/2), 4-stage
                              * ring, one block per CU (the 4096- / 1024-row levels).
                              * LR_PIPE_HALO (8, ABI 23), tile_m 256 with tile_n 160 | 320: the halo-tile conv -- 3x3, stride 1, pad 1, no
-                             * upsample, H and W multiples of 16, no split-K: a block owns a 16 x 16 pixel tile, the 18 x 18 input patch of a
+                             * upsample, W a multiple of 16 and H a multiple of 16 (or H = 8 with an even number of samples: a tile is then the
+                             * 8 x 16 pixels of two samples); split-K by whole 64-channel chunks: a block owns a 16 x 16 pixel tile, the 18 x 18 input patch of a
                              * 64-channel chunk is copied to LDS once and the nine taps are shifted reads of it (conv_halo.hip); K is
                              * accumulated chunk-major, so results agree with the other instances to fp32 rounding, not bit for bit.
                              * Anything else: LR_E_UNSUPPORTED */

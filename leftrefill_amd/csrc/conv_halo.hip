@@ -39,8 +39,8 @@
 #define HALO_EXP 0
 #endif
 #define HALO_PW 18          // patch width / height in pixels (16 + 2)
-#define HALO_NPX 324
-#define HALO_NQ 41          // LDS-DMA instructions per patch (8 pixel rows of 128 B each): 328 rows, the last 4 unused
+#define HALO_NQ 45          // LDS-DMA instructions per patch buffer (8 pixel rows of 128 B each): 41 in use for a 16-line image tile
+                            // (18 x 18 = 324 rows), 45 for the two-segment tile of 8-line images (2 x 10 x 18 = 360 rows)
 
 // BN = 320: 2 x 4 waves, wave tile 8 lines x 80 columns (40 MFMA tiles), 2-slot weight ring  (level 0: N = 320 is one tile)
 // BN = 160: 4 x 2 waves, wave tile 4 lines x 80 columns (20 MFMA tiles), 3-slot weight ring  (level 1: 16384 x 640 = 256 tiles)
@@ -73,12 +73,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   [[maybe_unused]] const int lr_trace_tile = bid;
   const int tile_n = bid % P.ntiles_n, tile = bid / P.ntiles_n;      // tile: 16 x 16 pixel tiles numbered sample-major, line-major
-  const int tiles_x = P.W >> 4, tps = (P.H >> 4) * tiles_x;
+  // 8-line images (the 8 x 16 level): a tile is lines 0..7 of TWO consecutive samples -- in token order exactly a 16-line image of
+  // the pair, so the output side needs nothing; the patch holds the two samples' 10 x 18 halo segments one after the other
+  // (zero rows between them: each segment has its own padding) and a wave's lines lie in one segment
+  const bool seg = P.H == 8;
+  const int Hv = seg ? 16 : P.H;                                      // height of the (virtual) image the tile grid covers
+  const int npx = seg ? 2 * 10 * HALO_PW : HALO_PW * HALO_PW, nq = (npx + 7) >> 3;
+  const int tiles_x = P.W >> 4, tps = (Hv >> 4) * tiles_x;
   const int smp = tile / tps, trem = tile - smp * tps;
   const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
   const int y0 = tyi * 16, x0 = txi * 16;
   const int n0 = tile_n * BN;
-  const int m_org = (smp * P.H + y0) * P.W + x0;
+  const int m_org = (smp * Hv + y0) * P.W + x0;
 
   // ---- patch loader state: source pixel of each of this lane's (up to 6) patch rows, -1 = outside the image (or row >= 324)
   // (bit 30 of a valid entry's complement is free: the channel chunk of the lane's LDS slot, (lane & 7) ^ (column & 6), rides in bits 28-30)
@@ -86,11 +92,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int px = (w + 8 * k) * 8 + (lane >> 3);
-    const int pl = (px * 3641) >> 16, pc = px - pl * HALO_PW;        // px / 18 for px < 328
-    const int y = y0 - 1 + pl, x = x0 - 1 + pc;
-    const bool ok = px < HALO_NPX && (unsigned)y < (unsigned)P.H && (unsigned)x < (unsigned)P.W;
+    const int pl = (px * 3641) >> 16, pc = px - pl * HALO_PW;        // px / 18 for px < 368
+    const int sg = seg ? (pl * 26) >> 8 : 0;                          // pl / 10 for pl < 20: the sample of the pair
+    const int y = (seg ? pl - 10 * sg : y0 + pl) - 1, x = x0 - 1 + pc;
+    const bool ok = px < npx && (unsigned)y < (unsigned)P.H && (unsigned)x < (unsigned)P.W;
     const int c = (lane & 7) ^ (pc & 6);
-    pix[k] = ok ? (((smp * P.H + y) * P.W + x) | (c << 28)) : -1;
+    pix[k] = ok ? (((((seg ? 2 * smp + sg : smp) * P.H + y) * P.W + x)) | (c << 28)) : -1;
   }
   const int Ctot = P.C1 + P.C2;
   const int cpt1 = P.C1 >> 6, ncm = Ctot >> 6, cpt3 = P.C3 >> 6;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int q = w + 8 * k;
-      if (q < HALO_NQ) {      // wave-uniform (only wave 0 has a sixth piece)
+      if (q < nq) {      // wave-uniform (only the first waves have a sixth piece)
         const unsigned vo = pix[k] >= 0 ? (unsigned)((pix[k] & 0x0FFFFFFF) * cs + (pix[k] >> 28) * 8) * 2u : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(patch + q * 1024), 16, vo, coff, 0, 0);
       }
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   };
 
   // ---- fragments: activation = 16 consecutive patch pixels of line (wave line i + ky) starting at column kx; weights as the GEMM
-  const int pb0 = wm * TM * HALO_PW + fr;
+  const int pb0 = (wm * TM + (seg ? 2 * ((wm * TM) >> 3) : 0)) * HALO_PW + fr;      // (second segment: two halo lines further down)
   auto read_frags = [&](vec8<T> (&xf)[TM], vec8<T> (&wf)[TN], const int slot, const int ks, const int ky, const int kx) {
     const char* Bs = wring + slot * B_BYTES;
     const int kc = ks * 4 + fq;
@@ -281,7 +288,7 @@ static int launch_halo_t(const GemmParams& P0, hipStream_t st) {
 // the LR_PIPE_HALO instances of lr_gemm_conv_f16 (called from gemm_conv.hip after its argument checks)
 int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
   if (P.taps != 9 || P.stride != 1 || P.up || P.zins || P.pad != 1 || P.c16 || P.splits < 1 || P.geglu || P.gelu || P.ln_part ||
-      P.wt_bstride || P.st_out || (P.H & 15) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
+      P.wt_bstride || P.st_out || ((P.H & 15) && !(P.H == 8 && P.M % 256 == 0)) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
     return LR_E_UNSUPPORTED;
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);

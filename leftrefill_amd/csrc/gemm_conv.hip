@@ -765,7 +765,7 @@ static int choose_splits(int M, int N, int K, int tm, int tn, int geglu, int sta
     if (t_ * 10 > 256 * 6 || chunks < 8) return 1;
     int s_ = (256 + t_ / 2) / t_;
     if (s_ > 8) s_ = 8;
-    if (s_ > chunks / 4) s_ = chunks / 4;
+    if (s_ > chunks / 2) s_ = chunks / 2;
     return s_ < 1 ? 1 : s_;
   }
   const int slots = (tm == 256 || stages == 4) ? 256 : 512;   // resident blocks on the chip

@@ -352,7 +352,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
             a.pipe = best[3] if len(best) > 3 else 0
-            if a.pipe == 8 and (H % 16 or W % 16):      # the table is keyed by M: the halo-tile instance needs 16 x 16 pixel tiles,
+            if a.pipe == 8 and (W % 16 or (H % 16 and not (H == 8 and M % 256 == 0))):      # the table is keyed by M: the halo-tile instance needs 16 x 16 pixel tiles (or pairs of 8-line images),
                 a.pipe = 0                              # any other latent of the same size takes the tile's gather instance
         if skip is not None and best is None:      # static heuristic: ask the library, then make sure the tile is a pipelined one
             plan = (ctypes.c_int32 * 4)()

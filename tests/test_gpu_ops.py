@@ -259,12 +259,18 @@ def test_conv_halo_tile(tile_n):
     for sp in (2, 3, 7):                                                                      # split-K by whole chunks (20 chunks: 10 | 7,7,6 | 3,3,3,3,3,3,2)
         _conv_case(f"halo{tile_n}_splitk{sp}", 2, 1280, 640, 16, 32, rowvec=True, resid=True, **dict(k, splits=sp))
     _conv_case(f"halo{tile_n}_splitk_empty", 1, 128, 320, 16, 16, **dict(k, splits=3))        # 2 chunks over 3 slices: one slice has no work
+    # 8-line images (the 8 x 16 level of the UNet): a tile = the 8 x 16 pixels of two consecutive samples, each with its own zero padding
+    _conv_case(f"halo{tile_n}_h8", 4, 320, 320, 8, 16, rowvec=True, resid=True, **k)
+    _conv_case(f"halo{tile_n}_h8_wide", 2, 128, 640, 8, 48, C2=192, **k)                      # three column tiles per pair of samples
+    _conv_case(f"halo{tile_n}_h8_splitk", 8, 1280, 1280, 8, 16, resid=True, **dict(k, splits=4))
     # shapes the instance does not cover are refused, never run wrong
     d = dev()
     x = torch.zeros(2 * 24 * 16, 64, device=d, dtype=torch.float16)
     w = torch.zeros(320, 576, device=d, dtype=torch.float16)
     with pytest.raises(RuntimeError):
         ops.gemm_conv(x, w, B=2, H=24, W=16, taps=9, **k)                                     # H not a multiple of 16
+    with pytest.raises(RuntimeError):
+        ops.gemm_conv(x[:3 * 8 * 16], w, B=3, H=8, W=16, taps=9, **k)                         # 8-line images come in pairs
     with pytest.raises(RuntimeError):
         ops.gemm_conv(x[:2 * 8 * 8 * 4], w, B=2, H=8, W=8, Hs=16, Ws=16, taps=9, stride=2, **k)
 

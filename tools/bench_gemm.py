@@ -1,6 +1,6 @@
 """Micro-benchmark of lr_gemm_conv_f16 for one shape across tile configurations (MI355X only).
 
-    python tools/bench_gemm.py M N K taps [tile_m tile_n splits] [--reps 20]
+    python tools/bench_gemm.py M N K taps [tile_m tile_n splits [pipe]] [--reps 20]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leftrefill_amd import ops  # noqa: E402
 
 
-def run(M, N, K, taps, tm, tn, splits, reps, geglu=False):
+def run(M, N, K, taps, tm, tn, splits, reps, geglu=False, pipe=0):
     dev = torch.device("cuda:0")
     C = K // taps
     if taps == 9:
@@ -27,7 +27,7 @@ def run(M, N, K, taps, tm, tn, splits, reps, geglu=False):
     b = torch.randn(N, device=dev)
     out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=torch.float16)
     f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits,
-                              geglu=geglu)
+                              geglu=geglu, pipe=pipe)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
@@ -53,11 +53,12 @@ if __name__ == "__main__":
         cfgs = [(a.dims[4], a.dims[5], a.dims[6] if len(a.dims) > 6 else 0)]
     else:
         cfgs = [(128, 64, 0), (128, 128, 0), (128, 160, 0), (256, 128, 0), (256, 160, 0), (256, 320, 0)]
+    pipe = a.dims[7] if len(a.dims) > 7 else 0
     for tm, tn, sp in cfgs:
         try:
             if a.geglu and tn == 160:
                 continue
-            us, tf = run(M, N, K, taps, tm, tn, sp, a.reps, a.geglu)
-            print(f"M={M} N={N} K={K} taps={taps} tile {tm}x{tn} splits={sp}: {us:8.1f} us  {tf:7.1f} TFLOP/s")
+            us, tf = run(M, N, K, taps, tm, tn, sp, a.reps, a.geglu, pipe)
+            print(f"M={M} N={N} K={K} taps={taps} tile {tm}x{tn} splits={sp} pipe={pipe}: {us:8.1f} us  {tf:7.1f} TFLOP/s")
         except Exception as e:  # noqa: BLE001
             print(f"tile {tm}x{tn}: {e}")

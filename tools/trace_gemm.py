@@ -42,6 +42,9 @@ def main():
     dev = torch.device("cuda:0")
     tiles = [(256, 320, 0), (256, 160, 0), (256, 256, 0)]
     argv = sys.argv[1:]
+    splits = 1
+    if argv and argv[0].startswith("--splits="):      # split-K factor of every launch (blockIdx.y slices; stamps per (slice, tile))
+        splits = int(argv.pop(0)[9:])
     if argv and argv[0].startswith("--tiles="):      # e.g. --tiles=128x160x4,256x128
         tiles = [tuple((list(map(int, t_.split("x"))) + [0])[:3]) for t_ in argv.pop(0)[8:].split(",")]
     only = argv or ["l0 KC", "l0 qkv", "l0 geglu", "l0 conv3x3 resid"]
@@ -54,12 +57,12 @@ def main():
                 continue
             trace = torch.zeros(8192 * 8, device=dev, dtype=torch.int64)
             for i in range(4):
-                launch(sets[i], tm, tn, 1, stg)       # warm
+                launch(sets[i], tm, tn, splits, stg)       # warm
             torch.cuda.synchronize()
             lib.lr_gemm_set_trace(trace.data_ptr())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(sets[4], tm, tn, 1, stg)
+            launch(sets[4], tm, tn, splits, stg)
             e1.record()
             torch.cuda.synchronize()
             lib.lr_gemm_set_trace(None)
