@@ -199,6 +199,12 @@ typedef struct lr_gemm_args {
    * stride 1, no upsample, no GEGLU / LayerNorm fold / per-sample weights: anything else LR_E_UNSUPPORTED.  resid / rowvec / statistics
    * outputs work as without it. */
   const lr_half* skip1; const lr_half* skip2; int32_t Cs1, Cs2;
+  /* splitk_mode (ABI 23): 0 = the split-K partials are reduced by a second launch (fixed order); 1 = in-launch reduce where the plan
+   * allows it (8-wave instances with 160- / 320-column tiles, tiles x splits <= 256 so that every K-slice block of the grid is
+   * resident at once): every slice block publishes its partial tile write-through, waits for its tile's other slices on an
+   * agent-scope counter (bounded spin) and reduces its share of the tile's rows in slice order with the full epilogue -- still
+   * deterministic, no second launch.  Plans that do not qualify fall back to mode 0 silently. */
+  int32_t splitk_mode;
 } lr_gemm_args;
 /* row tiles per sample of gn_group_out for this call, 0 if the plan cannot produce per-group sums */
 int lr_gemm_gn_group_chunks(const lr_gemm_args* args);
@@ -212,6 +218,10 @@ int lr_gemm_stats_parts(const lr_gemm_args* args);
 /* bytes of workspace lr_gemm_conv_f16 would like for this problem (0 if it will not split) */
 int64_t lr_gemm_workspace_bytes(const lr_gemm_args* args);
 int lr_gemm_conv_f16(const lr_gemm_args* args, lr_stream_t s);
+/* number of bounded-spin timeouts of the in-launch split-K reduce since the library was loaded (0 in a healthy run; synchronises
+ * the device; -1 on a runtime error).  A timeout means a K-slice block did not see its tile's other slices arrive: wrong results
+ * for that launch instead of a hang. */
+int lr_gemm_splitk_timeouts(void);
 
 /* ---- fused scaled-dot-product attention (flash-style, d_head = 64) ---------------------------------------------
  * replaces: xformers.ops.memory_efficient_attention (attention.py:236) == softmax(q k^T * d^-0.5) v of the vanilla

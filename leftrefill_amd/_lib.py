@@ -43,6 +43,7 @@ class GemmArgs(ctypes.Structure):
         ("wt_bstride", ctypes.c_int32), ("bias_bstride", ctypes.c_int32),
         ("wt_pm", ctypes.c_int32),
         ("skip1", c_void_p), ("skip2", c_void_p), ("Cs1", ctypes.c_int32), ("Cs2", ctypes.c_int32),
+        ("splitk_mode", ctypes.c_int32),
     ]
 
 
@@ -126,6 +127,7 @@ SIGNATURES = {
     "lr_ffn_block_f16": [ctypes.POINTER(FfnArgs), c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_row_copy": [c_void_p, c_int, c_void_p],
+    "lr_gemm_splitk_timeouts": [],
     "lr_mv_scatter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_ddim_cfg_step": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                          c_float, c_float, c_void_p],

@@ -260,6 +260,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
     __builtin_amdgcn_s_barrier();
     gn_group_reduce<BN, WMW, 256>(P, gsl, tile * 256, n0, t);
   }
+  if (P.sk_cnt != nullptr && P.splits > 1)      // in-launch split-K reduce: sub-block j = two 16-pixel line segments of the tile
+    sk_fused_tail<T, BN>(P, tile * P.ntiles_n + tile_n, 8,
+                         [&](const int j, const int r) { return m_org + (2 * j + (r >> 4)) * P.W + (r & 15); },
+                         [&](const int j) { return tile * 8 + j; }, [&](const int j) { return tile * 256 + 32 * j; }, n0,
+                         reinterpret_cast<float*>(smem), t);
   LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -293,4 +298,10 @@ int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);
   return LR_E_UNSUPPORTED;
+}
+
+unsigned lr_halo_sk_timeouts() {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(lr_sk_error), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
+  return v;
 }

@@ -46,6 +46,9 @@ struct GemmParams {
   // Stride 1, no upsample; the main part may itself be pointwise (taps == 1): out = W_a [p1 | p2] + W_s [p3 | p4].
   const f16* p3; const f16* p4; int C3, C4;
   int bf16;   // 16-bit type of activations / weights / outputs: 0 = fp16, 1 = bf16
+  // in-launch split-K reduce (lr_gemm_args.splitk_mode == 1): per-tile arrival counters (zero on entry, left zero); NULL = the partials
+  // are reduced by splitk_reduce_kernel in a second launch
+  unsigned* sk_cnt;
 #ifdef LR_GEMM_STAGGER
   int stagger;   // developer build only: shader-clock cycles the SECOND co-resident block of a CU waits before it starts (env LR_GEMM_STAGGER)
 #endif
@@ -160,6 +163,8 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
   const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc(P.rowvec ? (const void*)P.rowvec : (const void*)P.out,
                                                   (P.rowvec && fin) ? ((size_t)((P.M - 1) / P.rows_per_batch) * P.ld_rowvec + N_out) * 2 : 0);
   const __amdgpu_buffer_rsrc_t rsO = uniform_rsrc(P.out, fin ? ((size_t)(P.M - 1) * P.ld_out + N_out) * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rsWS = uniform_rsrc(P.sk_cnt ? (const void*)P.ws : (const void*)P.out,
+                                                   P.sk_cnt ? (size_t)P.splits * P.M * P.N * 4 : 0);
   // one register array serves both kinds of output statistics (a GEMM feeds a LayerNorm or a GroupNorm, never both):
   // row mode (P.st_out): s1[i] = sg[i], s2[i] = sg[SGH + i];  channel mode (P.gs_out): g1[q] = sg[q], g2[q] = sg[SGH + q]
   constexpr int SGH = TM > 8 ? TM : 8;
@@ -291,8 +296,14 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     if (!fin) {   // raw fp32 partial; bias / row vector / residual are applied by splitk_reduce_kernel
       if (ok) {
         float* dst = P.ws + ((size_t)blockIdx.y * P.M + m) * P.N + n;
-        *reinterpret_cast<f32x4*>(dst) = a;
-        *reinterpret_cast<f32x4*>(dst + 4) = b;
+        if (P.sk_cnt) {      // read by OTHER blocks of this launch: write-through (sc1) stores, no release fence needed (guide G16, R1)
+          const unsigned off = (unsigned)((((size_t)blockIdx.y * P.M + m) * P.N + n) * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rsWS, off, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rsWS, off + 16, 0, 16);
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = a;
+          *reinterpret_cast<f32x4*>(dst + 4) = b;
+        }
       }
       return;
     }
@@ -447,5 +458,155 @@ static inline void lr_udiv_magic(unsigned d, unsigned* mul, unsigned* sh) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// =====================================================================================================================
+// In-launch split-K reduce (lr_gemm_args.splitk_mode = 1).  Every K-slice block of an output tile writes its fp32
+// partial tile with write-through stores, arrives on the tile's counter, waits (bounded) until all `splits` slices have arrived and
+// then reduces ITS SHARE of the tile -- 32-row sub-blocks j = slice, slice + splits, ... -- summing the slices in the fixed order
+// 0 .. splits-1 and running the epilogue splitk_reduce_kernel would run (bias, row vector, GELU, residual, 16-bit store, the
+// consumer GroupNorm's statistics in the same layouts): deterministic, no second launch, the partials are read back from L2 /
+// Infinity Cache.  Protocol per MI355X guide G16: payload sc1 stores, every storing wave drains vmcnt, ONE relaxed agent-scope
+// counter per tile, ONE relaxed poll loop (one lane, s_sleep), ONE agent acquire, then plain loads.  The blocks of a tile spin on
+// each other, so the host only selects this mode when the whole grid is resident at once (tiles x splits <= CUs, one block per
+// CU for these kernels); the spin is bounded all the same (lr_sk_error counts timeouts; results are then wrong, not hung).
+// The counter is self-resetting: the slices arrive a second time after their share, the last one stores 0.
+// =====================================================================================================================
+static __device__ unsigned lr_sk_error = 0;
+
+// one 32-row x 160-column block: sum of the partials + epilogue + statistics.  >= 320 threads; red: >= 16 * 336 floats of LDS.
+template <typename T, typename RowFn>
+__device__ __forceinline__ void sk_reduce_block(const GemmParams& P, RowFn row_m, const int rb, const int mbv, const int nbase,
+                                                float* red, const int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int LD = 16 * 20 + 16;
+  const int cg = tid % 20, rr = tid / 20;      // (row of the 16-row pass, 8-channel group); tid < 320 active
+  const bool act = tid < 320;
+  const bool stats = P.gs_out != nullptr || P.gp_out != nullptr;
+  float ssum = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int m = act ? row_m(pass * 16 + rr) : -1;
+    const int n = nbase + cg * 8;
+    const bool ok = act && m >= 0 && m < P.M && n < P.N;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    if (ok) {
+      const float* src = P.ws + (size_t)m * P.N + n;
+      const size_t slice = (size_t)P.M * P.N;
+      int sidx = 0;
+      for (; sidx + 4 <= P.splits; sidx += 4) {      // four slices in flight, summed in slice order
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a[k] = *reinterpret_cast<const f32x4*>(src + (sidx + k) * slice);
+          b[k] = *reinterpret_cast<const f32x4*>(src + (sidx + k) * slice + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[0] += a[k][0]; v[1] += a[k][1]; v[2] += a[k][2]; v[3] += a[k][3];
+          v[4] += b[k][0]; v[5] += b[k][1]; v[6] += b[k][2]; v[7] += b[k][3];
+        }
+      }
+      for (; sidx < P.splits; ++sidx) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + sidx * slice), b = *reinterpret_cast<const f32x4*>(src + sidx * slice + 4);
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+      }
+      if (P.bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += P.bias[n + i];
+      }
+      if (P.rowvec) {
+        float e[8];
+        lr_unpack8<T>(*reinterpret_cast<const uint4*>(P.rowvec + (size_t)(m / P.rows_per_batch) * P.ld_rowvec + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      if (P.gelu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lr_gelu_erf(v[i]);
+      }
+      if (P.resid) {
+        float e[8];
+        lr_unpack8<T>(*reinterpret_cast<const uint4*>(P.resid + (size_t)m * P.ld_resid + n), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += e[i];
+      }
+      const uint4 pk = lr_pack8<T>(v);
+      *reinterpret_cast<uint4*>(P.out + (size_t)m * P.ld_out + n) = pk;
+      if (stats) lr_unpack8<T>(pk, v);       // statistics of what the consumer will read
+    }
+    if (stats) {      // block-uniform
+      if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = ok ? v[i] : 0.f;
+          red[(2 * i) * LD + rr * 20 + cg] = x; red[(2 * i + 1) * LD + rr * 20 + cg] = x * x;
+        }
+      }
+      __syncthreads();
+      if (act) {      // thread (pr = rr, cg): value pr of channel group cg, summed over the pass's 16 rows in a fixed order
+#pragma unroll 8
+        for (int k = 0; k < 16; ++k) ssum += red[rr * LD + k * 20 + cg];
+      }
+      __syncthreads();
+    }
+  }
+  if (stats) {
+    const int pr = rr;
+    const int nn = nbase + cg * 8;
+    if (act && nn < P.N && P.gs_store) P.gs_out[((size_t)rb * P.N + nn) * 2 + pr] = ssum;      // [row block][N][2], (sum, sumsq) interleaved
+    if (P.gp_out) {      // per-group sums of the block's 160 channels over its 32 rows
+      if (act) red[(pr & 1) * LD + cg * 8 + (pr >> 1)] = ssum;
+      __syncthreads();
+      const int gcg = P.gp_cg;
+      if (tid < 2 * (160 / gcg)) {
+        const int gl = tid >> 1, j = tid & 1;
+        const int g = nbase / gcg + gl;
+        if (g < 32) {
+          float a = 0.f;
+          for (int c = 0; c < gcg; ++c) a += red[j * LD + gl * gcg + c];
+          const int smp = mbv / P.gp_hw, chunk = (mbv - smp * P.gp_hw) / 32;
+          P.gp_out[(((size_t)smp * P.gp_chunks + chunk) * 32 + g) * 2 + j] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#endif
+}
+
+// tile_id: index of the output tile's counter; nsub: 32-row sub-blocks of the tile; row_fn(j, r) -> m of row r of sub-block j (or -1);
+// rb_fn(j) -> statistics row-block index; mbv_fn(j) -> first (virtual linear) row of sub-block j; BN_: tile width (multiple of 160)
+template <typename T, int BN_, typename RowFn, typename RbFn, typename MbvFn>
+__device__ __forceinline__ void sk_fused_tail(const GemmParams& P, const int tile_id, const int nsub, RowFn row_fn, RbFn rb_fn, MbvFn mbv_fn,
+                                              const int n0, float* red, const int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(BN_ % 160 == 0, "the reduce block is 160 columns wide");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+  __syncthreads();
+  unsigned* cnt = P.sk_cnt + tile_id;
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P.splits) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { __hip_atomic_fetch_add(&lr_sk_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  for (int j = blockIdx.y; j < nsub; j += P.splits) {
+#pragma unroll
+    for (int h = 0; h < BN_ / 160; ++h)
+      sk_reduce_block<T>(P, [&](const int r) { return row_fn(j, r); }, rb_fn(j), mbv_fn(j), n0 + h * 160, red, tid);
+  }
+  __syncthreads();
+  if (tid == 0) {      // second arrival: the last slice to finish its share re-arms the counter for the next launch
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 2u * (unsigned)P.splits - 1u) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+}
+
 // conv_halo.hip: the LR_PIPE_HALO instances (3x3 stride-1 conv with an LDS-resident 18 x 18 pixel patch); tile_n = 160 | 320
 int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st);
+unsigned lr_halo_sk_timeouts();      // conv_halo.hip's copy of lr_sk_error (synchronises the device)

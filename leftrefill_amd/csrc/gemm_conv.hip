@@ -547,6 +547,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
         gn_group_reduce<BN, WMW, BM2>(P, gsl, m0, n0, t);
       }
     }
+    if constexpr (MODE != 1 && BN % 160 == 0) {
+      if (P.sk_cnt != nullptr && P.splits > 1)      // in-launch split-K reduce (gemm_common.h): this slice's share of the tile
+        sk_fused_tail<T, BN>(P, tile_m * P.ntiles_n + tile_n, BM2 / 32,
+                             [&](const int j, const int r) { return m0 + 32 * j + r; },
+                             [&](const int j) { return (m0 >> 5) + j; }, [&](const int j) { return m0 + 32 * j; }, n0,
+                             reinterpret_cast<float*>(smem), t);
+    }
     LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -867,6 +874,31 @@ extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
   return splits > 1 ? (int64_t)splits * M * a->N * (int64_t)sizeof(float) : 0;
 }
 
+// Arrival counters of the in-launch split-K reduce: 16 slots x 2048 tiles, zero at module load and left zero by every launch
+// (self-resetting protocol, gemm_common.h).  Consecutive launches rotate through the slots, so two launches that overlap on the
+// device (graph branches, other streams) do not share counters unless 16 of them are in flight at once.
+static __device__ unsigned lr_sk_counters[16][2048];
+static unsigned* sk_counter_slot() {
+  static unsigned* base[64] = {nullptr};
+  static unsigned next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  dev &= 63;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(lr_sk_counters)) != hipSuccess) return nullptr;
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev] + (size_t)((next++) & 15) * 2048;
+}
+
+extern "C" int lr_gemm_splitk_timeouts(void) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(lr_sk_error), sizeof(v)) != hipSuccess) return -1;
+  const unsigned h = lr_halo_sk_timeouts();
+  return h == 0xFFFFFFFFu ? -1 : (int)(v + h);
+}
+
 extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (!a || !a->p1 || !a->wt || !a->out) return LR_E_ARG;
   GemmParams P;
@@ -939,6 +971,8 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   }
   P.splits = splits;
   P.ws = a->workspace;
+  P.sk_cnt = nullptr;
+  if (a->splitk_mode != 0 && a->splitk_mode != 1) return LR_E_ARG;
   // LayerNorm fold (pointwise, single source, K = normalised width) and per-row output statistics
   P.ln_part = a->ln_stats; P.ln_cs = a->ln_colsum; P.ln_parts = a->ln_parts; P.ln_eps = a->ln_eps;
   P.ln_invc = 1.0f / (float)P.K;
@@ -981,10 +1015,16 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
   if (a->pipe != 0 && a->pipe != choose_stages(tm, tn, a->pipe)) return LR_E_UNSUPPORTED;
   const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
+  // in-launch split-K reduce: the 8-wave instances with 160- / 320-column tiles, the whole grid resident at once (one block per CU)
+  if (P.splits > 1 && a->splitk_mode == 1 && mode != 1 && (tn == 160 || tn == 320) && (tm == 256 || deep || a->pipe == LR_PIPE_HALO)) {
+    const int64_t tiles = (int64_t)((P.M + tm - 1) / tm) * ((P.N + tn - 1) / tn);
+    if (tiles * P.splits <= 256 && tiles <= 2048 && (int64_t)P.splits * P.M * P.N * 4 < lim && P.N % 8 == 0)
+      P.sk_cnt = sk_counter_slot();
+  }
   if (a->pipe == LR_PIPE_HALO) {      // 3x3 stride-1 conv with the input patch resident in LDS (conv_halo.hip)
     if (mode != 0 || a->asym) return LR_E_UNSUPPORTED;
     rc = lr_launch_conv_halo(P, tn, st);
-    if (rc || P.splits == 1) return rc;
+    if (rc || P.splits == 1 || P.sk_cnt) return rc;
     return launch_reduce(P, st);
   }
   if (mode == 0) {
@@ -1015,6 +1055,6 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
     else if (tm == 256 && tn == 128) rc = launch_gemm256<128, 4, 3, 2>(P, st);
     else return LR_E_UNSUPPORTED;
   }
-  if (rc || P.splits == 1) return rc;
+  if (rc || P.splits == 1 || P.sk_cnt) return rc;
   return launch_reduce(P, st);
 }

@@ -34,6 +34,9 @@ TILE_TABLE_PATH = os.environ.get("LEFTREFILL_TILE_TABLE_PATH",      # (developer
                                  os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json"))
 _tile_cache = None
 PLAN_LOG = os.environ.get("LEFTREFILL_PLAN_LOG", "0") == "1"
+# lr_gemm_args.splitk_mode: 1 = split-K partials reduced inside the GEMM launch where the plan allows it (every K-slice block resident
+# at once), 0 = by the separate fixed-order reduce launch
+SPLITK_MODE = int(os.environ.get("LEFTREFILL_SPLITK_MODE", "0"))
 _untabulated = set()
 
 
@@ -321,6 +324,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     a.wt_bstride, a.bias_bstride = (Nw * Kw, Nw if bias is not None else 0) if per_sample else (0, 0)
     a.wt_pm = int(bool(wt_pm))
     a.skip1, a.skip2, a.Cs1, a.Cs2 = (_p(skip[0]), _p(skip[1]), Cs1, Cs2) if skip is not None else (0, 0, 0, 0)
+    a.splitk_mode = SPLITK_MODE
     assert wt.dtype == x1.dtype, (wt.dtype, x1.dtype)
     a.dtype = int(x1.dtype == torch.bfloat16)      # LR_DTYPE_F16 | LR_DTYPE_BF16
     if ln is not None:

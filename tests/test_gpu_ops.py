@@ -367,6 +367,63 @@ def test_conv_split_k():
     assert torch.equal(ops.gemm_conv(x, w, B=1, H=1, W=256, taps=1, splits=5), ys[2]), "split-K must be deterministic"
 
 
+@pytest.mark.parametrize("tile", [(256, 160), (256, 320), (128, 160, 4), (256, 160, 8), (256, 320, 8)], ids=lambda t_: "x".join(map(str, t_)))
+def test_splitk_in_launch_reduce(tile, monkeypatch):
+    """lr_gemm_args.splitk_mode = 1: the K-slice blocks of a tile reduce the partials inside the GEMM launch (agent-scope counter,
+    write-through partials, every slice reduces its share of the rows in slice order) -- the 16-bit output is bit-identical to the
+    separate fixed-order reduce launch, the GroupNorm statistics describe the stored tensor, repeated launches stay identical (the
+    counters re-arm themselves), no spin ever times out; plans whose grid would not be resident at once fall back silently."""
+    from leftrefill_amd import _lib, ops, packing
+    d = dev()
+    N, H, W, Cin, Cout = 8, 8, 16, 1280, 640                  # M = 1024 rows (the 8 x 16 level), K = 11520
+    name = "skf." + "x".join(map(str, tile))
+    x = h16(G.T(name + ".x", (N, Cin, H, W)) * 0.5 + 0.1)
+    w = h16(torch.from_numpy(weights.fill_like(name + ".w", (Cout, Cin, 3, 3))))
+    b = torch.from_numpy(weights.fill_like(name + ".b", (Cout,))) + 0.3
+    rs = h16(G.T(name + ".rs", (N, Cout, H, W)))
+    rv = h16(G.T(name + ".rv", (N, Cout)))
+    wp, bp = packing.pack_conv(w, cin_pad=Cin).to(d), packing.pack_bias(b).to(d)
+    kw = dict(B=N, H=H, W=W, taps=9, bias=bp, resid=to_tok(rs), rowvec=rv.half().to(d), want_gn_stats=True, **tile_kw(tile))
+    ref = F.conv2d(x, w, b, padding=1) + rs + rv[:, :, None, None]
+    lib = _lib.load()
+    for splits in (2, 4, 5, 8):
+        monkeypatch.setattr(ops, "SPLITK_MODE", 0)
+        y0, gs0 = ops.gemm_conv(to_tok(x), wp, splits=splits, **kw)
+        monkeypatch.setattr(ops, "SPLITK_MODE", 1)
+        ys = [ops.gemm_conv(to_tok(x), wp, splits=splits, **kw) for _ in range(6)]
+        y1, gs1 = ys[0]
+        report(f"in-launch split-K {tile} s{splits}", from_tok(y1, N, H, W), ref)
+        assert torch.equal(y1, y0), "the in-launch reduce sums the slices in the same order as the reduce launch"
+        assert all(torch.equal(y_, y1) and torch.equal(g_[0], gs1[0]) for y_, g_ in ys[1:]), "reruns (self-resetting counters)"
+        part, R, gp, chunks = gs1
+        assert R == 32
+        yf = y1.float()
+        if len(tile) > 2 and tile[2] == 8:      # halo tiles: a 32-row statistics block = two 16-pixel line segments of a 16 x 16 tile (pairs of samples here)
+            yt = yf.reshape(N // 2, 16, W // 16, 16, Cout).permute(0, 2, 1, 3, 4).reshape(-1, 32, Cout)
+        else:
+            yt = yf.reshape(-1, 32, Cout)
+        assert torch.allclose(part[..., 0], yt.sum(1), rtol=1e-5, atol=5e-3)
+        assert torch.allclose(part[..., 1], (yt * yt).sum(1), rtol=1e-5, atol=5e-3)
+        if gp is not None:
+            tot = y1.double().reshape(N, H * W, 32, Cout // 32)
+            assert torch.allclose(gp[..., 0].double().sum(1), tot.sum((1, 3)), rtol=1e-5, atol=2e-2)
+            assert torch.allclose(gp[..., 1].double().sum(1), (tot * tot).sum((1, 3)), rtol=1e-5, atol=2e-2)
+            gam = 1.0 + 0.3 * G.T(name + ".g", (Cout,))
+            bet = 0.2 * G.T(name + ".be", (Cout,))
+            out = ops.group_norm_groups(y1, N, H * W, gam.to(d), bet.to(d), 1e-5, True, gp, chunks)
+            report(f"in-launch split-K gn(groups) {tile} s{splits}", from_tok(out, N, H, W),
+                   F.silu(F.group_norm(from_tok(y1, N, H, W), 32, gam, bet, 1e-5)))
+        assert lib.lr_gemm_splitk_timeouts() == 0
+    # a grid that is not resident at once (tiles x splits > 256) takes the reduce launch: same bits, nothing to wait for
+    xb = h16(G.T(name + ".xb", (256, 256, 8, 16)))
+    wb = packing.pack_conv(h16(torch.from_numpy(weights.fill_like(name + ".wb", (320, 256, 3, 3)))), cin_pad=256).to(d)
+    monkeypatch.setattr(ops, "SPLITK_MODE", 0)
+    ya = ops.gemm_conv(to_tok(xb), wb, B=256, H=8, W=16, taps=9, splits=2, **tile_kw(tile))
+    monkeypatch.setattr(ops, "SPLITK_MODE", 1)
+    assert torch.equal(ops.gemm_conv(to_tok(xb), wb, B=256, H=8, W=16, taps=9, splits=2, **tile_kw(tile)), ya)
+    assert lib.lr_gemm_splitk_timeouts() == 0
+
+
 def test_conv_golden_cases(golden):
     """The reference-generated operator goldens (G3) for the conv family."""
     from leftrefill_amd import ops, packing
