@@ -17,7 +17,9 @@ from collections import defaultdict
 
 def family(name):
     # (rocprofv3 reports mangled names for templates: ILi256ELi8ELi320ELi2ELi2E... = <256, 8, 320, 2, 2, ...>)
-    for mangled, label in (("gemm_conv_pipe_kernelILi256ELi8ELi320ELi2ELi2ELi0", "gemm_conv_pipe_kernel<256,8,320,2,2> (wave tile 128x80)"),
+    for mangled, label in (("conv_halo_kernelILi320", "conv_halo_kernel<320,2,2> (halo-tile 3x3 conv, wave tile 8 lines x 80)"),
+                           ("conv_halo_kernelILi160", "conv_halo_kernel<160,4,3> (halo-tile 3x3 conv, wave tile 4 lines x 80)"),
+                           ("gemm_conv_pipe_kernelILi256ELi8ELi320ELi2ELi2ELi0", "gemm_conv_pipe_kernel<256,8,320,2,2> (wave tile 128x80)"),
                            ("gemm_conv_pipe_kernelILi256ELi8ELi320ELi4ELi2ELi1", "gemm_conv_pipe_kernel<256,8,320,4,2,GEGLU>"),
                            ("gemm_conv_pipe_kernelILi256ELi8ELi256", "gemm_conv_pipe_kernel<256,8,256,2,2>"),
                            ("gemm_conv_pipe_kernelILi256ELi8ELi160", "gemm_conv_pipe_kernel<256,8,160,4,3>"),
