@@ -469,7 +469,7 @@ static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, in
   int R = 256 / nOct;
   if (R < 1) R = 1;
   const int threads = nOct * R;
-  static const int base_apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 512);
+  static const int base_apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 2048);      // round 5: 512 -> 2048 (tools/bench_gn_apply.py: 654 -> 626 us per step, same bits)
   const long long want_blocks = ((long long)N * HW * C * 2) >> 18;     // one block per 256 KB for very large tensors
   const long long apply_blocks = want_blocks > base_apply_blocks ? want_blocks : base_apply_blocks;
   ppb = (int)(((long long)N * HW + apply_blocks - 1) / apply_blocks);
