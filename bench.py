@@ -885,7 +885,7 @@ def main():
                                 f"{tr['write_bytes_per_launch'] / 1e6:.1f} MB per launch over {tr['fetch_launches']} launches")
             else:
                 traffic_note = "measurement failed: " + str(err)
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> / gemm_conv_pipe_kernel<BM,NW,BN,..> (implicit-GEMM conv3x3 / 1x1 / linear family, tile picked per shape)",
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel<BN> / gemm_conv_pipe_kernel<BM,NW,BN,..> / conv_halo_kernel<BN,..> (implicit-GEMM conv3x3 / 1x1 / linear family incl. the halo-tile 3x3 conv, instance picked per shape by the tile table)",
                            "achieved": g["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": g["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
