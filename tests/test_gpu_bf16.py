@@ -79,7 +79,7 @@ def test_groupnorm_layernorm_bf16(C1, C2, N, H, W, silu):
     report(f"layernorm {C}", yl, F.layer_norm(xl, (C,), g, b, 1e-5))
 
 
-def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, rowvec=False, resid=False, tile_m=0, tile_n=0, splits=0):
+def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, rowvec=False, resid=False, tile_m=0, tile_n=0, splits=0, pipe=0):
     from leftrefill_amd import ops, packing
     d = dev()
     Ct = Cin + C2
@@ -102,7 +102,7 @@ def _conv_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, rowvec=Fa
     y = ops.gemm_conv(to_tok(x[:, :Cin]), wp, B=N, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up,
                       x2=to_tok(x[:, Cin:]) if C2 else None, bias=packing.pack_bias(b).to(d),
                       rowvec=rv.to(BF).to(d) if rowvec else None, resid=to_tok(rs) if resid else None,
-                      tile_m=tile_m, tile_n=tile_n, splits=splits)
+                      tile_m=tile_m, tile_n=tile_n, splits=splits, pipe=pipe)
     assert y.dtype == BF
     report(name, from_tok(y[:, :Cout], N, H, W), ref)
 
@@ -116,6 +116,10 @@ def test_gemm_conv_bf16_variants():
     _conv_case("bf.up", 1, 640, 640, 8, 12, up=1)
     _conv_case("bf.out", 2, 320, 64, 8, 16)
     _conv_case("bf.splitk", 1, 1280, 1280, 8, 8, splits=4)
+    # the halo-tile conv (conv_halo.hip) in bf16: both instances, concat + row vector + residual, split-K, the two-sample tile of 8-line images
+    for tn in (160, 320):
+        _conv_case(f"bf.halo{tn}", 2, 320, 320, 32, 16, C2=320, rowvec=True, resid=True, tile_m=256, tile_n=tn, splits=1, pipe=8)
+        _conv_case(f"bf.halo{tn}_splitk", 4, 1280, 640, 8, 16, resid=True, tile_m=256, tile_n=tn, splits=3, pipe=8)
 
 
 @pytest.mark.parametrize("tm,tn", [(128, 64), (128, 128), (128, 160), (256, 128), (256, 160), (256, 256), (256, 320)])
