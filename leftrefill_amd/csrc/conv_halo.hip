@@ -295,6 +295,7 @@ int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
   if (P.taps != 9 || P.stride != 1 || P.up || P.zins || P.pad != 1 || P.c16 || P.splits < 1 || P.geglu || P.gelu || P.ln_part ||
       P.wt_bstride || P.st_out || ((P.H & 15) && !(P.H == 8 && P.M % 256 == 0)) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
     return LR_E_UNSUPPORTED;
+  if ((long long)P.M >= (1ll << 28)) return LR_E_UNSUPPORTED;      // the patch loader packs (pixel index | chunk << 28) into one register
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);
   return LR_E_UNSUPPORTED;

@@ -17,6 +17,7 @@
 //   consecutive output channels of ONE output row: the fp32 tile goes to LDS with 16-byte writes, and the epilogue
 //   (bias, per-sample time-embedding row, residual, GEGLU gate) streams it out as whole fp16 lines.
 #include "gemm_common.h"
+#include <atomic>
 
 #ifdef LR_GEMM_TRACE
 static unsigned long long* g_trace = nullptr;
@@ -880,7 +881,7 @@ extern "C" int64_t lr_gemm_workspace_bytes(const lr_gemm_args* a) {
 static __device__ unsigned lr_sk_counters[16][2048];
 static unsigned* sk_counter_slot() {
   static unsigned* base[64] = {nullptr};
-  static unsigned next = 0;
+  static std::atomic<unsigned> next{0};      // (host threads may launch concurrently)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   dev &= 63;
@@ -889,7 +890,7 @@ static unsigned* sk_counter_slot() {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(lr_sk_counters)) != hipSuccess) return nullptr;
     base[dev] = (unsigned*)p;
   }
-  return base[dev] + (size_t)((next++) & 15) * 2048;
+  return base[dev] + (size_t)(next.fetch_add(1, std::memory_order_relaxed) & 15) * 2048;
 }
 
 extern "C" int lr_gemm_splitk_timeouts(void) {
