@@ -72,7 +72,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   const int q8 = P.nblocks >> 3, r8 = P.nblocks & 7;
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   [[maybe_unused]] const int lr_trace_tile = bid;
-  const int tile_n = bid % P.ntiles_n, tile = bid / P.ntiles_n;      // tile: 16 x 16 pixel tiles numbered sample-major, line-major
+  int tile_n, tile;      // tile: 16 x 16 pixel tiles numbered sample-major, line-major
+  tile_order(P, bid, tile, tile_n);
   // 8-line images (the 8 x 16 level): a tile is lines 0..7 of TWO consecutive samples -- in token order exactly a 16-line image of
   // the pair, so the output side needs nothing; the patch holds the two samples' 10 x 18 halo segments one after the other
   // (zero rows between them: each segment has its own padding) and a wave's lines lie in one segment
@@ -279,6 +280,7 @@ static int launch_halo_t(const GemmParams& P0, hipStream_t st) {
   P.ntiles_n = (P.N + BN - 1) / BN;
   P.ntiles_m = P.M / 256;
   P.m_fastest = 0;
+  // (the grouped tile order of gemm_conv_pipe_kernel was measured here too: no effect -- 4 column tiles at most, one round)
   P.nblocks = P.ntiles_n * P.ntiles_m;
   const size_t smem = (size_t)HALO_NQ * 1024 + NSTAGE * (size_t)BN * 128 + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static unsigned long long attr_done = 0;

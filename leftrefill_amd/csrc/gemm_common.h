@@ -64,11 +64,18 @@ struct GemmParams {
 #endif
 
 // Blocks are handed to XCDs in contiguous logical chunks (bijective remap of blockIdx).  Inside a chunk the order is
+//   grouped (m_fastest = G > 1): panels of G row tiles, m-fastest inside a panel (see launch_pipe_t);
 //   m-fastest: neighbours share the WEIGHT slice (BN x K) -- right when that slice is MBs (3x3 convs at 1280 channels:
 //              3.7 MB per N-tile, 29 MB in total, far beyond one XCD's 4 MB L2) ;
 //   n-fastest: neighbours share the activation rows -- right when the weights are small and fit L2 anyway.
 __device__ __forceinline__ void tile_order(const GemmParams& P, int bid, int& tile_m, int& tile_n) {
-  if (P.m_fastest) { tile_m = bid % P.ntiles_m; tile_n = bid / P.ntiles_m; }
+  if (P.m_fastest > 1) {      // grouped: panels of m_fastest consecutive row tiles, inside a panel m-fastest over all column tiles -- the ~32 tiles
+    // an XCD runs at once then share m_fastest x (32 / m_fastest) row / column slices instead of 2 x 16 (both operands fit its L2)
+    const int G = P.m_fastest, per = G * P.ntiles_n;
+    const int grp = bid / per, first = grp * G;
+    const int gsz = min(G, P.ntiles_m - first), r = bid - grp * per;
+    tile_m = first + r % gsz; tile_n = r / gsz;
+  } else if (P.m_fastest) { tile_m = bid % P.ntiles_m; tile_n = bid / P.ntiles_m; }
   else { tile_n = bid % P.ntiles_n; tile_m = bid / P.ntiles_n; }
 }
 

@@ -570,7 +570,21 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
   P.ntiles_n = (P.N + BN - 1) / BN;
   const int ntm = (P.M + BM2 - 1) / BM2;
   P.ntiles_m = ntm;
-  P.m_fastest = 0;   // measured on MI355X: n-fastest wins even for 3.7 MB weight slices (1038 vs 928 TFLOP/s)
+  // Tile order inside an XCD's contiguous range (round 5): panels of G row tiles, m-fastest inside a panel, so that the ~32 tiles an XCD
+  // runs at once (one 8-wave block per CU) are G x (32 / G) row / column slices instead of 2 x 16 (n-fastest) -- wide-N GEMMs whose
+  // CUs run several tiles back to back (GEGLU / qkv projections: 4 rounds) drift out of lockstep, and with n-fastest an XCD then streams
+  // the whole weight matrix per two row tiles.  Measured: 16384 x 5120 x 640 GEGLU 152 -> 140 us, 4096 x 10240 x 1280 129 -> 117 us,
+  // 16384 x 1920 x 640 74 -> 68 us, UNet step -0.25 ... -0.32 ms on three boxes (G = 8 / 16; G = 32: -0.07; plain m-fastest was
+  // measured slower in round 1: 928 vs 1038 TFLOP/s).  Pure scheduling: same tiles, same bits.  LR_GEMM_GROUP_M=0 restores n-fastest.
+  {
+    static const int g_env = getenv("LR_GEMM_GROUP_M") ? atoi(getenv("LR_GEMM_GROUP_M")) : -1;
+    static const int g_env2 = getenv("LR_GEMM_GROUP_M2") ? atoi(getenv("LR_GEMM_GROUP_M2")) : -1;      // developer knobs (wide / narrow N)
+    int G = 0;
+    if (P.ntiles_n > 1) G = P.ntiles_n >= 4 ? 8 : 16;
+    if (g_env >= 0 && P.ntiles_n >= 4) G = g_env;
+    if ((g_env2 >= 0 || g_env >= 0) && P.ntiles_n > 1 && P.ntiles_n < 4) G = g_env2 >= 0 ? g_env2 : g_env;
+    P.m_fastest = (G > 1 && ntm > 1) ? G : 0;
+  }
   P.nblocks = P.ntiles_n * ntm;
   // stages + (mean, rstd) rows + (bias, ln_colsum) columns
   const size_t smem = NSTAGE * (size_t)(BM2 + BN) * 128 + BM2 * 2 * sizeof(float) + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
