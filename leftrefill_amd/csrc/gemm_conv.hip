@@ -583,6 +583,8 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
     if (P.ntiles_n > 1) G = P.ntiles_n >= 4 ? 8 : 16;
     if (g_env >= 0 && P.ntiles_n >= 4) G = g_env;
     if ((g_env2 >= 0 || g_env >= 0) && P.ntiles_n > 1 && P.ntiles_n < 4) G = g_env2 >= 0 ? g_env2 : g_env;
+    static const int g_conv = getenv("LR_GEMM_GROUP_CONV") ? atoi(getenv("LR_GEMM_GROUP_CONV")) : 0;
+    if (P.taps != 1 && !g_conv) G = 0;      // 3x3 gathers re-read their rows per tap: column-tile neighbours on one XCD are worth more there (measured 0 ... +2 %)
     P.m_fastest = (G > 1 && ntm > 1) ? G : 0;
   }
   P.nblocks = P.ntiles_n * ntm;
