@@ -41,12 +41,17 @@ def main():
     ap.add_argument("--fresh", action="store_true", help="ignore the committed table (re-tune every shape)")
     ap.add_argument("--retune-conv", action="store_true",
                     help="re-time only the 3x3 stride-1 entries (all tile candidates incl. the halo-tile instances), keep the rest of the table")
+    ap.add_argument("--retune-pointwise", action="store_true",
+                    help="re-time only the taps = 1 entries (the grouped tile order of round 5 changed what multi-round pointwise plans cost), keep the rest")
     a = ap.parse_args()
     assert ops.AUTOTUNE
     if a.fresh:
         ops.tile_cache().clear()
     if a.retune_conv:
         for k in [k for k in ops.tile_cache() if k.split(",")[3:6] == ["9", "1", "0"]]:
+            del ops.tile_cache()[k]
+    if a.retune_pointwise:
+        for k in [k for k in ops.tile_cache() if k.split(",")[3] == "1"]:
             del ops.tile_cache()[k]
     device = torch.device("cuda:0")
     wl = a.workloads.split(",")
