@@ -38,6 +38,11 @@ PLAN_LOG = os.environ.get("LEFTREFILL_PLAN_LOG", "0") == "1"
 # at once), 0 = by the separate fixed-order reduce launch
 SPLITK_MODE = int(os.environ.get("LEFTREFILL_SPLITK_MODE", "0"))
 _untabulated = set()
+# developer hooks of tools/tune_in_step.py (None in the product): PLAN_TRIAL maps a table key to the (tile_m, tile_n, splits, pipe) to try
+# instead of the table's plan (splits 0 = the library's static choice for that tile; a plan the library refuses falls back to the table's);
+# LAUNCH_HOOK(key, phase, plan) is called right before (0) and after (1) the launch
+PLAN_TRIAL = None
+LAUNCH_HOOK = None
 
 
 # Plan GEMMs as if the batch were `scale` times larger (the shared prefix of a CFG batch runs on half the samples but must
@@ -353,6 +358,8 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)
             tile_cache()[key] = best
+        if best is not None and PLAN_TRIAL is not None and PLAN_TRIAL.get(key) is not None:
+            best = PLAN_TRIAL[key]
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
             a.pipe = best[3] if len(best) > 3 else 0
@@ -385,7 +392,20 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             a.gn_stats_out = _p(gstats[0])
             a.gn_group_out = _p(gp)
     ws = _workspace(lib, a, x1.device)
-    _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
+    if LAUNCH_HOOK is not None and tile_m == 0 and tile_n == 0 and splits == 0:
+        plan = (ctypes.c_int32 * 4)()
+        lib.lr_gemm_plan(a, plan)
+        LAUNCH_HOOK(key, 0, tuple(plan))
+        rc = lib.lr_gemm_conv_f16(a, st)
+        LAUNCH_HOOK(key, 1, rc)
+        if rc != 0 and PLAN_TRIAL is not None and PLAN_TRIAL.get(key) is not None:      # the trial plan is not one this call can take
+            PLAN_TRIAL[key] = None
+            return gemm_conv(x1, wt, B=B, H=H, W=W, Hs=Hs, Ws=Ws, taps=taps, stride=stride, up=up, asym=asym, x2=x2, bias=bias, rowvec=rowvec,
+                             resid=resid, geglu=geglu, gelu=gelu, out=out, ln=ln, want_stats=want_stats, want_gn_stats=want_gn_stats, gn_hw=gn_hw,
+                             per_sample=per_sample, wt_pm=wt_pm, skip=skip)
+        _lib.check(rc, "gemm_conv")
+    else:
+        _lib.check(lib.lr_gemm_conv_f16(a, st), "gemm_conv")
     if want_gn_stats:
         return out, gstats
     return (out, stats) if want_stats else out
