@@ -123,6 +123,19 @@ __device__ __forceinline__ void swap_rows16(f32x4& a, f32x4& b) {
 // MODE (compile time, keeps the unrolled epilogue small: the erf polynomial is only instantiated where it is used):
 //   0 plain | 1 GEGLU (value * gelu(gate)) | 2 erf-GELU of (acc + bias [+ rowvec]) before the residual
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Cache policy of the epilogue's output stores: sc1 (write-through).  MEASURED, whole UNet step, same box, alternating runs of builds that
+// differ in this constant only: sc1 -0.07 ... -0.21 ms in six pairs (mean -0.12); nt (2) +0.1 ms; nt + sc1 (18) +0.25 ms; training step
+// -0.07 / -0.10 ms; multi-view step unchanged within its run-to-run spread.  The same policy tried on the other large writers, one site at a
+// time: attention outputs +0.04 ms, gn_apply / fused blocks / split-K reduce outputs +-0.02, split-K partials +0.44 ms -- so only these
+// stores carry it.
+// WHY is not established.  The test was prompted by the guide's "boundary" row (a kernel that leaves B bytes dirty in the L2s pays ~B / 6 TB/s
+// at the kernel boundary), but no boundary gap or write-back counter was measured here, and the per-site results above do not follow from
+// that alone (attention leaves as many dirty bytes and did not gain; the partials result says the next launch does read producer data
+// from the L2s).  Treat the number as empirical; a kernel-trace of launch-to-launch gaps or a TCC write-back --pmc pass with 0 vs 16 would
+// decide it (not done).
+#ifndef LR_OUT_AUX
+#define LR_OUT_AUX 16
+#endif
 
 // Which 16-column tile of the block's EMITTED column space wave `wn` accumulates in its je-th tile column (TE per wave,
 // WNW waves along n).  Contiguous ranges, except TE = 5 (80-column wave tiles of the 160 / 320-wide blocks): 80 columns
@@ -308,7 +321,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rsWS, off, 0, 16);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rsWS, off + 16, 0, 16);
         } else {
-          *reinterpret_cast<f32x4*>(dst) = a;
+          *reinterpret_cast<f32x4*>(dst) = a;      // (plain stores: the reduce launch finds most of the partials in the L2s; written through: +0.44 ms per step)
           *reinterpret_cast<f32x4*>(dst + 4) = b;
         }
       }
@@ -341,7 +354,7 @@ __device__ __forceinline__ void epilogue_units(const GemmParams& P, f32x4 (&acc)
     }
     const uint4 pk = lr_pack8<T>(v);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rsO,
-                                           ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, 0);
+                                           ok ? (unsigned)(((size_t)m * P.ld_out + n) * 2) : OOB, 0, LR_OUT_AUX);
     if (gstat) {
       float f[8];
       lr_unpack8<T>(pk, f);
