@@ -128,11 +128,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // -0.07 / -0.10 ms; multi-view step unchanged within its run-to-run spread.  The same policy tried on the other large writers, one site at a
 // time: attention outputs +0.04 ms, gn_apply / fused blocks / split-K reduce outputs +-0.02, split-K partials +0.44 ms -- so only these
 // stores carry it.
-// WHY is not established.  The test was prompted by the guide's "boundary" row (a kernel that leaves B bytes dirty in the L2s pays ~B / 6 TB/s
-// at the kernel boundary), but no boundary gap or write-back counter was measured here, and the per-site results above do not follow from
-// that alone (attention leaves as many dirty bytes and did not gain; the partials result says the next launch does read producer data
-// from the L2s).  Treat the number as empirical; a kernel-trace of launch-to-launch gaps or a TCC write-back --pmc pass with 0 vs 16 would
-// decide it (not done).
+// What it changes, MEASURED (rocprofv3 --pmc WRITE_SIZE per dispatch, tools/pmc_write_probe.py; bench.py's roofline.traffic): with plain stores
+// a level-0 conv_halo<320> launch moves 43.5-54.5 MB (mean 51.5) out of the L2s for 41.9 MB of output + 1.4 MB of statistics; written
+// through it moves 43.3 MB, every launch.  GEMM family over the step: WRITE_SIZE 40.1 -> 31.7 MB per launch (-1.16 GB per UNet step), FETCH
+// unchanged.  So the plain stores wrote ~20 % of their bytes twice; why (half-filled 128-byte lines evicted and written again is a guess)
+// was not measured.  The hypothesis this experiment STARTED from -- output bytes left dirty and written back at the kernel boundary (the
+// guide's "boundary" row) -- made the opposite prediction (a plain-store conv showing LESS than its output in its own counter window, the
+// rest on its successor) and is not supported: own bytes >= output in both builds, the following gn_apply shows its own 41.9 MB in both.
 #ifndef LR_OUT_AUX
 #define LR_OUT_AUX 16
 #endif
