@@ -130,9 +130,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // stores carry it.
 // What it changes, MEASURED (rocprofv3 --pmc WRITE_SIZE per dispatch, tools/pmc_write_probe.py; bench.py's roofline.traffic): with plain stores
 // a level-0 conv_halo<320> launch moves 43.5-54.5 MB (mean 51.5) out of the L2s for 41.9 MB of output + 1.4 MB of statistics; written
-// through it moves 43.3 MB, every launch.  GEMM family over the step: WRITE_SIZE 40.1 -> 31.7 MB per launch (-1.16 GB per UNet step), FETCH
-// unchanged.  So the plain stores wrote ~20 % of their bytes twice; why (half-filled 128-byte lines evicted and written again is a guess)
-// was not measured.  The hypothesis this experiment STARTED from -- output bytes left dirty and written back at the kernel boundary (the
+// through it moves 43.3 MB, every launch.  GEMM family over the step (one box, tools/pmc_step.py after its selection fix): WRITE_SIZE 46.3 -> 40.8 MB per call (-0.76 GB per UNet step), FETCH
+// x2 127.1 -> 123.9 MB.  So a level-0 conv's plain stores wrote ~20 % of its bytes twice (12 % over the family, whose split-K calls write
+// partials either way); why (half-filled 128-byte lines evicted and written again is a guess) was not measured.  The hypothesis this experiment STARTED from -- output bytes left dirty and written back at the kernel boundary (the
 // guide's "boundary" row) -- made the opposite prediction (a plain-store conv showing LESS than its output in its own counter window, the
 // rest on its successor) and is not supported: own bytes >= output in both builds, the following gn_apply shows its own 41.9 MB in both.
 #ifndef LR_OUT_AUX

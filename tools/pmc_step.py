@@ -66,19 +66,44 @@ def _rows(d):
     return out
 
 
+FAMILY = ("gemm_conv", "conv_halo_kernel")      # the GEMM family of bench.py's roofline object (kernel-name substrings)
+
+
+def _family_groups(rows, counter):
+    """Counter value (bytes) per ops.gemm_conv CALL, in dispatch order: a family kernel plus the splitk_reduce launch that follows it.
+    (Until the middle of round 5 this selected by "gemm_conv" alone: the conv_halo launches fell out, their descriptors did not, and the
+    per-launch averages were taken over a set that reached back into the previous step -- see profiles/README.md, round-5 erratum.)"""
+    out = []
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        v = float(r["Counter_Value"]) * 1024.0
+        name = r["Kernel_Name"]
+        if any(k in name for k in FAMILY) and "splitk_reduce" not in name:
+            out.append(v)
+        elif "splitk_reduce" in name and out:
+            out[-1] += v
+    return out
+
+
 def reduce_(fetch_dir, write_dir, out_path, launches=194):
     res = {}
     per = {}
     for key, d, counter, corr in (("fetch", fetch_dir, "FETCH_SIZE", 2.0), ("write", write_dir, "WRITE_SIZE", 1.0)):
-        rows = [r for r in _rows(d) if "gemm_conv" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        last = rows[-launches:]
-        kib = sum(float(r["Counter_Value"]) for r in last)
-        res[key + "_bytes_per_launch"] = corr * kib * 1024.0 / len(last)
+        groups = _family_groups(_rows(d), counter)
+        # pmc_step.run makes two eager steps; the context K / V projections (gemm_conv calls outside the armed region) come on top, so the
+        # count is bounded, not exact -- the instrumented step is the TAIL of the process, and the per-shape check below (no kernel writes
+        # less than its output) is what proves the alignment
+        if not 2 * launches <= len(groups) <= 2 * launches + 64:
+            raise RuntimeError(f"{counter}: {len(groups)} GEMM-family calls in the trace for {launches} per step -- refusing to average a misaligned set")
+        last = groups[-launches:]
+        res[key + "_bytes_per_launch"] = corr * sum(last) / len(last)
         res[key + "_launches"] = len(last)
-        per[key] = [corr * float(r["Counter_Value"]) * 1024.0 for r in last]
+        per[key] = [corr * v for v in last]
     if os.path.exists("gpurun_out/pmc_descs.json"):
         descs = json.load(open("gpurun_out/pmc_descs.json"))
-        if len(descs) == len(per["fetch"]):
+        assert len(descs) == len(per["fetch"]), (len(descs), len(per["fetch"]))
+        if True:
             agg = {}
             for d, f, w in zip(descs, per["fetch"], per["write"]):
                 src_rows = d["M"] * (4 if d["stride"] == 2 else 1) / (4 if d["up"] else 1)
@@ -91,6 +116,9 @@ def reduce_(fetch_dir, write_dir, out_path, launches=194):
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
             res["per_shape"] = [dict(shape=k, n=a[0], fetch_mb=a[1] / a[0] / 1e6, alg_read_mb=a[2] / a[0] / 1e6,
                                      write_mb=a[3] / a[0] / 1e6, alg_write_mb=a[4] / a[0] / 1e6) for k, a in rows]
+            bad = [r for r in res["per_shape"] if r["write_mb"] < 0.9 * r["alg_write_mb"]]
+            if bad:      # a kernel cannot write less than its output: the alignment is wrong again
+                raise RuntimeError(f"per-shape write bytes below the output size: {bad[:3]}")
             for r in res["per_shape"][:30]:
                 print(f'{r["shape"]:38s} n={r["n"]:2d} fetch {r["fetch_mb"]:8.1f} MB (alg {r["alg_read_mb"]:7.1f})  '
                       f'write {r["write_mb"]:7.1f} (alg {r["alg_write_mb"]:7.1f})')
