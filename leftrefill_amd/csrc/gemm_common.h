@@ -89,8 +89,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // four consecutive channels of one output row per MFMA tile.  `v_permlane16_swap` of two tiles (A, B) exchanges the odd
 // 16-lane rows of A with the even rows of B, after which the lane owns EIGHT consecutive channels (16 bytes of fp16) of
 // tile (fq & 1 ? B : A): residual / per-sample row vector come in as one 16-byte load, the result leaves as one 16-byte
-// store, and a wave-wide store covers 16 rows x 64 contiguous bytes (tile pairs adjacent in n) -- L2 merges the two
-// halves of every 128-byte line.  An odd leftover tile column is paired along m instead.  Loads of the next unit are
+// store, and a wave-wide store covers 16 rows x 64 contiguous bytes (tile pairs adjacent in n); the other half of each 128-byte line
+// comes from a later unit (with plain stores ~20 % of a level-0 conv's bytes reached memory twice, see LR_OUT_AUX below).  An odd leftover tile column is paired along m instead.  Loads of the next unit are
 // independent of the current one, so the residual latency overlaps across units and across the block's waves.
 //   optional: LayerNorm fold (see GemmParams), per-row (sum, sumsq) of the rounded output for the NEXT LayerNorm.
 // =====================================================================================================================

@@ -586,6 +586,10 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
     static const int g_conv = getenv("LR_GEMM_GROUP_CONV") ? atoi(getenv("LR_GEMM_GROUP_CONV")) : 0;
     if (P.taps != 1 && !g_conv) G = 0;      // 3x3 gathers re-read their rows per tap: column-tile neighbours on one XCD are worth more there (measured 0 ... +2 %)
     P.m_fastest = (G > 1 && ntm > 1) ? G : 0;
+    // developer switch, default off (LR_GATHER_MFASTEST=1): split-K 3x3 gathers walk m-fastest.  Measured: fetch DOWN at 1024 rows
+    // (1024 x 1280 x 11520: 169 -> 96 MB) but UP at 4096 rows (378 -> 492 MB; this kernel re-gathers its rows per tap), step time unchanged.
+    static const int mf = getenv("LR_GATHER_MFASTEST") ? atoi(getenv("LR_GATHER_MFASTEST")) : 0;
+    if (mf && P.taps != 1 && P.splits > 1 && ntm > 1) P.m_fastest = 1;
   }
   P.nblocks = P.ntiles_n * ntm;
   // stages + (mean, rstd) rows + (bias, ln_colsum) columns
