@@ -38,4 +38,5 @@ __device__ __forceinline__ vec8<T> xa_pack(const f32x4& a, const f32x4& b) {
   for (int i = 0; i < 4; ++i) { r[i] = (T)a[i]; r[4 + i] = (T)b[i]; }
   return r;
 }
-
+// xattn_block640.hip: the C = 640 / 10-head instance of lr_xattn_block_f16 (64-row blocks, 4 waves); arguments already checked
+int lr_xattn640_launch(const lr_xattn_args* a, int bf16_, lr_stream_t s);

@@ -26,6 +26,7 @@
 // Epilogue: out^T + bias -> fp16 -> wave-private LDS rows -> whole 16-byte pieces: + residual (x, L2-hot), store, and the
 // per-row (sum, sumsq) of the rounded output for the LayerNorm folded into the GEGLU projection that follows.
 #include "chain_common.h"
+#include <type_traits>
 
 #define XA_C 320
 #define XA_HEADS 5
@@ -486,13 +487,19 @@ template <typename T>
 static int xattn_block_t(const lr_xattn_args* a, lr_stream_t s) {
   if (!a || !a->x || !a->wq || !a->bq || !a->k || !a->vt || !a->wo || !a->bo || !a->out) return LR_E_ARG;
   if (a->M <= 0 || a->HW <= 0 || a->Lc <= 0 || a->ldk <= 0) return LR_E_ARG;
-  if (a->C != XA_C || a->heads != XA_HEADS || a->Lc > 96) return LR_E_UNSUPPORTED;
-  if (a->M % XA_ROWS || a->HW % XA_ROWS || a->M % a->HW) return LR_E_UNSUPPORTED;     // a block stays inside one sample
+  const bool wide = a->C == 640 && a->heads == 10;      // level 1: xattn_block640.hip (64-row blocks)
+  if ((!wide && (a->C != XA_C || a->heads != XA_HEADS)) || a->Lc > 96) return LR_E_UNSUPPORTED;
+  if (!wide && (a->M % XA_ROWS || a->HW % XA_ROWS || a->M % a->HW)) return LR_E_UNSUPPORTED;     // a block stays inside one sample
   if (a->ldk % 8) return LR_E_ALIGN;
   if (((uintptr_t)a->x | (uintptr_t)a->wq | (uintptr_t)a->bq | (uintptr_t)a->k | (uintptr_t)a->vt | (uintptr_t)a->wo |
        (uintptr_t)a->bo | (uintptr_t)a->out) & 15)
     return LR_E_ALIGN;
   if (a->stats_out && ((uintptr_t)a->stats_out & 7)) return LR_E_ALIGN;
+  if (a->pre_a) {
+    if (!a->pre_w || !a->pre_b) return LR_E_ARG;
+    if (((uintptr_t)a->pre_a | (uintptr_t)a->pre_w | (uintptr_t)a->pre_b) & 15) return LR_E_ALIGN;
+  }
+  if (wide) return lr_xattn640_launch(a, std::is_same<T, bf16>::value ? 1 : 0, s);
   const int B = a->M / a->HW;
   const int64_t kb = (int64_t)B * a->Lc * a->ldk * 2, vb = (int64_t)B * XA_HEADS * 2 * 64 * 128;
   if (kb >= ((int64_t)1 << 31) || vb >= ((int64_t)1 << 31)) return LR_E_UNSUPPORTED;
@@ -507,10 +514,6 @@ static int xattn_block_t(const lr_xattn_args* a, lr_stream_t s) {
 #endif
   const size_t smem = 3 * XA_SLOT + 3 * XA_C * sizeof(float);
   const bool six = a->Lc > 80, pre = a->pre_a != nullptr;
-  if (pre) {
-    if (!a->pre_w || !a->pre_b) return LR_E_ARG;
-    if (((uintptr_t)a->pre_a | (uintptr_t)a->pre_w | (uintptr_t)a->pre_b) & 15) return LR_E_ALIGN;
-  }
   P.pre_a = a->pre_a; P.pre_w = a->pre_w; P.pre_b = a->pre_b;
   const void* fns[4] = {reinterpret_cast<const void*>(xattn_block_kernel<T, 5, false>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, false>),
                         reinterpret_cast<const void*>(xattn_block_kernel<T, 5, true>), reinterpret_cast<const void*>(xattn_block_kernel<T, 6, true>)};

@@ -165,7 +165,7 @@ class PackedAttn:
             self.kv = PackedLinear(weight=torch.cat([attn.to_k.weight, attn.to_v.weight], 0))
         self.out = PackedLinear(attn.to_out[0])
         self.xk = None
-        if not is_self and norm is not None and attn.to_q.weight.shape[0] == ops.XATTN_C:
+        if not is_self and norm is not None and attn.to_q.weight.shape[0] in ops.XATTN_WIDTHS:
             # operands of the fused cross-attention block (lr_xattn_block_f16): to_k rows / to_out columns in its k-slot order
             self.xk, self.xwo = packing.pack_xattn(attn.to_k.weight.detach(), attn.to_out[0].weight.detach(), compute_dtype())
             # LayerNorm-folded to_q with its columns in k-slot order: the variant that also runs the self-attention's out-projection

@@ -545,11 +545,18 @@ def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=None):
 
 
 XATTN_C, XATTN_ROWS, XATTN_MAX_KEYS = 320, 128, 96
+# widths lr_xattn_block_f16 has an instance for -> rows per block (C = 640: the 64-row / 4-wave instance of xattn_block640.hip)
+XATTN_WIDTHS = {320: 128, 640: 64}
+# LEFTREFILL_XATTN_WIDE=0 keeps the to_q -> attention -> to_out launches at C = 640
+XATTN_WIDE = os.environ.get("LEFTREFILL_XATTN_WIDE", "1") != "0"
 
 
 def xattn_ok(M, HW, C, heads, Lc):
     """Shapes lr_xattn_block_f16 takes (everything else keeps the to_q -> attention -> to_out path)."""
-    return C == XATTN_C and heads * 64 == C and M % XATTN_ROWS == 0 and HW % XATTN_ROWS == 0 and 0 < Lc <= XATTN_MAX_KEYS
+    rows = XATTN_WIDTHS.get(C)
+    if rows is None or (C != XATTN_C and not XATTN_WIDE):
+        return False
+    return heads * 64 == C and M % rows == 0 and HW % rows == 0 and 0 < Lc <= XATTN_MAX_KEYS
 
 
 def xattn_pack_vt(v, B, heads, Lc, out=None):

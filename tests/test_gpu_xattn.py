@@ -12,9 +12,10 @@ from oracle import golden_spec as G, unet_ref, weights  # noqa: E402
 from tests.test_gpu_ops import dev, h16, report  # noqa: E402
 
 C, HEADS = 320, 5
+WIDTHS = [(320, 5), (640, 10)]      # level 0 (128-row blocks, xattn_block.hip) and level 1 (64-row blocks, xattn_block640.hip)
 
 
-def _params(tag):
+def _params(tag, C=C):
     sd = {}
     for n in ("to_q", "to_k", "to_v"):
         sd[f"a.{n}.weight"] = h16(torch.from_numpy(weights.fill_like(f"xa.{tag}.{n}.weight", (C, C if n == "to_q" else 1024))))
@@ -29,13 +30,14 @@ def _oracle(sd, gamma, beta, x, ctx):
     """fp32 restatement on the fp16-rounded inputs: x + to_out(attention(LN(x) Wq, ctx Wk, ctx Wv))."""
     m = unet_ref._Mode("fp32")
     n = unet_ref.layer_norm(x, gamma, beta)
-    return x + unet_ref.cross_attention(sd, "a", n, ctx, HEADS, m)
+    return x + unet_ref.cross_attention(sd, "a", n, ctx, x.shape[-1] // 64, m)
 
 
 def _run_fused(sd, gamma, beta, x, ctx, want_stats=True):
     from leftrefill_amd import ops, packing
     d = dev()
-    B, L, _ = x.shape
+    B, L, C = x.shape
+    HEADS = C // 64
     Lc = ctx.shape[1]
     wq, bq, _cs = packing.fold_layernorm(sd["a.to_q.weight"], None, gamma, beta)
     xk_w, xwo = packing.pack_xattn(sd["a.to_k.weight"], sd["a.to_out.0.weight"])
@@ -48,15 +50,18 @@ def _run_fused(sd, gamma, beta, x, ctx, want_stats=True):
                            eps=1e-5, scale=64 ** -0.5, want_stats=want_stats)
 
 
-@pytest.mark.parametrize("B,L,Lc", [(1, 128, 77), (2, 256, 77), (2, 128, 96), (1, 384, 5), (2, 128, 80), (1, 128, 81)])
-def test_xattn_block_vs_oracle(B, L, Lc):
-    sd, gamma, beta = _params("p")
+@pytest.mark.parametrize("C,HEADS", WIDTHS)
+@pytest.mark.parametrize("B,L,Lc", [(1, 128, 77), (2, 256, 77), (2, 128, 96), (1, 384, 5), (2, 128, 80), (1, 128, 81), (3, 64, 77)])
+def test_xattn_block_vs_oracle(B, L, Lc, C, HEADS):
+    if C == 320 and L % 128:
+        pytest.skip("the C = 320 instance owns 128-row blocks")
+    sd, gamma, beta = _params("p", C)
     x = h16(G.T(f"xa.{L}.{Lc}.x", (B, L, C)) * 1.3 + 0.2)
     ctx = h16(G.T(f"xa.{L}.{Lc}.ctx", (B, Lc, 1024)))
     ref = _oracle(sd, gamma, beta, x, ctx)
     out, st = _run_fused(sd, gamma, beta, x, ctx)
     # composite of four products with fp16 hand-offs (q, P, O) and two 16-bit roundings of the result
-    report(f"xattn B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, atol=3e-3)
+    report(f"xattn C{C} B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, atol=3e-3 if C == 320 else 4e-3)
     # row statistics of the ROUNDED output, as the LayerNorm fold of the next GEMM reads them
     o32 = out.float()
     assert st.shape == (B * L, 1, 2)
@@ -64,13 +69,14 @@ def test_xattn_block_vs_oracle(B, L, Lc):
     torch.testing.assert_close(st[:, 0, 1], (o32 * o32).sum(1), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("C,HEADS", WIDTHS)
 @pytest.mark.parametrize("B,L,Lc", [(1, 128, 77), (2, 256, 96), (1, 256, 40)])
-def test_xattn_block_with_fused_self_attention_out_projection(B, L, Lc):
+def test_xattn_block_with_fused_self_attention_out_projection(B, L, Lc, C, HEADS):
     """PRE variant: x1 = a Wo1^T + bo1 + x (attn1's out-projection + residual, attention.py:280) runs in front of the
     cross-attention block in the same launch; oracle = the two reference lines evaluated in fp32."""
     from leftrefill_amd import ops, packing
     d = dev()
-    sd, gamma, beta = _params("pre")
+    sd, gamma, beta = _params("pre", C)
     wo1 = h16(torch.from_numpy(weights.fill_like("xa.pre.attn1.to_out.weight", (C, C))))
     bo1 = torch.from_numpy(weights.fill_like("xa.pre.attn1.to_out.bias", (C,)))
     x = h16(G.T(f"xa.pre.{L}.{Lc}.x", (B, L, C)) * 1.3 + 0.2)
@@ -88,15 +94,16 @@ def test_xattn_block_with_fused_self_attention_out_projection(B, L, Lc):
                               sd["a.to_out.0.bias"].to(d), HW=L, heads=HEADS, Lc=Lc, eps=1e-5, scale=64 ** -0.5, want_stats=True,
                               pre=(a.reshape(B * L, C).half().to(d), wo1.half().to(d), bo1.to(d)))
     # one more fp16 hand-off than the plain block (x1 is rounded like the unfused path stores it)
-    report(f"xattn+pre B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, rtol=3e-3, atol=4e-3)
+    report(f"xattn+pre C{C} B{B} L{L} Lc{Lc}", out.reshape(B, L, C), ref, rtol=3e-3, atol=4e-3 if C == 320 else 6e-3)
     o32 = out.float()
     torch.testing.assert_close(st[:, 0, 0], o32.sum(1), rtol=1e-5, atol=1e-3)
 
 
-def test_xattn_block_hot_shape_and_reruns():
-    """configs[1] shape of the level-0 blocks: M = 8 x 8192 rows (sampled rows against the oracle), bit-identical reruns."""
-    B, L, Lc = 8, 8192, 77
-    sd, gamma, beta = _params("hot")
+@pytest.mark.parametrize("C,L", [(320, 8192), (640, 2048)])
+def test_xattn_block_hot_shape_and_reruns(C, L):
+    """configs[1] shapes of the level-0 / level-1 blocks: M = 8 x 8192 / 8 x 2048 rows (sampled rows against the oracle), bit-identical reruns."""
+    B, Lc = 8, 77
+    sd, gamma, beta = _params("hot", C)
     g = torch.Generator().manual_seed(5)
     x = h16(torch.randn(B, L, C, generator=g))
     ctx = h16(torch.randn(B, Lc, 1024, generator=g))
@@ -105,18 +112,21 @@ def test_xattn_block_hot_shape_and_reruns():
     assert torch.equal(out, out2)
     rows = torch.arange(0, L, 37)
     ref = _oracle(sd, gamma, beta, x[:, rows], ctx)
-    report("xattn hot", out.reshape(B, L, C)[:, rows], ref, atol=3e-3)
+    report(f"xattn hot C{C}", out.reshape(B, L, C)[:, rows], ref, atol=3e-3 if C == 320 else 4e-3)
 
 
 def test_xattn_unsupported_shapes_are_reported():
     from leftrefill_amd import ops
     assert not ops.xattn_ok(100, 100, 320, 5, 77)      # ragged rows
-    assert not ops.xattn_ok(256, 128, 640, 10, 77)     # other widths keep the three-kernel path
+    assert ops.xattn_ok(256, 128, 640, 10, 77)         # level 1: 64-row blocks
+    assert not ops.xattn_ok(256, 96, 640, 10, 77)
+    assert not ops.xattn_ok(256, 128, 1280, 20, 77)    # other widths keep the three-kernel path
     assert not ops.xattn_ok(256, 128, 320, 5, 97)
     assert ops.xattn_ok(65536, 8192, 320, 5, 77)
 
 
-def test_engine_cross_attention_fused_equals_unfused_path():
+@pytest.mark.parametrize("C,HEADS", WIDTHS)
+def test_engine_cross_attention_fused_equals_unfused_path(C, HEADS):
     """engine.cross_attention with the per-context K / V^T pack (fused launch) vs the to_q -> attention -> to_out launches."""
     import importlib
     from leftrefill_amd import engine, ops
@@ -125,8 +135,8 @@ def test_engine_cross_attention_fused_equals_unfused_path():
     att = importlib.import_module("ldm.modules.attention")
     torch.manual_seed(0)
     d = dev()
-    ca = att.CrossAttention(320, context_dim=1024, heads=5, dim_head=64).to(d).eval()
-    norm = torch.nn.LayerNorm(320).to(d)
+    ca = att.CrossAttention(C, context_dim=1024, heads=HEADS, dim_head=64).to(d).eval()
+    norm = torch.nn.LayerNorm(C).to(d)
     with torch.no_grad():
         for p_ in list(ca.parameters()) + list(norm.parameters()):
             p_.copy_(torch.randn_like(p_) * 0.05)
@@ -134,10 +144,10 @@ def test_engine_cross_attention_fused_equals_unfused_path():
     pa, pn = engine.PackedAttn(ca, False, norm), engine.PackedNorm(norm)
     assert pa.xk is not None
     B, L, Lc = 2, 256, 77
-    x = torch.randn(B * L, 320, device=d).half()
+    x = torch.randn(B * L, C, device=d).half()
     ctx = torch.randn(B * Lc, 1024, device=d).half()
     kv = ops.gemm_conv(ctx, pa.kv.w, B=1, H=1, W=B * Lc, taps=1)
-    ent = (kv, None, ops.gemm_conv(ctx, pa.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, 320:], B, 5, Lc))
+    ent = (kv, None, ops.gemm_conv(ctx, pa.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, C:], B, HEADS, Lc))
     with torch.no_grad():
         fused, st = engine.cross_attention(x, None, pn, ctx, pa, B, L, Lc, kv=ent, want_stats=True)
         engine.XATTN = False
@@ -151,8 +161,9 @@ def test_engine_cross_attention_fused_equals_unfused_path():
     torch.testing.assert_close(st.sum(1)[:, 0], st2.sum(1)[:, 0], rtol=1e-3, atol=2e-1)
 
 
-def test_transformer_block_pre_fused_equals_separate_launches():
-    """engine.transformer_block at C = 320 with the self-attention's out-projection fused into the cross-attention launch vs the
+@pytest.mark.parametrize("C,HEADS", WIDTHS)
+def test_transformer_block_pre_fused_equals_separate_launches(C, HEADS):
+    """engine.transformer_block at C = 320 / 640 with the self-attention's out-projection fused into the cross-attention launch vs the
     separate out-projection GEMM: same block output to fp16 noise."""
     import importlib
     from leftrefill_amd import engine, ops
@@ -161,7 +172,7 @@ def test_transformer_block_pre_fused_equals_separate_launches():
     att = importlib.import_module("ldm.modules.attention")
     torch.manual_seed(1)
     d = dev()
-    blk = att.BasicTransformerBlock(320, 5, 64, context_dim=1024).to(d).eval()
+    blk = att.BasicTransformerBlock(C, HEADS, 64, context_dim=1024).to(d).eval()
     with torch.no_grad():
         for p_ in blk.parameters():
             p_.copy_(torch.randn_like(p_) * 0.05)
@@ -169,10 +180,10 @@ def test_transformer_block_pre_fused_equals_separate_launches():
             n_.weight.add_(1.0)
     pt = engine.PackedTBlock(blk)
     B, L, Lc = 2, 256, 77
-    x = torch.randn(B * L, 320, device=d).half()
+    x = torch.randn(B * L, C, device=d).half()
     ctx = torch.randn(B * Lc, 1024, device=d).half()
     kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=B * Lc, taps=1)
-    ent = (kv, None, ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, 320:], B, 5, Lc))
+    ent = (kv, None, ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, C:], B, HEADS, Lc))
     outs = []
     for flag in (True, False):
         engine.XATTN_PRE = flag

@@ -31,9 +31,10 @@ def main():
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--L", type=int, default=8192)
     ap.add_argument("--Lc", type=int, default=77)
+    ap.add_argument("--C", type=int, default=320, help="320 (level 0, default L 8192) | 640 (level 1: pass --L 2048)")
     a = ap.parse_args()
     d = torch.device("cuda:0")
-    C, heads, B, L, Lc = 320, 5, a.B, a.L, a.Lc
+    C, heads, B, L, Lc = a.C, a.C // 64, a.B, a.L, a.Lc
     M = B * L
     g = torch.Generator(device="cpu").manual_seed(0)
     wq = torch.randn(C, C, generator=g) / C ** 0.5
