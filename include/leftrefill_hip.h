@@ -68,18 +68,6 @@ int lr_groupnorm_apply(const lr_half* x1, int C1, const lr_half* x2, int C2, int
 int lr_groupnorm_finalize(const float* p1, int C1, int R1, const float* p2, int C2, int R2, int N, int HW, float* partials,
                           lr_stream_t s);
 
-/* ---- GroupNorm folded into the pointwise GEMM that consumes it (ABI 20) -------------------------------------------------
- * replaces: `x = self.norm(x)` of SpatialTransformer.forward (attention.py:399-404: Normalize = GroupNorm(32, eps 1e-6, affine), no
- *           activation) in front of proj_in (attention.py:405-408): per sample b the normalisation is a per-channel scale / shift
- *           a[b][c] = gamma[c] rstd[b][g(c)], t[b][c] = beta[c] - mean[b][g(c)] a[b][c], so
- *              proj_in(norm(x))[m][n] = sum_c (W[n][c] a[b][c]) x[m][c] + (bias[n] + sum_c W[n][c] t[b][c])
- *           -- the GEMM runs on the RAW x with per-sample weights (lr_gemm_args.wt_bstride) and the normalised tensor is never written.
- *   gpart [B][chunks][32][2]: per-group (sum, sumsq) partials of x from its producer (lr_gemm_args.gn_group_out), HW rows per sample;
- *   w [N][C] fp16, bias [N] fp32 or NULL  ->  w_out [B][N][C] = fp16(W a_b),  bias_out [B][N] = bias + W beta - rounded(W a_b) mean_b
- *   (the mean term uses the ROUNDED weights, so it cancels exactly what the matrix cores accumulate for a constant input).
- *   C % 32 == 0, C % 8 == 0, C <= 2048. */
-int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
-                           const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
 /* ---- the UNet's `out` block in one launch (ABI 21) -------------------------------------------------------------------------
  * replaces: `self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3,
  *           padding=1)))` applied as `self.out(h)` (reference ldm/modules/diffusionmodules/openaimodel.py:714-718, 812) and the
@@ -199,7 +187,8 @@ typedef struct lr_gemm_args {
    * stride 1, no upsample, no GEGLU / LayerNorm fold / per-sample weights: anything else LR_E_UNSUPPORTED.  resid / rowvec / statistics
    * outputs work as without it. */
   const lr_half* skip1; const lr_half* skip2; int32_t Cs1, Cs2;
-  /* splitk_mode (ABI 23): 0 = the split-K partials are reduced by a second launch (fixed order); 1 = in-launch reduce where the plan
+  /* splitk_mode (ABI 23): 0 = the split-K partials are reduced by a second launch (fixed order); 1 (developer builds only -- measured
+   * slower, profiles/r05_splitk_inlaunch.txt; the product library answers LR_E_UNSUPPORTED, ABI 24) = in-launch reduce where the plan
    * allows it (8-wave instances with 160- / 320-column tiles, tiles x splits <= 256 so that every K-slice block of the grid is
    * resident at once): every slice block publishes its partial tile write-through, waits for its tile's other slices on an
    * agent-scope counter (bounded spin) and reduces its share of the tile's rows in slice order with the full epilogue -- still
@@ -415,8 +404,6 @@ int lr_geglu_bwd_bf16(const lr_half* pre, const lr_half* dy, lr_half* dpre, int 
 int lr_sumpool2x2_bf16(const lr_half* x, lr_half* y, int N, int H, int W, int C, lr_stream_t s);
 int lr_mv_gather_bwd_bf16(const lr_half* dseq, lr_half* dx, int b, int v, int s, int C, lr_stream_t st);
 int lr_mv_scatter_bwd_bf16(const lr_half* dx, lr_half* dseq, int b, int v, int s, int C, lr_stream_t st);
-int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
-                            const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
 int lr_gn_conv_out_bf16(const lr_half* x, int B, int H, int W, int C, const float* gpart, int chunks, const float* gamma, const float* beta,
                         float eps, const lr_half* w, int ldw, const float* bias, int Cout, lr_half* y, lr_stream_t s);
 int lr_attention_bf16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o, int
@@ -432,6 +419,31 @@ int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s);
 int lr_xattn_block_bf16(const lr_xattn_args* args, lr_stream_t s);
 int lr_ffn_block_bf16(const lr_ffn_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_bf16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
+
+/* ==== developer builds only (-DLR_DEV_VARIANTS, tools/build_variant.sh) ==================================================================
+ * The product library (python -m leftrefill_amd.build) exports none of the following and reads no environment variable or other
+ * process-global switch: every behaviour is selected by the arguments of a call.  A developer build additionally compiles the kernel
+ * variants that were measured and not adopted (the 8-wave ping-pong attention kernel, the in-launch split-K reduce of
+ * lr_gemm_args.splitk_mode = 1, alternative tile orders, the GroupNorm fold below; profiles/README.md has the measurements) and a small
+ * name -> integer table that selects them; leftrefill_amd/_lib.py forwards LR_* environment variables to lr_dev_set. */
+#ifdef LR_DEV_VARIANTS
+int lr_dev_set(const char* name, int value);
+int lr_dev_unset(const char* name);
+/* ---- GroupNorm folded into the pointwise GEMM that consumes it (ABI 20) -------------------------------------------------
+ * replaces: `x = self.norm(x)` of SpatialTransformer.forward (attention.py:399-404: Normalize = GroupNorm(32, eps 1e-6, affine), no
+ *           activation) in front of proj_in (attention.py:405-408): per sample b the normalisation is a per-channel scale / shift
+ *           a[b][c] = gamma[c] rstd[b][g(c)], t[b][c] = beta[c] - mean[b][g(c)] a[b][c], so
+ *              proj_in(norm(x))[m][n] = sum_c (W[n][c] a[b][c]) x[m][c] + (bias[n] + sum_c W[n][c] t[b][c])
+ *           -- the GEMM runs on the RAW x with per-sample weights (lr_gemm_args.wt_bstride) and the normalised tensor is never written.
+ *   gpart [B][chunks][32][2]: per-group (sum, sumsq) partials of x from its producer (lr_gemm_args.gn_group_out), HW rows per sample;
+ *   w [N][C] fp16, bias [N] fp32 or NULL  ->  w_out [B][N][C] = fp16(W a_b),  bias_out [B][N] = bias + W beta - rounded(W a_b) mean_b
+ *   (the mean term uses the ROUNDED weights, so it cancels exactly what the matrix cores accumulate for a constant input).
+ *   C % 32 == 0, C % 8 == 0, C <= 2048. */
+int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
+                           const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
+int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps,
+                            const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s);
+#endif /* LR_DEV_VARIANTS */
 
 #ifdef __cplusplus
 }

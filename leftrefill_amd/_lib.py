@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -103,8 +103,6 @@ SIGNATURES = {
     "lr_gemm_stats_parts": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_gn_rows": [ctypes.POINTER(GemmArgs)],
     "lr_gemm_gn_group_chunks": [ctypes.POINTER(GemmArgs)],
-    "lr_gn_fold_weights_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p,
-                               c_void_p, c_void_p],
     "lr_gn_conv_out_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
                            c_int, c_void_p, c_void_p],
     "lr_groupnorm_finalize": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -139,7 +137,7 @@ BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n"
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
               "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",
-              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_gn_fold_weights_f16", "lr_gn_conv_out_f16"]
+              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_gn_conv_out_f16"]
 
 
 def twin(name):
@@ -149,6 +147,11 @@ def twin(name):
 
 for _n in BF16_TWINS:
     SIGNATURES[twin(_n)] = SIGNATURES[_n]
+
+# entry points of developer builds only (-DLR_DEV_VARIANTS, include/leftrefill_hip.h last section): bound when present
+_FOLD_SIG = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+DEV_SIGNATURES = {"lr_dev_set": [ctypes.c_char_p, c_int], "lr_dev_unset": [ctypes.c_char_p],
+                  "lr_gn_fold_weights_f16": _FOLD_SIG, "lr_gn_fold_weights_bf16": _FOLD_SIG}
 
 _lib = None
 
@@ -182,8 +185,32 @@ def load():
     v = lib.lr_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libleftrefill_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    for name, argtypes in DEV_SIGNATURES.items():
+        if hasattr(lib, name):
+            f_ = getattr(lib, name)
+            f_.argtypes, f_.restype = argtypes, c_int
     _lib = lib
+    if dev_variants():      # developer library: its knobs come from the LR_* environment variables of the tools/ A/B scripts
+        for k, val in os.environ.items():
+            if k.startswith("LR_") and val.lstrip("-").isdigit():
+                lib.lr_dev_set(k.encode(), int(val))
     return lib
+
+
+def dev_variants():
+    """True when the loaded library is a developer build (tools/build_variant.sh: -DLR_DEV_VARIANTS) -- the only kind that has knobs."""
+    return hasattr(load(), "lr_dev_set")
+
+
+def dev_set(name, value):
+    """Set (int) or clear (None) a developer knob of a developer build; the product library has none (RuntimeError)."""
+    lib = load()
+    if not hasattr(lib, "lr_dev_set"):
+        raise RuntimeError(f"{name}: developer knobs exist only in a -DLR_DEV_VARIANTS build (tools/build_variant.sh)")
+    if value is None:
+        lib.lr_dev_unset(name.encode())
+    else:
+        lib.lr_dev_set(name.encode(), int(value))
 
 
 def check(rc, what):

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const AttnParams
   }
 }
 
+#ifdef LR_DEV_VARIANTS
 // =====================================================================================================================
 // Ping-pong variant for long key sequences (pre-transposed V, Nkv a multiple of 64): block = 8 waves = two GROUPS of four.
 //
@@ -638,26 +639,20 @@ __global__ __launch_bounds__(PP_THREADS) void attention_pp_kernel(const AttnPara
 #endif
 }
 
-// LR_ATTN_PP (developer A/B switch, read at every launch): 0 (default) = attention_kernel for every shape; 1 = the ping-pong
-// kernel with the block size picked by the rule in launch_attention, 2 / 3 = with 512- / 256-query blocks forced.
-// Measured on MI355X (profiles/r04_attn_pingpong.txt): 8192^2 753 us (attention_kernel) vs 860 / 797 us, 2048^2 116 vs 151 / 121,
-// 20480^2 1408 vs 1383 / 1495 -- the complementary-segment schedule does not pay at d_head = 64, so it is not the default.
-static int attn_pp_mode() {
-  const char* v = getenv("LR_ATTN_PP");
-  return v ? atoi(v) : 0;
-}
+#endif  // LR_DEV_VARIANTS
 
-// LR_ATTN_NQB = 1 | 2 forces 128- / 256-query blocks for lr_attention_f16 on natural V; unset: the rule in launch_attention
-static int attn_nqb_mode() {
-  const char* v = getenv("LR_ATTN_NQB");
-  return v ? atoi(v) : 0;
-}
-
-// developer switch: LR_ATTN_TR=0 sends natural-layout V through the register transpose (VM = 0) instead of the LDS transpose read
-static bool attn_tr_mode() {
-  const char* v = getenv("LR_ATTN_TR");
-  return v ? atoi(v) != 0 : true;
-}
+// Developer build only (LR_DEV, common.h):
+//   LR_ATTN_PP: 0 (default) = attention_kernel for every shape; 1 = the ping-pong kernel with the block size picked by the rule in
+//     launch_attention, 2 / 3 = with 512- / 256-query blocks forced.  Measured on MI355X (profiles/r04_attn_pingpong.txt): 8192^2 753 us
+//     (attention_kernel) vs 860 / 797 us, 2048^2 116 vs 151 / 121, 20480^2 1408 vs 1383 / 1495 -- the complementary-segment schedule does
+//     not pay at d_head = 64, so attention_pp_kernel is not compiled into the product library.
+//   LR_ATTN_NQB = 1 | 2 forces 128- / 256-query blocks for lr_attention_f16 on natural V; unset: the rule in launch_attention
+//   LR_ATTN_TR = 0 sends natural-layout V through the register transpose (VM = 0) instead of the LDS transpose read
+#ifdef LR_DEV_VARIANTS
+static int attn_pp_mode() { return LR_DEV("LR_ATTN_PP", 0); }
+#endif
+static int attn_nqb_mode() { return LR_DEV("LR_ATTN_NQB", 0); }
+static bool attn_tr_mode() { return LR_DEV("LR_ATTN_TR", 1) != 0; }
 
 template <typename T>
 static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
@@ -675,6 +670,7 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
   P.nblocks = P.nqt * heads * B;
   P.c = scale * 1.44269504088896340736f;
   P.lse = lse;
+#ifdef LR_DEV_VARIANTS
   const int pp = attn_pp_mode();
   if (vt && !lse && pp && Nkv % ATT_KB == 0 && Nkv >= 4 * ATT_KB) {
     // ping-pong kernel: 512-query blocks when they fill the chip for at least two rounds, else 256-query blocks
@@ -689,6 +685,7 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
     }
     return lr_launch_status();
   }
+#endif
   if (lse) {      // training forward: exact scale handling, the backward recomputes P from the unscaled operands and this log-sum-exp
     if (vt) return LR_E_UNSUPPORTED;
     hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
@@ -714,7 +711,9 @@ static int launch_attention(const lr_half* q, int ldq, const lr_half* k, int ldk
       hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
     }
   }
+#ifdef LR_DEV_VARIANTS
   else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(P.nblocks), dim3(ATT_THREADS), 0, (hipStream_t)s, P);
+#endif
   return lr_launch_status();
 }
 

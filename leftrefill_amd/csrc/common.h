@@ -8,6 +8,19 @@
 
 #define LR_WAVE 64
 
+// Developer knobs.  The PRODUCT library has none: LR_DEV(name, dflt) is the constant `dflt`, and nothing in csrc/ reads the environment,
+// a file or any other process-global switch ("no global state inside").  A -DLR_DEV_VARIANTS build (tools/build_variant.sh)
+// additionally compiles the measured-and-lost kernel variants (profiles/README.md lists them) and exports lr_dev_set(name, value): the
+// Python front end forwards LR_* environment variables through it (leftrefill_amd/_lib.py), so the A/B scripts of tools/ keep working
+// against a variant library.
+#ifdef LR_DEV_VARIANTS
+extern "C" int lr_dev_set(const char* name, int value);
+int lr_dev_get(const char* name, int dflt);
+#define LR_DEV(name, dflt) lr_dev_get(name, dflt)
+#else
+#define LR_DEV(name, dflt) (dflt)
+#endif
+
 typedef _Float16 f16;
 typedef __bf16 bf16;          // the second 16-bit activation / weight type (LR_DTYPE_BF16): same layouts, same kernels
 template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));

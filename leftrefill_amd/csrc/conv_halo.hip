@@ -261,11 +261,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
     __builtin_amdgcn_s_barrier();
     gn_group_reduce<BN, WMW, 256>(P, gsl, tile * 256, n0, t);
   }
+#ifdef LR_DEV_VARIANTS
   if (P.sk_cnt != nullptr && P.splits > 1)      // in-launch split-K reduce: sub-block j = two 16-pixel line segments of the tile
     sk_fused_tail<T, BN>(P, tile * P.ntiles_n + tile_n, 8,
                          [&](const int j, const int r) { return m_org + (2 * j + (r >> 4)) * P.W + (r & 15); },
                          [&](const int j) { return tile * 8 + j; }, [&](const int j) { return tile * 256 + 32 * j; }, n0,
                          reinterpret_cast<float*>(smem), t);
+#endif
   LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -281,12 +283,11 @@ static int launch_halo_t(const GemmParams& P0, hipStream_t st) {
   P.ntiles_m = P.M / 256;
   P.m_fastest = 0;
   // (the grouped tile order of gemm_conv_pipe_kernel was measured here too: no effect -- 4 column tiles at most, one round)
-  // developer switch, default off (LR_HALO_MFASTEST=1): split-K launches walk m-fastest, so an XCD's consecutive tiles share ONE column tile's
+  // developer build (LR_DEV), default off (LR_HALO_MFASTEST=1): split-K launches walk m-fastest, so an XCD's consecutive tiles share ONE column tile's
   // weight slice instead of spanning all of them.  Measured (profiles/r05_conv_halo_proto.txt section 15): the launches' L2-miss bytes fall as
   // that predicts (4096 x 1280 x 23040: 578 -> 287 MB, 1024 x 1280 x 23040: 289 -> 143; family -1.34 GB per step), the UNet step does not move
   // (seven same-box pairs: +0.006 ... +0.031 ms, one -0.10) -- not enabled: it would only improve the traffic figure.
-  static const int mf = getenv("LR_HALO_MFASTEST") ? atoi(getenv("LR_HALO_MFASTEST")) : 0;
-  if (mf && P.splits > 1) P.m_fastest = 1;
+  if (LR_DEV("LR_HALO_MFASTEST", 0) && P.splits > 1) P.m_fastest = 1;
   P.nblocks = P.ntiles_n * P.ntiles_m;
   const size_t smem = (size_t)HALO_NQ * 1024 + NSTAGE * (size_t)BN * 128 + 2 * (((BN + 63) / 64) * 64) * sizeof(float);
   static unsigned long long attr_done = 0;

@@ -222,7 +222,33 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 23; }
+extern "C" int lr_abi_version(void) { return 24; }
+
+#ifdef LR_DEV_VARIANTS
+// developer build only: name -> value table behind LR_DEV (common.h); set through lr_dev_set by the Python front end
+#include <map>
+#include <mutex>
+#include <string>
+static std::map<std::string, int>& lr_dev_table() { static std::map<std::string, int> t; return t; }
+static std::mutex lr_dev_mutex;
+extern "C" int lr_dev_set(const char* name, int value) {
+  if (!name) return LR_E_ARG;
+  std::lock_guard<std::mutex> g(lr_dev_mutex);
+  lr_dev_table()[name] = value;
+  return 0;
+}
+extern "C" int lr_dev_unset(const char* name) {
+  if (!name) return LR_E_ARG;
+  std::lock_guard<std::mutex> g(lr_dev_mutex);
+  lr_dev_table().erase(name);
+  return 0;
+}
+int lr_dev_get(const char* name, int dflt) {
+  std::lock_guard<std::mutex> g(lr_dev_mutex);
+  const auto it = lr_dev_table().find(name);
+  return it == lr_dev_table().end() ? dflt : it->second;
+}
+#endif
 
 template <typename T>
 static int lr_nchw_f32_to_nhwc_t(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N,

@@ -494,6 +494,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // =====================================================================================================================
 static __device__ unsigned lr_sk_error = 0;
 
+#ifdef LR_DEV_VARIANTS
 // one 32-row x 160-column block: sum of the partials + epilogue + statistics.  >= 320 threads; red: >= 16 * 336 floats of LDS.
 template <typename T, typename RowFn>
 __device__ __forceinline__ void sk_reduce_block(const GemmParams& P, RowFn row_m, const int rb, const int mbv, const int nbase,
@@ -628,6 +629,7 @@ __device__ __forceinline__ void sk_fused_tail(const GemmParams& P, const int til
   }
 #endif
 }
+#endif  // LR_DEV_VARIANTS
 
 // conv_halo.hip: the LR_PIPE_HALO instances (3x3 stride-1 conv with an LDS-resident 18 x 18 pixel patch); tile_n = 160 | 320
 int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st);

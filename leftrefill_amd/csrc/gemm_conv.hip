@@ -548,6 +548,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
         gn_group_reduce<BN, WMW, BM2>(P, gsl, m0, n0, t);
       }
     }
+#ifdef LR_DEV_VARIANTS
     if constexpr (MODE != 1 && BN % 160 == 0) {
       if (P.sk_cnt != nullptr && P.splits > 1)      // in-launch split-K reduce (gemm_common.h): this slice's share of the tile
         sk_fused_tail<T, BN>(P, tile_m * P.ntiles_n + tile_n, BM2 / 32,
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
                              [&](const int j) { return (m0 >> 5) + j; }, [&](const int j) { return m0 + 32 * j; }, n0,
                              reinterpret_cast<float*>(smem), t);
     }
+#endif
     LR_STAMP(5);
 #ifdef LR_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -575,21 +577,19 @@ static int launch_pipe_t(const GemmParams& P0, hipStream_t st) {
   // CUs run several tiles back to back (GEGLU / qkv projections: 4 rounds) drift out of lockstep, and with n-fastest an XCD then streams
   // the whole weight matrix per two row tiles.  Measured: 16384 x 5120 x 640 GEGLU 152 -> 140 us, 4096 x 10240 x 1280 129 -> 117 us,
   // 16384 x 1920 x 640 74 -> 68 us, UNet step -0.25 ... -0.32 ms on three boxes (G = 8 / 16; G = 32: -0.07; plain m-fastest was
-  // measured slower in round 1: 928 vs 1038 TFLOP/s).  Pure scheduling: same tiles, same bits.  LR_GEMM_GROUP_M=0 restores n-fastest.
+  // measured slower in round 1: 928 vs 1038 TFLOP/s).  Pure scheduling: same tiles, same bits.
+  // (developer build, LR_DEV: LR_GEMM_GROUP_M / LR_GEMM_GROUP_M2 override G for wide / narrow N, 0 = n-fastest; LR_GEMM_GROUP_CONV groups the
+  // 3x3 gathers too; LR_GATHER_MFASTEST = 1: split-K 3x3 gathers walk m-fastest -- measured: fetch DOWN at 1024 rows (1024 x 1280 x 11520:
+  // 169 -> 96 MB) but UP at 4096 rows (378 -> 492 MB; this kernel re-gathers its rows per tap), step time unchanged)
   {
-    static const int g_env = getenv("LR_GEMM_GROUP_M") ? atoi(getenv("LR_GEMM_GROUP_M")) : -1;
-    static const int g_env2 = getenv("LR_GEMM_GROUP_M2") ? atoi(getenv("LR_GEMM_GROUP_M2")) : -1;      // developer knobs (wide / narrow N)
+    const int g_env = LR_DEV("LR_GEMM_GROUP_M", -1), g_env2 = LR_DEV("LR_GEMM_GROUP_M2", -1);
     int G = 0;
     if (P.ntiles_n > 1) G = P.ntiles_n >= 4 ? 8 : 16;
     if (g_env >= 0 && P.ntiles_n >= 4) G = g_env;
     if ((g_env2 >= 0 || g_env >= 0) && P.ntiles_n > 1 && P.ntiles_n < 4) G = g_env2 >= 0 ? g_env2 : g_env;
-    static const int g_conv = getenv("LR_GEMM_GROUP_CONV") ? atoi(getenv("LR_GEMM_GROUP_CONV")) : 0;
-    if (P.taps != 1 && !g_conv) G = 0;      // 3x3 gathers re-read their rows per tap: column-tile neighbours on one XCD are worth more there (measured 0 ... +2 %)
+    if (P.taps != 1 && !LR_DEV("LR_GEMM_GROUP_CONV", 0)) G = 0;      // 3x3 gathers re-read their rows per tap: column-tile neighbours on one XCD are worth more there (measured 0 ... +2 %)
     P.m_fastest = (G > 1 && ntm > 1) ? G : 0;
-    // developer switch, default off (LR_GATHER_MFASTEST=1): split-K 3x3 gathers walk m-fastest.  Measured: fetch DOWN at 1024 rows
-    // (1024 x 1280 x 11520: 169 -> 96 MB) but UP at 4096 rows (378 -> 492 MB; this kernel re-gathers its rows per tap), step time unchanged.
-    static const int mf = getenv("LR_GATHER_MFASTEST") ? atoi(getenv("LR_GATHER_MFASTEST")) : 0;
-    if (mf && P.taps != 1 && P.splits > 1 && ntm > 1) P.m_fastest = 1;
+    if (LR_DEV("LR_GATHER_MFASTEST", 0) && P.taps != 1 && P.splits > 1 && ntm > 1) P.m_fastest = 1;
   }
   P.nblocks = P.ntiles_n * ntm;
   // stages + (mean, rstd) rows + (bias, ln_colsum) columns
@@ -994,6 +994,9 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   P.ws = a->workspace;
   P.sk_cnt = nullptr;
   if (a->splitk_mode != 0 && a->splitk_mode != 1) return LR_E_ARG;
+#ifndef LR_DEV_VARIANTS
+  if (a->splitk_mode == 1) return LR_E_UNSUPPORTED;      // the in-launch reduce (measured slower, profiles/r05_splitk_inlaunch.txt) is compiled in developer builds only
+#endif
   // LayerNorm fold (pointwise, single source, K = normalised width) and per-row output statistics
   P.ln_part = a->ln_stats; P.ln_cs = a->ln_colsum; P.ln_parts = a->ln_parts; P.ln_eps = a->ln_eps;
   P.ln_invc = 1.0f / (float)P.K;
@@ -1007,7 +1010,7 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   if (a->dtype != LR_DTYPE_F16 && a->dtype != LR_DTYPE_BF16) return LR_E_ARG;
   P.bf16 = a->dtype == LR_DTYPE_BF16;
 #ifdef LR_GEMM_STAGGER
-  { const char* e = getenv("LR_GEMM_STAGGER"); P.stagger = e ? atoi(e) : 0; }
+  P.stagger = LR_DEV("LR_GEMM_STAGGER", 0);
 #endif
   if (P.bf16 && P.gelu) return LR_E_UNSUPPORTED;
   P.gs_out = a->gn_stats_out;
@@ -1036,12 +1039,14 @@ extern "C" int lr_gemm_conv_f16(const lr_gemm_args* a, lr_stream_t s) {
   const int mode = P.geglu ? 1 : P.gelu ? 2 : 0;
   if (a->pipe != 0 && a->pipe != choose_stages(tm, tn, a->pipe)) return LR_E_UNSUPPORTED;
   const bool deep = tm == 128 && choose_stages(tm, tn, a->pipe) == 4;
+#ifdef LR_DEV_VARIANTS
   // in-launch split-K reduce: the 8-wave instances with 160- / 320-column tiles, the whole grid resident at once (one block per CU)
   if (P.splits > 1 && a->splitk_mode == 1 && mode != 1 && (tn == 160 || tn == 320) && (tm == 256 || deep || a->pipe == LR_PIPE_HALO)) {
     const int64_t tiles = (int64_t)((P.M + tm - 1) / tm) * ((P.N + tn - 1) / tn);
     if (tiles * P.splits <= 256 && tiles <= 2048 && (int64_t)P.splits * P.M * P.N * 4 < lim && P.N % 8 == 0)
       P.sk_cnt = sk_counter_slot();
   }
+#endif
   if (a->pipe == LR_PIPE_HALO) {      // 3x3 stride-1 conv with the input patch resident in LDS (conv_halo.hip)
     if (mode != 0 || a->asym) return LR_E_UNSUPPORTED;
     rc = lr_launch_conv_halo(P, tn, st);

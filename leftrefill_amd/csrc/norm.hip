@@ -273,12 +273,8 @@ __global__ void softmax_rows_kernel(const T* __restrict__ s, T* __restrict__ p, 
   }
 }
 
-static int gn_env(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 static int gn_nchunks(int N, int HW, int C) {
-  static const int base_blocks = gn_env("LR_GN_STAT_BLOCKS", 256);
+  const int base_blocks = LR_DEV("LR_GN_STAT_BLOCKS", 256);
   // ~1 block per CU for the UNet's tensors (<= 126 MB); tensors of the VAE's size (0.5 GB) get one block per 512 KB so
   // enough loads are in flight to stream at HBM rate
   const long long want = ((long long)N * HW * C * 2) >> 19;
@@ -359,6 +355,7 @@ extern "C" int lr_groupnorm_finalize(const float* p1, int C1, int R1, const floa
   return lr_launch_status();
 }
 
+#ifdef LR_DEV_VARIANTS      // (measured: the fold loses to gn_apply + proj_in in the step -- developer builds only, like the engine switch)
 // GroupNorm folded into the pointwise GEMM that consumes it (lr_gn_fold_weights_f16): per sample the normalisation is a per-channel
 // scale / shift, which goes into a per-sample copy of the weights.  grid = (N / FOLD_ROWS, B), block = 256 = 4 waves; prologue as in
 // gn_apply_kernel (mean / rstd of the sample's 32 groups from the chunk partials, fp64, fixed order), then one wave per weight row.
@@ -431,6 +428,7 @@ static int lr_gn_fold_weights_t(const float* gpart, int chunks, int B, int HW, i
 }
 extern "C" int lr_gn_fold_weights_f16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps, const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s) { return lr_gn_fold_weights_t<f16>(gpart, chunks, B, HW, C, gamma, beta, eps, w, bias, N, w_out, bias_out, s); }
 extern "C" int lr_gn_fold_weights_bf16(const float* gpart, int chunks, int B, int HW, int C, const float* gamma, const float* beta, float eps, const lr_half* w, const float* bias, int N, lr_half* w_out, float* bias_out, lr_stream_t s) { return lr_gn_fold_weights_t<bf16>(gpart, chunks, B, HW, C, gamma, beta, eps, w, bias, N, w_out, bias_out, s); }
+#endif  // LR_DEV_VARIANTS
 
 template <typename T>
 static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, int C2, int N, int HW, const float* partials,
@@ -469,7 +467,7 @@ static int groupnorm_apply_impl(const lr_half* x1, int C1, const lr_half* x2, in
   int R = 256 / nOct;
   if (R < 1) R = 1;
   const int threads = nOct * R;
-  static const int base_apply_blocks = gn_env("LR_GN_APPLY_BLOCKS", 2048);      // round 5: 512 -> 2048 (tools/bench_gn_apply.py: 654 -> 626 us per step, same bits)
+  const int base_apply_blocks = LR_DEV("LR_GN_APPLY_BLOCKS", 2048);      // round 5: 512 -> 2048 (tools/bench_gn_apply.py: 654 -> 626 us per step, same bits)
   const long long want_blocks = ((long long)N * HW * C * 2) >> 18;     // one block per 256 KB for very large tensors
   const long long apply_blocks = want_blocks > base_apply_blocks ? want_blocks : base_apply_blocks;
   ppb = (int)(((long long)N * HW + apply_blocks - 1) / apply_blocks);

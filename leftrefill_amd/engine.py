@@ -615,14 +615,14 @@ def _mv_sharded_self_attention(x, pt: PackedTBlock, N, L, st=None):
 # GroupNorm of the SpatialTransformer folded into proj_in through per-sample weights (levels where the activation is much larger
 # than N copies of the weights).  OFF by default since round 5: its own A/B is noise (18.43 vs 18.41 ms per step, round 4) and the
 # folded weights W gamma rstd carry no range guard for near-constant groups (rstd up to 1e3 at eps 1e-6) -- the default
-# path is GroupNorm-apply -> proj_in, whose normalised activations are bounded.  LEFTREFILL_ST_GN_FOLD=1 enables the fold (the
-# kernel lr_gn_fold_weights_f16 and its parity test stay).
+# path is GroupNorm-apply -> proj_in, whose normalised activations are bounded.  LEFTREFILL_ST_GN_FOLD=1 enables the fold with a
+# developer build of the library (round 6: lr_gn_fold_weights_f16 and its parity test are compiled under -DLR_DEV_VARIANTS only).
 ST_GN_FOLD = __import__("os").environ.get("LEFTREFILL_ST_GN_FOLD", "0") != "0"
 
 
 def st_gn_fold_ok(x_in, act: Act, gs_in, ps: PackedST):
     C = x_in.shape[1]
-    return (ST_GN_FOLD and gs_in is not None and gs_in[2] is not None and fold_ok(x_in) and gn_fuse_ok(x_in)
+    return (ST_GN_FOLD and ops._lib.dev_variants() and gs_in is not None and gs_in[2] is not None and fold_ok(x_in) and gn_fuse_ok(x_in)
             and x_in.shape[0] >= 2 * act.N * C and act.HW % 256 == 0 and ps.proj_in.w.shape == (C, C))
 
 

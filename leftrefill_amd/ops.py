@@ -36,7 +36,7 @@ _tile_cache = None
 PLAN_LOG = os.environ.get("LEFTREFILL_PLAN_LOG", "0") == "1"
 # lr_gemm_args.splitk_mode: 1 = split-K partials reduced inside the GEMM launch where the plan allows it (every K-slice block resident
 # at once), 0 = by the separate fixed-order reduce launch
-SPLITK_MODE = int(os.environ.get("LEFTREFILL_SPLITK_MODE", "0"))
+SPLITK_MODE = int(os.environ.get("LEFTREFILL_SPLITK_MODE", "0"))      # (1 needs a developer build of the library)
 _untabulated = set()
 # developer hooks of tools/tune_in_step.py (None in the product): PLAN_TRIAL maps a table key to the (tile_m, tile_n, splits, pipe) to try
 # instead of the table's plan (splits 0 = the library's static choice for that tile; a plan the library refuses falls back to the table's);
@@ -208,6 +208,8 @@ def gn_fold_weights(gp, chunks, N, HW, gamma, beta, eps, w, bias):
     """Per-sample copies of a pointwise layer's weights with GroupNorm(32, affine) folded in (lr_gn_fold_weights_f16):
     w [Nout, C] 16-bit, bias [Nout] fp32 | None -> (w_b [N, Nout, C], bias_b [N, Nout] fp32); gp / chunks as in group_norm_groups."""
     lib = _lib.load()
+    if not _lib.dev_variants():
+        raise RuntimeError("lr_gn_fold_weights_f16 is compiled in developer builds only (tools/build_variant.sh)")
     _chk16(w, "w")
     Nout, C = w.shape
     assert gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (N, chunks, 32, 2)

@@ -45,21 +45,27 @@ import contextlib
 def v_path(mode):
     """How V reaches the PV product of ops.attention: "tr" = natural V + LDS transpose read (lr_attention_f16, the default), "vt" =
     lr_transpose_v_f16 + lr_attention_vt_f16 for every length, "reg" = natural V transposed in registers (LR_ATTN_TR=0)."""
-    from leftrefill_amd import ops
-    old = (ops.VT_MIN_KEYS, ops.ATTN_VT, os.environ.get("LR_ATTN_TR"))
+    from leftrefill_amd import _lib, ops
+    old = (ops.VT_MIN_KEYS, ops.ATTN_VT)
     ops.VT_MIN_KEYS, ops.ATTN_VT = (1, True) if mode == "vt" else (1 << 30, False)
-    if mode == "reg":
-        os.environ["LR_ATTN_TR"] = "0"
-    else:
-        os.environ.pop("LR_ATTN_TR", None)
+    # "reg" is a variant of developer builds (LR_DEV_VARIANTS); against the product library the mode is the default path again
+    dev = _lib.dev_variants()
+    if dev:
+        _lib.dev_set("LR_ATTN_TR", 0 if mode == "reg" else None)
     try:
         yield
     finally:
-        ops.VT_MIN_KEYS, ops.ATTN_VT = old[:2]
-        if old[2] is None:
-            os.environ.pop("LR_ATTN_TR", None)
-        else:
-            os.environ["LR_ATTN_TR"] = old[2]
+        ops.VT_MIN_KEYS, ops.ATTN_VT = old
+        if dev:
+            _lib.dev_set("LR_ATTN_TR", None)
+
+
+def need_dev_build():
+    """Tests of kernel variants that only a -DLR_DEV_VARIANTS library contains (tools/build_variant.sh dev -DLR_DEV_VARIANTS;
+    LEFTREFILL_LIB_PATH=<that .so> pytest ...)."""
+    from leftrefill_amd import _lib
+    if not _lib.dev_variants():
+        pytest.skip("variant compiled in developer builds only (LR_DEV_VARIANTS)")
 
 
 def report(name, out, ref, rtol=RTOL, atol=ATOL):
@@ -374,6 +380,7 @@ def test_splitk_in_launch_reduce(tile, monkeypatch):
     separate fixed-order reduce launch, the GroupNorm statistics describe the stored tensor, repeated launches stay identical (the
     counters re-arm themselves), no spin ever times out; plans whose grid would not be resident at once fall back silently."""
     from leftrefill_amd import _lib, ops, packing
+    need_dev_build()
     d = dev()
     N, H, W, Cin, Cout = 8, 8, 16, 1280, 640                  # M = 1024 rows (the 8 x 16 level), K = 11520
     name = "skf." + "x".join(map(str, tile))
@@ -785,6 +792,7 @@ def test_groupnorm_folded_into_pointwise_gemm(C, HW):
     different statistics (a constant offset of 10 on one of them, |mean| >> std) keep the tolerance (the mean term is formed with the
     rounded weights)."""
     from leftrefill_amd import ops
+    need_dev_build()
     d = dev()
     N = 3
     M = N * HW
@@ -957,16 +965,14 @@ def test_attention_pretransposed_v(B, heads, Nq, Nkv):
     assert torch.equal(outs["tr"], outs["vt"]) and torch.equal(outs["tr"], outs["reg"])
     assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt), outs["tr"])
     # 128- and 256-query blocks (LR_ATTN_NQB; the library picks by grid size) run the same arithmetic per query
-    old_nqb = os.environ.get("LR_ATTN_NQB")
-    try:
-        for nqb in ("1", "2"):
-            os.environ["LR_ATTN_NQB"] = nqb
-            assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5), outs["tr"]), nqb
-    finally:
-        if old_nqb is None:
-            os.environ.pop("LR_ATTN_NQB", None)
-        else:
-            os.environ["LR_ATTN_NQB"] = old_nqb
+    from leftrefill_amd import _lib
+    if _lib.dev_variants():      # (forcing the block size is a developer knob)
+        try:
+            for nqb in (1, 2):
+                _lib.dev_set("LR_ATTN_NQB", nqb)
+                assert torch.equal(ops.attention(q, k, v, B, heads, Nq, Nkv, 64 ** -0.5), outs["tr"]), nqb
+        finally:
+            _lib.dev_set("LR_ATTN_NQB", None)
 
 
 def test_attention_online_softmax_rescale():
@@ -1050,7 +1056,8 @@ def test_attention_pingpong_kernel_matches_reference_kernel(B, heads, Nq, Nkv):
     arithmetic per wave as attention_kernel: bit-identical outputs for 512- and 256-query blocks, query tails, every ring
     slot phase (T = 4, 5, 16, 32, 64 key tiles), with forced running-max jumps (guide rule 26) in the first, a middle and
     the last key tile."""
-    from leftrefill_amd import ops
+    from leftrefill_amd import _lib, ops
+    need_dev_build()
     d = dev()
     C = heads * 64
     q = h16(G.T(f"attpp.{Nq}.{Nkv}.q", (B, Nq, C)))
@@ -1061,18 +1068,14 @@ def test_attention_pingpong_kernel_matches_reference_kernel(B, heads, Nq, Nkv):
     k[0, Nkv - 2, :64] = q[0, 7, :64] * 6.0
     qd, kd, vd = (t_.reshape(-1, C).half().to(d) for t_ in (q, k, v))
     vt = ops.transpose_v(vd, B, heads, Nkv)
-    old = os.environ.get("LR_ATTN_PP")
     outs = {}
     try:
         for mode in ("0", "2", "3", "1"):
-            os.environ["LR_ATTN_PP"] = mode
+            _lib.dev_set("LR_ATTN_PP", int(mode))
             outs[mode] = ops.attention(qd, kd, vd, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt)
             assert torch.equal(outs[mode], ops.attention(qd, kd, vd, B, heads, Nq, Nkv, 64 ** -0.5, vt=vt)), f"mode {mode}: rerun differs"
     finally:
-        if old is None:
-            os.environ.pop("LR_ATTN_PP", None)
-        else:
-            os.environ["LR_ATTN_PP"] = old
+        _lib.dev_set("LR_ATTN_PP", None)
     for mode in ("2", "3", "1"):
         assert torch.equal(outs[mode], outs["0"]), f"LR_ATTN_PP={mode} differs from attention_kernel"
     ref = unet_ref.attention(q, k, v, heads, unet_ref._Mode("fp32"))

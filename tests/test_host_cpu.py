@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "leftrefill_hip.h")).read()
+    src = re.sub(r"#ifdef LR_DEV_VARIANTS.*?#endif /\* LR_DEV_VARIANTS \*/", "", src, flags=re.S)      # developer builds only
     return sorted(set(re.findall(r"^(?:int|int64_t) (lr_\w+)\(", src, flags=re.M)))
 
 
@@ -28,6 +29,19 @@ def test_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/leftrefill_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
     assert _lib.load().lr_abi_version() == _lib.ABI_VERSION
+
+
+def test_product_library_has_no_switches():
+    """SURVEY section 8b "no global state inside": nothing in csrc/ reads the environment, and the product build exports neither the
+    developer knob table nor the measured-and-lost variants (they exist under -DLR_DEV_VARIANTS only, tools/build_variant.sh)."""
+    from leftrefill_amd import _lib, build
+    build.build(verbose=False)
+    csrc = os.path.join(ROOT, "leftrefill_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in _lib.DEV_SIGNATURES:
+        assert not hasattr(lib, s), f"{s} must not be exported by the product library"
 
 
 def test_gemm_args_struct_layout_matches_header():
