@@ -131,8 +131,9 @@ def kernel_roofline(model, batch, B, dump=None):
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
-    rec = {"gemm_conv": [], "attention": [], "xattn_block": [], "ffn_block": []}
-    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block, "ffn_block": ops.ffn_block}
+    rec = {"gemm_conv": [], "attention": [], "xattn_block": [], "ffn_block": [], "stin_block": []}
+    orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block, "ffn_block": ops.ffn_block,
+            "stin_block": ops.stin_block}
 
     def wrap(name):
         def f(*a, **k):
@@ -148,6 +149,8 @@ def kernel_roofline(model, batch, B, dump=None):
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], Lc=k["Lc"], heads=k["heads"], pre=int(k.get("pre") is not None))
             elif name == "ffn_block":        # fused LayerNorm + GEGLU projection + gate + second Linear + residual (level 0)
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], H=a[3].shape[0] * 64)
+            elif name == "stin_block":       # fused proj_in + LayerNorm + q|k|v projection (level 0)
+                desc = dict(M=a[0].shape[0], C=a[0].shape[1], NQ=a[3].shape[0])
             else:
                 desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
             rec[name].append((e0, e1, desc))
@@ -184,7 +187,9 @@ def kernel_roofline(model, batch, B, dump=None):
     # numerators of the GEMM / attention families (which only count what those kernels still execute)
     ffn_fl = lambda d: 6.0 * d["M"] * d["C"] * d["H"]      # [M, C] x [C, 2H] + [M, H] x [H, C]
     xl_fl = lambda d: (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"]      # to_q + to_out (+ the self-attention's out-projection)
-    moved = {"gemm": sum(xl_fl(d) for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"]),
+    stin_fl = lambda d: 2.0 * d["M"] * d["C"] * (d["C"] + d["NQ"])      # proj_in + the fused q|k|v projection
+    moved = {"gemm": sum(xl_fl(d) for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"])
+                     + sum(stin_fl(d) for _, _, d in rec["stin_block"]),
              "attn": sum(4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
@@ -199,6 +204,10 @@ def kernel_roofline(model, batch, B, dump=None):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec["ffn_block"])
         out["ffn_block"] = {"launches": len(rec["ffn_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["ffn_block"]),
                             "tflops": sum(ffn_fl(d) for _, _, d in rec["ffn_block"]) / (ms * 1e-3) / 1e12}
+    if rec["stin_block"]:
+        ms = sum(a.elapsed_time(b) for a, b, _ in rec["stin_block"])
+        out["stin_block"] = {"launches": len(rec["stin_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["stin_block"]),
+                             "tflops": sum(stin_fl(d) for _, _, d in rec["stin_block"]) / (ms * 1e-3) / 1e12}
     out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
     out["gemm_conv"]["algorithmic_gflop"] = (n * fl["gemm"] - moved["gemm"]) / 1e9
     # per-shape table of this instrumented step (what tools/kernel_table.py prints from --dump-kernels)
@@ -215,6 +224,9 @@ def kernel_roofline(model, batch, B, dump=None):
             elif name == "ffn_block":
                 key = f'ffn {d["M"]}x{d["C"]} hidden{d["H"]} (ln + geglu proj + gate + linear + resid)'
                 fl_ = 6.0 * d["M"] * d["C"] * d["H"]
+            elif name == "stin_block":
+                key = f'stin {d["M"]}x{d["C"]} qkv{d["NQ"]} (proj_in + ln + q|k|v projection)'
+                fl_ = stin_fl(d)
             else:
                 key = f'attn B{d["B"]} h{d["heads"]} {d["Nq"]}x{d["Nkv"]}'
                 fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
@@ -233,6 +245,8 @@ def kernel_roofline(model, batch, B, dump=None):
                     fl_ = (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
                 elif name == "ffn_block":
                     fl_ = 6.0 * d["M"] * d["C"] * d["H"]
+                elif name == "stin_block":
+                    fl_ = stin_fl(d)
                 else:
                     fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
                 rows.append(dict(kernel=name, us=us, tflops=fl_ / us / 1e6, **d))
@@ -905,7 +919,7 @@ def main():
             res["roofline"]["frac_of_sustained_peak"] = g["tflops"] / pk["tflops_random_16x16x32"]
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
         res["kernel_table"] = kern.get("table", [])[:48]
-        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"),
+        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"), "stin_block_kernel": kern.get("stin_block"),
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline and a.workload == "single":

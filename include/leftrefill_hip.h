@@ -264,6 +264,24 @@ typedef struct lr_xattn_args {
 int lr_xattn_block_f16(const lr_xattn_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_f16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
 
+/* ---- entry of a SpatialTransformer's block (C = 320: level 0 of the SD2 UNet; ABI 24) --------------------------------------
+ * replaces: `x = self.proj_in(x)` (use_linear, attention.py:405-408) and, of the block that follows, `self.norm1(x)` (attention.py:280)
+ *           with attn1's `q = self.to_q(x); k = self.to_k(context); v = self.to_v(context)` on context = x (attention.py:168-172), in ONE
+ *           launch instead of a K = 320 GEMM and a LayerNorm-folded 960-column GEMM:
+ *               x1 = x wp^T + bp;     qkv = LayerNorm(x1) [Wq; Wk; Wv]^T
+ *   x [M][320] (the GroupNorm-ed tokens), M % 256 == 0;  wp [320][320] = proj_in.weight, bp [320] its bias (fp32);
+ *   wqkv [NQ][320] = [to_q; to_k; to_v].weight * gamma (LayerNorm folded along K, natural column order), bqkv [NQ] = W beta (fp32);
+ *      NQ a multiple of 192 (960 for the SD2 block);
+ *   x1 [M][320] and qkv [M][ld_qkv] out (x1 is rounded to 16 bits before the LayerNorm, like the two-launch path stores it).
+ * Other widths / ragged M: LR_E_UNSUPPORTED -- callers keep the two-GEMM path. */
+typedef struct lr_stin_args {
+  const lr_half* x; const lr_half* wp; const float* bp; const lr_half* wqkv; const float* bqkv;
+  lr_half* x1; lr_half* qkv;
+  int32_t M, C, NQ, ld_qkv;
+  float ln_eps;
+} lr_stin_args;
+int lr_stin_block_f16(const lr_stin_args* args, lr_stream_t s);
+
 /* ---- fused feed-forward block (C = 320: level 0 of the SD2 UNet) ------------------------------------------------------
  * replaces: `x = self.ff(self.norm3(x)) + x` (attention.py:282) = norm3 (LayerNorm), GEGLU.proj + `x * F.gelu(gate)` (attention.py:51-58),
  *           FeedForward.net[2] Linear + bias (attention.py:74-78) and the residual add, in ONE launch: the [M][H] hidden activation
@@ -418,6 +436,7 @@ int lr_transpose_v_bf16(const lr_half* v, int ldv, lr_half* vt, int ld_vt, int B
 int lr_attention_bwd_bf16(const lr_attn_bwd_args* a, lr_stream_t s);
 int lr_xattn_block_bf16(const lr_xattn_args* args, lr_stream_t s);
 int lr_ffn_block_bf16(const lr_ffn_args* args, lr_stream_t s);
+int lr_stin_block_bf16(const lr_stin_args* args, lr_stream_t s);
 int lr_xattn_pack_vt_bf16(const lr_half* v, int ldv, lr_half* vt, int B, int heads, int Lc, lr_stream_t s);
 
 /* ==== developer builds only (-DLR_DEV_VARIANTS, tools/build_variant.sh) ==================================================================

@@ -40,3 +40,20 @@ __device__ __forceinline__ vec8<T> xa_pack(const f32x4& a, const f32x4& b) {
 }
 // xattn_block640.hip: the C = 640 / 10-head instance of lr_xattn_block_f16 (64-row blocks, 4 waves); arguments already checked
 int lr_xattn640_launch(const lr_xattn_args* a, int bf16_, lr_stream_t s);
+
+// Two swapped-form accumulator tiles (A = columns 16 j .., B = columns 16 (j + 1) .. of the same 16 rows; lane (fr, fq) holds columns
+// 4 fq .. + 3 of row fr in each) -> after the exchange the lane owns EIGHT consecutive columns of row fr: columns
+// 16 (j + (fq & 1)) + 8 (fq >> 1) .. + 7, in (a[0..3], b[0..3]) (the register epilogue of gemm_common.h: one 16-byte store per lane).
+__device__ __forceinline__ void xa_swap_rows16(f32x4& a, f32x4& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ar = a[r], br = b[r];
+    const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ar), __builtin_bit_cast(unsigned, br), false, false);
+    a[r] = __builtin_bit_cast(float, (unsigned)s[0]);
+    b[r] = __builtin_bit_cast(float, (unsigned)s[1]);
+  }
+#endif
+}
+
+// stin_block.hip: entry of a SpatialTransformer at C = 320 (proj_in + LayerNorm + fused q|k|v projection in one launch)

@@ -347,9 +347,10 @@ def attention_plain(x, ctx, pa: PackedAttn, B, L, Lc=None):
     return linear(a, pa.out)
 
 
-def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False):
-    """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None)."""
-    qkv = ln_linear(x, st, pn, pa.qkv)
+def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None):
+    """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None); qkv: the projection when its producer already
+    made it (ops.stin_block)."""
+    qkv = ln_linear(x, st, pn, pa.qkv) if qkv is None else qkv
     a = ops.attention_qkv(qkv, B, pa.heads, L, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
@@ -378,7 +379,7 @@ def ffn_fused(x, pt, rows=None, ctx=None):
 XATTN_PRE = __import__("os").environ.get("LEFTREFILL_XATTN_PRE", "1") != "0"
 
 
-def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False):
+def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False, qkv0=None):
     """attn1 and attn2 of a plain (single-view) block with the self-attention's out-projection fused into the cross-attention launch:
     LayerNorm-folded QKV GEMM -> flash attention -> ONE kernel for  x1 = a Wo1 + b + x;  x2 = x1 + to_out(attention(LN(x1) Wq, K, V)).
     dup: x holds the first N / 2 samples of a CFG batch whose halves are still identical: projection and self-attention run on them
@@ -386,11 +387,11 @@ def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False):
     pa1, pa2 = pt.attn1, pt.attn2
     if dup:
         with plan_batch_scale(2):
-            qkv = ln_linear(x, st, pt.n1, pa1.qkv)
+            qkv = ln_linear(x, st, pt.n1, pa1.qkv) if qkv0 is None else qkv0
         a = dup2(ops.attention_qkv(qkv, N // 2, pa1.heads, L, pa1.dim_head ** -0.5))
         x = dup2(x)
     else:
-        qkv = ln_linear(x, st, pt.n1, pa1.qkv)
+        qkv = ln_linear(x, st, pt.n1, pa1.qkv) if qkv0 is None else qkv0
         a = ops.attention_qkv(qkv, N, pa1.heads, L, pa1.dim_head ** -0.5)
     return ops.xattn_block(x, pa2.xq_pi, pa2.q.bf, kv[2], kv[3], pa2.xwo, pa2.out.b, HW=L, heads=pa2.heads, Lc=Lc, eps=pa2.q.eps,
                            scale=pa2.dim_head ** -0.5, want_stats=want_stats, pre=(a, pa1.out.w, pa1.out.b))
@@ -422,11 +423,12 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False, post=None):
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False, post=None, qkv0=None):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468.
     st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
     dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
-    self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix)."""
+    self-attention and the cross-attention's query projection run on them once (see UNetModel.cfg_shared_prefix).
+    qkv0 (single-view blocks): the fused q|k|v projection of LayerNorm(x) when the producer of x already made it (ops.stin_block)."""
     # The two fused-block decisions are taken ONCE per block (ADVICE r3): they steer which producers emit row statistics, so every
     # consumer below must see the same answer.  (Both are pure functions of shapes, switches and the autograd state.)
     use_xattn = xattn_fused(x, pt.attn2, N, L, Lc, kv)
@@ -435,14 +437,14 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     ws = fold_ok(x) and not use_xattn
     if pt.view_num is None and XATTN_PRE and use_xattn and pt.attn1.out.b is not None:
         ws = fold_ok(x) and not use_ffn
-        x = self_then_cross_attention(x, st, pt, N, L, Lc, kv, ws, dup=dup)
+        x = self_then_cross_attention(x, st, pt, N, L, Lc, kv, ws, dup=dup, qkv0=qkv0)
         x, st = x if ws else (x, None)
         return _ffn(x, st, pt, want_stats, post, use_ffn)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
-            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws)
+            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws, qkv=qkv0)
     elif pt.view_num is None:
-        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws)
+        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws, qkv=qkv0)
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
         x = _mv_sharded_self_attention(x, pt, N, L, st)
         ws = False
@@ -626,6 +628,19 @@ def st_gn_fold_ok(x_in, act: Act, gs_in, ps: PackedST):
             and x_in.shape[0] >= 2 * act.N * C and act.HW % 256 == 0 and ps.proj_in.w.shape == (C, C))
 
 
+# proj_in + LayerNorm + q|k|v projection of a SpatialTransformer's first block as one launch (level 0); LEFTREFILL_STIN=0 keeps the two GEMMs
+STIN = __import__("os").environ.get("LEFTREFILL_STIN", "1") != "0"
+
+
+def stin_fused(h, ps: PackedST):
+    """Will the entry of the SpatialTransformer take the one-launch path (lr_stin_block_f16)?  Single-view blocks only: a multi-view
+    block projects the re-arranged sequence, not the rows of h."""
+    if not (STIN and ps.blocks and ps.blocks[0].view_num is None and fold_ok(h) and ps.proj_in.b is not None):
+        return False
+    pq = ps.blocks[0].attn1.qkv
+    return pq.wf is not None and ps.proj_in.w.shape == (h.shape[1], h.shape[1]) and ops.stin_ok(h.shape[0], h.shape[1], pq.wf.shape[0])
+
+
 def st_dup_ok(ps: PackedST):
     return len(ps.blocks) > 0 and ps.blocks[0].view_num is None
 
@@ -635,6 +650,7 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
     the result is the full batch."""
     x_in = act.materialize()
     gs_in = act.gs if act.tok2 is None else None
+    qkv0 = None
     with plan_batch_scale(2 if dup else 1):
         if st_gn_fold_ok(x_in, act, gs_in, ps):
             # Normalize (GroupNorm(32, eps 1e-6, affine), attention.py:399-404) folded into proj_in: per-sample weights from the
@@ -644,8 +660,15 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
             h = ops.gemm_conv(x_in, wb, B=act.N, H=1, W=act.HW, taps=1, bias=bb, per_sample=True, want_stats=True)
         else:
             h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
-            ws = fold_ok(h)
-            h = linear(h, ps.proj_in, want_stats=ws)
+            if stin_fused(h, ps):
+                # one launch: proj_in + LayerNorm + the block's fused q|k|v projection (level 0); x1 and qkv leave while the next
+                # columns multiply
+                pq = ps.blocks[0].attn1.qkv
+                h, qkv0 = ops.stin_block(h, ps.proj_in.w, ps.proj_in.b, pq.wf, pq.bf, eps=pq.eps)
+                ws = False
+            else:
+                ws = fold_ok(h)
+                h = linear(h, ps.proj_in, want_stats=ws)
     h, st = h if ws else (h, None)
     if dup:
         assert st_dup_ok(ps)
@@ -660,7 +683,8 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
             post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW)
         elif last and FF_PROJ and want and ps.ff_proj_w is not None:
             post = ("compose", ps.ff_proj_w, ps.ff_proj_b, x_in, act.HW)      # proj_out composed with the last feed-forward Linear
-        r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post)
+        r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post,
+                              qkv0=qkv0 if i == 0 else None)
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
             return Act(r[1], act.N, act.H, act.W, gs=r[2])
         h, st = r

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import FfnArgs, GemmArgs, XattnArgs
+from ._lib import FfnArgs, GemmArgs, StinArgs, XattnArgs
 
 GN_CHUNKS = 256
 # per-group GroupNorm partials from the producers' epilogues (no lr_groupnorm_finalize launch); LEFTREFILL_GN_GROUPS=0 keeps the
@@ -602,6 +602,35 @@ def xattn_block(x, wq, bq, k, vt, wo, bo, *, HW, heads, Lc, eps, scale, want_sta
         a.pre_a, a.pre_w, a.pre_b = _p(pa_), _p(pw_), _p(pb_)
     _lib.check(_fn(lib, "lr_xattn_block_f16", x.dtype)(a, _stream()), "xattn_block")
     return (out, stats) if want_stats else out
+
+
+STIN_C, STIN_ROWS = 320, 256
+
+
+def stin_ok(M, C, NQ):
+    """Shapes lr_stin_block_f16 takes (everything else keeps the proj_in GEMM -> LayerNorm-folded q|k|v GEMM path)."""
+    return C == STIN_C and M % STIN_ROWS == 0 and NQ > 0 and NQ % 192 == 0 and NQ <= 4096
+
+
+def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None):
+    """x1 = x wp^T + bp;  qkv = LayerNorm(x1) wqkv^T + bqkv  in one launch (lr_stin_block_f16): SpatialTransformer.proj_in and the
+    LayerNorm-folded fused q|k|v projection of its block's self-attention.  wqkv / bqkv: packing.fold_layernorm of [to_q; to_k; to_v]
+    (natural column order).  Returns (x1 [M, C], qkv [M, NQ])."""
+    lib = _lib.load()
+    _chk16(x, "x")
+    M, C = x.shape
+    NQ = wqkv.shape[0]
+    assert stin_ok(M, C, NQ), (M, C, NQ)
+    assert wp.dtype == x.dtype and wp.is_contiguous() and wp.shape == (C, C) and wqkv.dtype == x.dtype and wqkv.is_contiguous() and wqkv.shape == (NQ, C)
+    assert bp.dtype == torch.float32 and bp.numel() == C and bqkv.dtype == torch.float32 and bqkv.numel() == NQ
+    x1 = torch.empty_like(x) if out is None else out
+    qkv = torch.empty(M, NQ, device=x.device, dtype=x.dtype) if qkv_out is None else qkv_out
+    assert x1.shape == x.shape and x1.is_contiguous() and qkv.shape == (M, NQ) and qkv.stride(1) == 1 and qkv.dtype == x.dtype
+    a = StinArgs()
+    a.x, a.wp, a.bp, a.wqkv, a.bqkv, a.x1, a.qkv = _p(x), _p(wp), _p(bp), _p(wqkv), _p(bqkv), _p(x1), _p(qkv)
+    a.M, a.C, a.NQ, a.ld_qkv, a.ln_eps = M, C, NQ, qkv.stride(0), float(eps)
+    _lib.check(_fn(lib, "lr_stin_block_f16", x.dtype)(a, _stream()), "stin_block")
+    return x1, qkv
 
 
 FFN_C, FFN_ROWS, FFN_MAX_H = 320, 128, 2048

@@ -376,6 +376,12 @@ def ffn_block(*a, **k):
     return ops.ffn_block(*a, **k)
 
 
+def stin_block(*a, **k):
+    """Fused SpatialTransformer entry (proj_in + LayerNorm + q|k|v): inference only, looked up on `ops` at call time (see xattn_block)."""
+    assert not _needs_grad(a[0])
+    return ops.stin_block(*a, **k)
+
+
 def mv_gather(x, b, v, s):
     return _MvGather.apply(x, b, v, s) if _needs_grad(x) else ops.mv_gather(x, b, v, s)
 
