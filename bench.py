@@ -131,9 +131,9 @@ def kernel_roofline(model, batch, B, dump=None):
     x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
     t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
     ctx = torch.cat([uc_cross, c_cross]).half()
-    rec = {"gemm_conv": [], "attention": [], "xattn_block": [], "ffn_block": [], "stin_block": []}
+    rec = {"gemm_conv": [], "attention": [], "xattn_block": [], "ffn_block": [], "stin_block": [], "rowlin": []}
     orig = {"gemm_conv": ops.gemm_conv, "attention": ops.attention, "xattn_block": ops.xattn_block, "ffn_block": ops.ffn_block,
-            "stin_block": ops.stin_block}
+            "stin_block": ops.stin_block, "rowlin": ops.rowlin}
 
     def wrap(name):
         def f(*a, **k):
@@ -151,6 +151,8 @@ def kernel_roofline(model, batch, B, dump=None):
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], H=a[3].shape[0] * 64)
             elif name == "stin_block":       # fused proj_in + LayerNorm + q|k|v projection (level 0)
                 desc = dict(M=a[0].shape[0], C=a[0].shape[1], NQ=a[3].shape[0])
+            elif name == "rowlin":           # row-resident LayerNorm + Linear (level 1: q|k|v, GEGLU)
+                desc = dict(M=a[0].shape[0], C=a[0].shape[1], N=a[1].shape[0], geglu=int(bool(k.get("geglu", False))))
             else:
                 desc = dict(B=a[3], heads=a[4], Nq=a[5], Nkv=a[6])
             rec[name].append((e0, e1, desc))
@@ -189,7 +191,7 @@ def kernel_roofline(model, batch, B, dump=None):
     xl_fl = lambda d: (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"]      # to_q + to_out (+ the self-attention's out-projection)
     stin_fl = lambda d: 2.0 * d["M"] * d["C"] * (d["C"] + d["NQ"])      # proj_in + the fused q|k|v projection
     moved = {"gemm": sum(xl_fl(d) for _, _, d in rec["xattn_block"]) + sum(ffn_fl(d) for _, _, d in rec["ffn_block"])
-                     + sum(stin_fl(d) for _, _, d in rec["stin_block"]),
+                     + sum(stin_fl(d) for _, _, d in rec["stin_block"]) + sum(2.0 * d["M"] * d["C"] * d["N"] for _, _, d in rec["rowlin"]),
              "attn": sum(4.0 * d["M"] * d["Lc"] * d["C"] for _, _, d in rec["xattn_block"])}
     for name, key in (("gemm_conv", "gemm"), ("attention", "attn")):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec[name])
@@ -208,6 +210,10 @@ def kernel_roofline(model, batch, B, dump=None):
         ms = sum(a.elapsed_time(b) for a, b, _ in rec["stin_block"])
         out["stin_block"] = {"launches": len(rec["stin_block"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["stin_block"]),
                              "tflops": sum(stin_fl(d) for _, _, d in rec["stin_block"]) / (ms * 1e-3) / 1e12}
+    if rec["rowlin"]:
+        ms = sum(a.elapsed_time(b) for a, b, _ in rec["rowlin"])
+        out["rowlin"] = {"launches": len(rec["rowlin"]), "total_ms": ms, "avg_us": 1e3 * ms / len(rec["rowlin"]),
+                         "tflops": sum(2.0 * d["M"] * d["C"] * d["N"] for _, _, d in rec["rowlin"]) / (ms * 1e-3) / 1e12}
     out["gemm_conv"]["algorithmic_bytes_per_launch"] = gbytes / max(1, len(rec["gemm_conv"]))
     out["gemm_conv"]["algorithmic_gflop"] = (n * fl["gemm"] - moved["gemm"]) / 1e9
     # per-shape table of this instrumented step (what tools/kernel_table.py prints from --dump-kernels)
@@ -215,24 +221,36 @@ def kernel_roofline(model, batch, B, dump=None):
     for name in rec:
         for a, b, d in rec[name]:
             us = 1e3 * a.elapsed_time(b)
+            # by_ = algorithmic HBM bytes of the launch: every operand read once, every output written once (16-bit elements)
             if name == "gemm_conv":
                 key = f'gemm {d["M"]}x{d["N"]}x{d["K"]} taps{d["taps"]} s{d["stride"]} up{d["up"]}' + (" geglu" if d["geglu"] else "") + (" cat" if d["cat"] else "")
                 fl_ = 2.0 * d["M"] * d["N"] * d["K"]
+                src_rows = d["M"] * (4 if d["stride"] == 2 else 1) / (4 if d["up"] else 1)
+                by_ = 2.0 * (src_rows * d["K"] / d["taps"] + d["N"] * d["K"] + d["M"] * (d["N"] // 2 if d["geglu"] else d["N"]) * (2 if d["resid"] else 1))
             elif name == "xattn_block":
                 key = f'xattn {d["M"]}x{d["C"]} keys{d["Lc"]} (' + ("attn1.to_out + resid + " if d["pre"] else "") + 'ln + to_q + attention + to_out + resid)'
                 fl_ = (4.0 + 2.0 * d["pre"]) * d["M"] * d["C"] * d["C"] + 4.0 * d["M"] * d["Lc"] * d["C"]
+                by_ = 2.0 * d["M"] * d["C"] * (2 + d["pre"]) + 2.0 * (2 + d["pre"]) * d["C"] * d["C"]
             elif name == "ffn_block":
                 key = f'ffn {d["M"]}x{d["C"]} hidden{d["H"]} (ln + geglu proj + gate + linear + resid)'
                 fl_ = 6.0 * d["M"] * d["C"] * d["H"]
+                by_ = 2.0 * d["M"] * d["C"] * 3 + 2.0 * 3 * d["C"] * d["H"]
             elif name == "stin_block":
                 key = f'stin {d["M"]}x{d["C"]} qkv{d["NQ"]} (proj_in + ln + q|k|v projection)'
                 fl_ = stin_fl(d)
+                by_ = 2.0 * d["M"] * (2 * d["C"] + d["NQ"]) + 2.0 * d["C"] * (d["C"] + d["NQ"])
+            elif name == "rowlin":
+                key = f'rowlin {d["M"]}x{d["N"]}x{d["C"]} (ln + linear' + (" + geglu gate)" if d["geglu"] else ")")
+                fl_ = 2.0 * d["M"] * d["C"] * d["N"]
+                by_ = 2.0 * d["M"] * (d["C"] + (d["N"] // 2 if d["geglu"] else d["N"])) + 2.0 * d["C"] * d["N"]
             else:
                 key = f'attn B{d["B"]} h{d["heads"]} {d["Nq"]}x{d["Nkv"]}'
                 fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
-            e = agg.setdefault(key, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += us; e[2] += fl_
-    out["table"] = [dict(shape=k, n=v[0], total_us=round(v[1], 1), avg_us=round(v[1] / v[0], 1), tflops=round(v[2] / v[1] / 1e6, 1))
+                by_ = 2.0 * d["B"] * d["heads"] * 64 * (2 * d["Nq"] + 2 * d["Nkv"])
+            e = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += us; e[2] += fl_; e[3] += by_
+    out["table"] = [dict(shape=k, n=v[0], total_us=round(v[1], 1), avg_us=round(v[1] / v[0], 1), tflops=round(v[2] / v[1] / 1e6, 1),
+                         gflop=round(v[2] / v[0] / 1e9, 3), alg_mb=round(v[3] / v[0] / 1e6, 2))
                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
     if dump:
         rows = []
@@ -247,6 +265,8 @@ def kernel_roofline(model, batch, B, dump=None):
                     fl_ = 6.0 * d["M"] * d["C"] * d["H"]
                 elif name == "stin_block":
                     fl_ = stin_fl(d)
+                elif name == "rowlin":
+                    fl_ = 2.0 * d["M"] * d["C"] * d["N"]
                 else:
                     fl_ = 4.0 * d["B"] * d["heads"] * d["Nq"] * d["Nkv"] * 64
                 rows.append(dict(kernel=name, us=us, tflops=fl_ / us / 1e6, **d))
@@ -701,7 +721,140 @@ def measure_traffic(launches):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def dist_selftest(rank, world, device, backend, share):
+    """First-contact checks of the multi-GPU job, before anything is timed: every stage is a named entry, the first
+    failure is what the JSON line reports.  Semantics the collectives must reproduce: the all-gather before the re-arranged cross-view
+    self-attention (reference ldm/modules/multiview_attention.py:436-462) and the sample sharding of configs[2]."""
+    import torch.distributed as dist
+    st = {}
+
+    def stage(name, fn):
+        try:
+            if os.environ.get("LR_BENCH_SELFTEST_FAIL") == name:      # test hook: tests/test_gpu_bench.py checks the error line
+                raise RuntimeError("forced failure (LR_BENCH_SELFTEST_FAIL)")
+            st[name] = fn()
+        except Exception as e:      # noqa: BLE001
+            st[name] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+        return bool(st[name].get("ok"))
+
+    def world_size():
+        return {"ok": dist.get_world_size() == world and dist.get_rank() == rank, "world": dist.get_world_size(), "backend": backend}
+
+    def stamp():      # all-gather of a rank-stamped tensor: every slot must carry its rank, in rank order
+        mine = torch.full((4,), float(rank), device=device)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        vals = [int(g[0].item()) for g in got]
+        return {"ok": vals == list(range(world)) and all(bool((g == g[0]).all()) for g in got), "ranks_seen": vals}
+
+    def into_tensor():      # the collective the sharded multi-view block uses (dist.mv_all_gather_rows): all_gather_into_tensor of fp16 rows
+        mine = torch.full((8, 64), float(rank + 1), device=device, dtype=torch.float16)
+        out = torch.empty(world * 8, 64, device=device, dtype=torch.float16)
+        dist.all_gather_into_tensor(out, mine)
+        want = torch.arange(1, world + 1, device=device, dtype=torch.float16).repeat_interleave(8)[:, None].expand(-1, 64)
+        return {"ok": bool(torch.equal(out, want))}
+
+    def reduce_sum():
+        v = torch.tensor([float(rank + 1)], device=device, dtype=torch.float64)
+        dist.all_reduce(v)
+        return {"ok": abs(v.item() - world * (world + 1) / 2) < 1e-9, "sum": v.item()}
+
+    def devices():      # one GPU per rank (unless the 1-GPU test hook shares cuda:0): no two ranks on the same device
+        if device.type == "cuda":
+            p = torch.cuda.get_device_properties(device)
+            ident = f"{torch.cuda.current_device()}:{getattr(p, 'uuid', '')}:{getattr(p, 'pci_bus_id', '')}"
+        else:      # (CPU ranks of tests/test_host_cpu.py)
+            ident = f"cpu:{rank}"
+        objs = [None] * world
+        dist.all_gather_object(objs, ident)
+        return {"ok": share or len(set(objs)) == world, "devices": objs, "shared_gpu_test_hook": bool(share)}
+
+    for name, fn in (("world_size", world_size), ("all_gather_rank_stamp", stamp), ("all_gather_into_tensor_f16", into_tensor),
+                     ("all_reduce_sum", reduce_sum), ("device_uniqueness", devices)):
+        if not stage(name, fn):
+            return {"ok": False, "failed_stage": name, "stages": st}
+    return {"ok": True, "stages": st}
+
+
+def mv_graph_selftest(model, batch, B):
+    """Sharded multi-view job: the captured hipGraph of the step (with its collectives inside) must replay to what the eager step gives
+    on the first step.  Under the gloo test hook the step is eager either way; the comparison then only exercises the code path."""
+    unet = model.model.diffusion_model
+    c_concat, c_cross, uc_cross, x_T = batch
+    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+    t = torch.full((2 * B,), 501, device=x.device, dtype=torch.long)
+    ctx = torch.cat([uc_cross, c_cross]).half()
+    with torch.no_grad():
+        prev = unet.use_hip_graph
+        unet.use_hip_graph = False
+        try:
+            eager = unet(x, t, ctx).float()
+        finally:
+            unet.use_hip_graph = prev
+        g1 = unet(x, t, ctx).float()
+        g2 = unet(x, t, ctx).float()
+    torch.cuda.synchronize()
+    d1, d2 = (g1 - eager).abs().max().item(), (g2 - g1).abs().max().item()
+    fin = bool(torch.isfinite(g1).all())
+    return {"ok": fin and d1 == 0.0 and d2 == 0.0, "max_abs_graph_vs_eager": d1, "max_abs_replay_vs_replay": d2, "finite": fin,
+            "graph_captured": bool(prev and getattr(unet, "mv_shard_graph", False))}
+
+
+def batch_sensitivity(model, h, w, device, Bs=(1, 2, 8), n=12, warm=3):
+    """Extra key, not the metric: HIP-event time of ONE graph-replayed UNet forward at other per-GPU batches B (UNet batch
+    2B under CFG), its whole-step fraction of the dense-fp16 MFMA peak, and how many GEMM shapes of that batch are not in the in-tree tile
+    table (they take the library's static heuristic)."""
+    from leftrefill_amd import ops
+    from leftrefill_amd.flops import unet_flops
+    unet = model.model.diffusion_model
+    out = {}
+    for B in Bs:
+        batch = synthetic_batch(B, h, w, device, 4242 + B)
+        c_concat, c_cross, uc_cross, x_T = batch
+        x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+        t = torch.full((2 * B,), 501, device=device, dtype=torch.long)
+        ctx = torch.cat([uc_cross, c_cross]).half()
+        ops.TABLE_MISSES.clear()
+        ops.TABLE_HITS.clear()
+        evs = []
+        with torch.no_grad():
+            for i in range(warm + n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                unet(x, t, ctx)
+                e1.record()
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs[warm:])
+        ms = ts[len(ts) // 2]
+        fl = unet_flops(unet, x.shape[2], x.shape[3])
+        tf = 2 * B * fl["total"] / (ms * 1e-3) / 1e12
+        out[f"B{B}"] = {"unet_batch": 2 * B, "unet_forward_ms_median": ms, "ms_per_sample": ms / B, "tflops": tf, "frac_of_mfma_peak": tf / 2500.0,
+                        "gemm_shapes": len(ops.TABLE_MISSES) + len(ops.TABLE_HITS), "gemm_shapes_not_in_tile_table": len(ops.TABLE_MISSES)}
+    return out
+
+
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001  -- a multi-GPU failure must be diagnosable from the JSON line alone
+        import traceback
+        rank = int(os.environ.get("RANK", "0"))
+        err = {"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": None, "unit": "images/s",
+               "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": {"stage": _STAGE[0], "rank": rank, "type": type(e).__name__,
+                                                                         "detail": str(e)[:500], "traceback_tail": traceback.format_exc()[-1500:]}}
+        if rank == 0 or _STAGE[0] in ("init_process_group", "selftest"):
+            print(json.dumps(err), flush=True)
+        print(f"[bench rank {rank}] failed in stage {_STAGE[0]}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.exit(1)
+
+
+_STAGE = ["arguments"]
+
+
+def _main():
     global S_DDIM
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -727,6 +880,10 @@ def main():
                     help="single workload with B < #GPUs: the unconditional / conditional UNet passes of the same samples on rank "
                          "pairs (2 j, 2 j + 1), one all-gather of the eps halves per DDIM step")
     ap.add_argument("--ddim-steps", type=int, default=S_DDIM, help="DDIM steps per sampling (the metric is quoted at 50)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="multi-GPU first-contact checks before timing (run automatically when --gpus > 1; this flag also runs them, "
+                         "trivially, at --gpus 1 and adds the graph-vs-eager comparison of the sharded multi-view step)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the batch-sensitivity side measurement (B = 1, 2, 8 per GPU)")
     ap.add_argument("--task", default="nvs", choices=["nvs", "refill"],
                     help="train workload: nvs = BASELINE configs[4] as stated (NVSLDM, prompt tokens + pose MLP); refill = RefInpaintLDM tokens only")
     a = ap.parse_args()
@@ -749,6 +906,8 @@ def main():
         raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: one rank per GPU, the two must agree")
     S_DDIM = a.ddim_steps
     backend = None
+    selftest = None
+    _STAGE[0] = "init_process_group"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -766,11 +925,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == a.gpus
         backend = dist.get_backend()
+        _STAGE[0] = "selftest"
+        selftest = dist_selftest(rank, world, torch.device("cuda", torch.cuda.current_device()), backend, share)
+        if not selftest["ok"]:      # every rank prints its own view: the collective that would gather them is what failed
+            print(json.dumps({"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": None,
+                              "unit": "images/s", "n_gpus": world,
+                              "error": {"stage": "selftest:" + selftest["failed_stage"], "rank": rank, "selftest": selftest}}), flush=True)
+            sys.exit(1)
     else:
         torch.cuda.set_device(0)
+        if a.selftest:
+            selftest = {"ok": True, "stages": {}, "note": "single GPU: no collectives to check"}
     device = torch.device("cuda", torch.cuda.current_device())
+    _STAGE[0] = "workload"
     if a.workload == "train":
+        _STAGE[0] = "train workload"
         res = train_bench(a, rank, world, device)
+        if selftest is not None:
+            res["selftest"] = selftest
         if rank == 0:
             print(json.dumps(res))
         if world > 1:
@@ -806,6 +978,7 @@ def main():
         torch.manual_seed(4321 + rank // 2)
         torch.cuda.manual_seed(4321 + rank // 2)
 
+    _STAGE[0] = "build_model"
     model = build_model(device, a.workload)
     batch = synthetic_batch(B, h, w, device, seed)
     if a.mv_shard:
@@ -821,12 +994,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if a.mv_shard and world > 1 and (a.selftest or backend == "nccl"):
+        _STAGE[0] = "selftest:mv_graph_vs_eager"
+        mvs = mv_graph_selftest(model, batch, B)
+        flags = [None] * world
+        torch.distributed.all_gather_object(flags, bool(mvs["ok"]))
+        selftest["stages"]["mv_graph_vs_eager"] = dict(mvs, ranks_ok=flags)
+        if not all(flags):
+            selftest.update(ok=False, failed_stage="mv_graph_vs_eager")
+            if rank == 0:
+                print(json.dumps({"metric": "multi-view samples/sec", "value": None, "unit": "samples/s", "n_gpus": world,
+                                  "error": {"stage": "selftest:mv_graph_vs_eager", "selftest": selftest}}), flush=True)
+            sys.exit(1)
     # one-time preparation, like building the model: tile autotune + hipGraph capture for this shape (a 4-step sampling),
     # so that --warmup 0 does not put them inside the timed region
+    _STAGE[0] = "prepare (first sampling: hipGraph capture)"
     sample_once(model, batch, B, steps=4)
+    _STAGE[0] = "warmup"
     for _ in range(a.warmup):
         sample_once(model, batch, B)
     barrier()
+    _STAGE[0] = "timed region"
     hw = HwSampler(device).start() if rank == 0 else None      # shader clock / socket power over exactly the timed region
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -839,6 +1027,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all()
+    _STAGE[0] = "report"
     ms_per_step = 1e3 * dt / a.steps
     images_per_s = replicas * samples_per_step * a.steps / dt
     unet_step_ms = ms_per_step / S_DDIM     # per DDIM iteration (UNet step at batch 2B + fused update), incl. host loop
@@ -856,6 +1045,8 @@ def main():
                               "context (3.9 of 1850 GFLOP per sample per forward, 0.2 %) and the timestep-embedding rows (time MLP + the 22 emb_layers: functions "
                               "of the schedule alone, 50 rows in 4 batched launches; LEFTREFILL_EMB_TABLE=0 recomputes them every step, +0.09 ms per step)"},
            "per_unet_step_ms": unet_step_ms}
+    if selftest is not None:
+        res["selftest"] = selftest
     if a.workload != "single":
         res["config"]["workload"] = (f"config 4 ({a.workload}): {MV_WORKLOADS[a.workload]}, {samples_per_step} sample(s) = {B} "
                                      f"canvases per GPU (UNet batch {2 * B}), {S_DDIM} DDIM steps, cfg=2.5, eta=1.0, fp16")
@@ -918,8 +1109,8 @@ def main():
         if pk.get("tflops_random_16x16x32"):
             res["roofline"]["frac_of_sustained_peak"] = g["tflops"] / pk["tflops_random_16x16x32"]
         step_tflops = 2 * B * fl["total"] / (unet_step_ms * 1e-3) / 1e12
-        res["kernel_table"] = kern.get("table", [])[:48]
-        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"), "stin_block_kernel": kern.get("stin_block"),
+        res["kernel_table"] = kern.get("table", [])[:64]
+        res["kernels"] = {"attention_kernel": kern["attention"], "xattn_block_kernel": kern.get("xattn_block"), "ffn_block_kernel": kern.get("ffn_block"), "stin_block_kernel": kern.get("stin_block"), "rowlin_kernel": kern.get("rowlin"),
                           "unet_step": {"algorithmic_tflop": 2 * B * fl["total"] / 1e12, "ms": unet_step_ms,
                                         "tflops": step_tflops, "frac_of_mfma_peak": step_tflops / MFMA_PEAK_TFLOPS}}
     if rank == 0 and not a.no_roofline and a.workload == "single":
@@ -950,6 +1141,8 @@ def main():
         if a.workload == "single":
             side("cfg_shared_prefix", shared_prefix)
         side("unet_step_events", lambda: unet_step_events(model, batch, B))
+        if world == 1 and not a.no_batch_sweep:
+            side("batch_sensitivity", lambda: batch_sensitivity(model, h, w, device))
         side("vae_512x1024", lambda: vae_timing(B, device))
         v = res["vae_512x1024"]
         if "error" not in v:

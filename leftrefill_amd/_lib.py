@@ -77,6 +77,12 @@ class StinArgs(ctypes.Structure):
                 ("ln_eps", ctypes.c_float)]
 
 
+class RowlinArgs(ctypes.Structure):
+    """struct lr_rowlin_args (include/leftrefill_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("N", ctypes.c_int32), ("ld_out", ctypes.c_int32), ("geglu", ctypes.c_int32), ("ln_eps", ctypes.c_float)]
+
+
 class FfnArgs(ctypes.Structure):
     """struct lr_ffn_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
@@ -131,6 +137,7 @@ SIGNATURES = {
     "lr_xattn_pack_vt_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "lr_ffn_block_f16": [ctypes.POINTER(FfnArgs), c_void_p],
     "lr_stin_block_f16": [ctypes.POINTER(StinArgs), c_void_p],
+    "lr_rowlin_f16": [ctypes.POINTER(RowlinArgs), c_void_p],
     "lr_mv_gather": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_row_copy": [c_void_p, c_int, c_void_p],
     "lr_gemm_splitk_timeouts": [],
@@ -145,7 +152,7 @@ BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n"
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
               "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",
-              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_stin_block_f16", "lr_gn_conv_out_f16"]
+              "lr_xattn_pack_vt_f16", "lr_ffn_block_f16", "lr_stin_block_f16", "lr_rowlin_f16", "lr_gn_conv_out_f16"]
 
 
 def twin(name):

@@ -14,11 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libleftrefill_hip.so")
-SOURCES = ["norm.hip", "elementwise.hip", "gemm_conv.hip", "conv_halo.hip", "attention.hip", "attention_bwd.hip", "xattn_block.hip", "xattn_block640.hip", "stin_block.hip", "ffn_block.hip", "conv_out.hip"]
+SOURCES = ["norm.hip", "elementwise.hip", "gemm_conv.hip", "conv_halo.hip", "attention.hip", "attention_bwd.hip", "xattn_block.hip", "xattn_block640.hip", "stin_block.hip", "rowlin.hip", "ffn_block.hip", "conv_out.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # attention: keep MFMA accumulators in VGPRs -- the softmax VALU stream reads every S^T value and rescales O, and
 # AGPR accumulators cost ~150 v_accvgpr_read/write per 64-key tile.
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "xattn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "ffn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "stin_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "xattn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "ffn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "stin_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "rowlin.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():

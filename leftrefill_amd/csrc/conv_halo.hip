@@ -305,6 +305,7 @@ int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
       P.wt_bstride || P.st_out || ((P.H & 15) && !(P.H == 8 && P.M % 256 == 0)) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
     return LR_E_UNSUPPORTED;
   if ((long long)P.M >= (1ll << 28)) return LR_E_UNSUPPORTED;      // the patch loader packs (pixel index | chunk << 28) into one register
+  if (P.splits > (P.C1 + P.C2 + P.C3 + P.C4) / 64) return LR_E_ARG;      // a K slice owns at least one 64-channel chunk
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);
   return LR_E_UNSUPPORTED;

@@ -1,0 +1,238 @@
+// Row-resident LayerNorm + Linear at C = 640 (level 1 of the SD2 UNet), for the two wide projections of a BasicTransformerBlock whose K loop
+// is only 10 K-steps long (reference ldm/modules/attention.py:280 + 168-172: norm1 + attn1.to_q / to_k / to_v, fused [3C] wide; 282 + 51-58:
+// norm3 + GEGLU.proj with `x * F.gelu(gate)`):
+//
+//     out = LayerNorm(x) W^T + b                       plain   (W = the LayerNorm-folded fused q|k|v projection, N = 1920)
+//     out = u * gelu_erf(g),  [u | g] = LN(x) W^T + b  GEGLU   (W's rows interleaved [u16 | g16 | ...] like lr_gemm_args.geglu, N = 5120 -> 2560 columns)
+//
+// The tiled GEMM runs these as 256 x 320 tiles of a 10-step loop: each tile fills its ring, multiplies for 38 % of its time and drains through
+// an epilogue (erf for the gate) with the matrix pipes idle, four tiles per CU one after the other (profiles/r05_conv_halo_proto.txt section 6).
+// Here, like stin_block.hip at C = 320: a block keeps 128 rows in registers as B operands of swapped 16x16x32 MFMAs (8 waves x 16 rows, the
+// LayerNorm two-pass in registers) and streams ITS SLICE of the weight rows -- grid = (M / 128) row blocks x ny column slices, 256 blocks at
+// M = 16384 with ny = 2 -- through a 3-slot ring of 40 KB steps (64 weight rows x one k half; two steps per 64-column piece), one barrier per
+// step, no fill / drain between pieces; a piece's four accumulator tiles are emitted (bias, gate, 16 bits, permlane swap, 16-byte stores)
+// WHILE the next piece multiplies.  Weight bytes through the LDS are the same as the tiled GEMM's (every block streams its slice once per
+// 128 rows); what goes away are the per-tile bubbles.
+#include "chain_common.h"
+
+#define RL_C 640
+#define RL_ROWS 128
+#define RL_THREADS 512
+#define RL_SLOT 40960
+#define RL_MAX_SLICE 2560      // weight rows per block whose bias fits the LDS region behind the ring
+
+struct RowlinParams {
+  const void* x; const void* w; const float* bias; void* out;
+  int M, N, ld_out, ny, np;    // np = 64-row pieces per block = N / (64 ny)
+  float eps;
+};
+
+template <typename T, bool GEGLU>
+__global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = RL_C, KL = C / 64;      // 10 sub-tiles of 64 k, 5 per step
+  constexpr int S = GEGLU ? 1 : 2;          // 16-byte stores per lane and piece
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* par = reinterpret_cast<float*>(smem + 3 * RL_SLOT);      // bias of this block's weight rows
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int odd = fq & 1, ch8 = (fq >> 1) * 8;
+  const int rb = blockIdx.x / P.ny, y = blockIdx.x - rb * P.ny;
+  const int m_w0 = rb * RL_ROWS + w * 16;
+  const int np = P.np;
+  const int g_base = y * np;                // first piece (64 weight rows) of this block's slice
+  const int j0 = rb % np;                   // the order of the pieces is free: neighbouring row blocks start at different pieces
+
+  // ---- the wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 32 u + 8 fq .. + 7]
+  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 8 * fq;
+  vec8<T> xf[KL][2];
+#pragma unroll
+  for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
+  for (int i = t; i < np * 16; i += RL_THREADS)       // bias rows of the slice -> LDS (no register loads inside the loop below)
+    *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(P.bias + (size_t)g_base * 64 + 4 * i);
+
+  // ---- weight ring: step (piece g, k half kh) = rows 64 g .. + 63, columns 320 kh .. + 319 as five [64 x 64 k] sub-tiles; 5 LDS-DMA per wave
+  const __amdgpu_buffer_rsrc_t rsW = uniform_rsrc(P.w, (size_t)P.N * C * 2);
+  const unsigned OOB = 0x80000000u;
+  const int lrow = w * 8 + (lane >> 3);
+  const int lchunk = (lane & 7) ^ ((lrow >> 1) & 7);
+  const unsigned vrow = (unsigned)((lrow * C + lchunk * 8) * 2);
+  auto issue = [&](int slot, int g, int kh, int i, bool live) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(smem + slot * RL_SLOT + (i * 64 + w * 8) * 128), 16, live ? vrow : OOB,
+                                             (g * 64 * C + 320 * kh + i * 64) * 2, 0, 0);
+  };
+  auto piece_of = [&](int j) -> int { const int q = j0 + j; return g_base + (q < np ? q : q - np); };
+  {
+    const int g0 = piece_of(0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) issue(0, g0, 0, i, true);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) issue(1, g0, 1, i, true);
+  }
+
+  // ---- LayerNorm of the rows in registers (two-pass; gamma / beta live in W / bias)
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (float)xf[t5][u][i];
+    const float mean = xa_row4_sum(s) * (1.0f / C);
+#pragma unroll
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[t5][u]));      // (convert again per pass: keeps 160 floats out of the register file)
+    float q2 = 0.f;
+#pragma unroll
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = (float)xf[t5][u][i] - mean; q2 = fmaf(d, d, q2); }
+    const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[t5][u]));
+#pragma unroll
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[t5][u][i] = (T)fmaf((float)xf[t5][u][i], rstd, nmr);
+  }
+
+  const int sw = (fr >> 1) & 7;
+  auto frag = [&](const char* base, int row, int chunk) -> vec8<T> {
+    return *reinterpret_cast<const vec8<T>*>(base + row * 128 + ((chunk ^ sw) << 4));
+  };
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  T* outp = reinterpret_cast<T*>(P.out);
+  // emit unit u of a finished piece (local piece index lp, global g): plain -- tiles (2 u, 2 u + 1) = 32 columns; GEGLU -- the piece's 32
+  // gated columns (u = 0 only): + bias, [gate,] 16 bits, permlane swap, one 16-byte store per lane
+  auto emit_unit = [&](const f32x4 (&acc)[4], int lp, int g, int u) __attribute__((always_inline)) {
+    const float* b = par + lp * 64 + 4 * fq;
+    f32x4 a, c;
+    int col;
+    if constexpr (GEGLU) {
+      const f32x4 u0 = acc[0] + *reinterpret_cast<const f32x4*>(b), g0 = acc[1] + *reinterpret_cast<const f32x4*>(b + 16);
+      const f32x4 u1 = acc[2] + *reinterpret_cast<const f32x4*>(b + 32), g1 = acc[3] + *reinterpret_cast<const f32x4*>(b + 48);
+      const f32x2_t e0 = lr_gelu_erf2((f32x2_t){g0[0], g0[1]}), e1 = lr_gelu_erf2((f32x2_t){g0[2], g0[3]});
+      const f32x2_t e2 = lr_gelu_erf2((f32x2_t){g1[0], g1[1]}), e3 = lr_gelu_erf2((f32x2_t){g1[2], g1[3]});
+      a = (f32x4){u0[0] * e0[0], u0[1] * e0[1], u0[2] * e1[0], u0[3] * e1[1]};
+      c = (f32x4){u1[0] * e2[0], u1[1] * e2[1], u1[2] * e3[0], u1[3] * e3[1]};
+      col = g * 32 + odd * 16 + ch8;
+    } else {
+      a = acc[2 * u] + *reinterpret_cast<const f32x4*>(b + (2 * u) * 16);
+      c = acc[2 * u + 1] + *reinterpret_cast<const f32x4*>(b + (2 * u + 1) * 16);
+      col = g * 64 + (2 * u + odd) * 16 + ch8;
+    }
+    xa_swap_rows16(a, c);
+    const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    *reinterpret_cast<uint4*>(outp + (size_t)(m_w0 + fr) * P.ld_out + col) = lr_pack8<T>(v);
+  };
+
+#define RL_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one step in ring slot `slot` (runtime): k half KH of the current piece into acc; fragment reads one k-step ahead; the five LDS-DMA of
+  // the step after next (same k half of the NEXT piece -> slot2) after k-steps 0 .. 4; EMIT at k-steps 5 and 7 (the previous piece's units)
+#define RL_STEP(KH, NWAIT_EARLY, EARLY, EMIT)                                                                                      \
+  {                                                                                                                                \
+    if (EARLY) xa_wait_vmcnt<NWAIT_EARLY>(); else xa_wait_vmcnt<5 + S>();                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                                  \
+    const char* Ws = smem + slot * RL_SLOT;                                                                                        \
+    const int slot2 = slot == 0 ? 2 : slot - 1;      /* (slot + 2) % 3 */                                                          \
+    vec8<T> fa[2][4];                                                                                                              \
+    auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {                                                        \
+      _Pragma("unroll") for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq);   \
+    };                                                                                                                             \
+    rd(0, fa[0]);                                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 10; ++ks) {                                                                            \
+      if (ks + 1 < 10) rd(ks + 1, fa[(ks + 1) & 1]);                                                                               \
+      RL_FENCE();                                                                                                                  \
+      _Pragma("unroll") for (int jd = 0; jd < 4; ++jd)                                                                             \
+        acc[jd] = lr_mfma16(fa[ks & 1][jd], xf[5 * (KH) + (ks >> 1)][ks & 1], ((KH) == 0 && ks == 0) ? z4 : acc[jd]);              \
+      if (ks < 5) issue(slot2, g_next, KH, ks, more);                                                                              \
+      if (ks == 5) { const int u = 0; EMIT; }                                                                                      \
+      if (ks == 7) { const int u = 1; EMIT; }                                                                                      \
+      RL_FENCE();                                                                                                                  \
+    }                                                                                                                              \
+    slot = slot == 2 ? 0 : slot + 1;                                                                                               \
+  }
+
+  f32x4 acc[4], prev[4];
+  int slot = 0, g_prev = 0;
+#pragma unroll 1
+  for (int j = 0; j < np; ++j) {
+    const int g = piece_of(j);
+    const bool more = j + 1 < np;
+    const int g_next = more ? piece_of(j + 1) : g;
+    // vector memory operations younger than a step's loads: the next step's 5 loads + the previous piece's S stores (none yet for the first steps)
+    RL_STEP(0, 5, j < 2, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
+    RL_STEP(1, 5, j < 1, { });
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) prev[jd] = acc[jd];
+    g_prev = g;
+  }
+#pragma unroll
+  for (int u = 0; u < (GEGLU ? 1 : 2); ++u) emit_unit(prev, g_prev - g_base, g_prev, u);
+  xa_wait_vmcnt<0>();                      // (the dead prefetches of the last piece)
+#undef RL_STEP
+#undef RL_FENCE
+#endif
+}
+
+// column slices per row block: as many as keep ~one block per CU, dividing the number of 64-row pieces
+static int rowlin_ny(int M, int N) {
+  const int rbs = M / RL_ROWS, pieces = N / 64;
+  int want = 256 / (rbs > 0 ? rbs : 1);
+  if (want < 1) want = 1;
+  int ny = 1;
+  for (int d = 1; d <= pieces && d <= want; ++d)
+    if (pieces % d == 0 && pieces / d * 64 <= RL_MAX_SLICE) ny = d;
+  while (pieces / ny * 64 > RL_MAX_SLICE && ny < pieces) {      // the bias slice must fit behind the ring
+    ++ny;
+    while (ny < pieces && pieces % ny) ++ny;
+  }
+  return ny;
+}
+
+template <typename T>
+static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
+  if (!a || !a->x || !a->w || !a->bias || !a->out) return LR_E_ARG;
+  if (a->M <= 0 || a->N <= 0 || (a->geglu != 0 && a->geglu != 1)) return LR_E_ARG;
+  if (a->C != RL_C || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+  const int n_out = a->geglu ? a->N / 2 : a->N;
+  if (a->ld_out < n_out || a->ld_out % 8) return LR_E_ALIGN;
+  if (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->bias | (uintptr_t)a->out) & 15) return LR_E_ALIGN;
+  if ((int64_t)a->N * RL_C * 2 >= ((int64_t)1 << 31)) return LR_E_UNSUPPORTED;
+  RowlinParams P;
+  P.x = a->x; P.w = a->w; P.bias = a->bias; P.out = a->out;
+  P.M = a->M; P.N = a->N; P.ld_out = a->ld_out; P.eps = a->ln_eps;
+  P.ny = rowlin_ny(a->M, a->N);
+  P.np = a->N / 64 / P.ny;
+  if (P.np * 64 > RL_MAX_SLICE) return LR_E_UNSUPPORTED;
+  const size_t smem = 3 * RL_SLOT + (size_t)RL_MAX_SLICE * sizeof(float);
+  static unsigned long long attr_done[2] = {0, 0};
+  const dim3 grid((a->M / RL_ROWS) * P.ny), block(RL_THREADS);
+  if (a->geglu) {
+    if (lr_attr_needed(&attr_done[1]))
+      hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((rowlin_kernel<T, true>), grid, block, smem, (hipStream_t)s, P);
+  } else {
+    if (lr_attr_needed(&attr_done[0]))
+      hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((rowlin_kernel<T, false>), grid, block, smem, (hipStream_t)s, P);
+  }
+  return lr_launch_status();
+}
+
+extern "C" int lr_rowlin_f16(const lr_rowlin_args* a, lr_stream_t s) { return rowlin_t<f16>(a, s); }
+extern "C" int lr_rowlin_bf16(const lr_rowlin_args* a, lr_stream_t s) { return rowlin_t<bf16>(a, s); }

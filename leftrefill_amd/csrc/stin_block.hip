@@ -33,7 +33,18 @@ struct StinParams {
   void* x1; void* qkv;
   int M, NQ, ld_qkv;          // NQ = width of the second stage (960), ld_qkv = row stride of qkv in elements
   float eps;
+#ifdef SI_TRACE
+  unsigned long long* trace;   // developer build only: shader-clock stamps [block][8 waves][64] (tools/trace_stin.py)
+#endif
 };
+
+#ifdef SI_TRACE
+#define SI_STAMP(k) do { if (P.trace && lane == 0) P.trace[((size_t)blockIdx.x * 8 + w) * 64 + (k)] = __builtin_readcyclecounter(); } while (0)
+static unsigned long long* g_si_trace = nullptr;
+extern "C" void lr_stin_set_trace(void* p) { g_si_trace = (unsigned long long*)p; }
+#else
+#define SI_STAMP(k) do { } while (0)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams P) {
@@ -47,6 +58,8 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
   const int fr = lane & 15, fq = lane >> 4;
   const int odd = fq & 1, ch8 = (fq >> 1) * 8;
   const int m_w0 = blockIdx.x * SI_ROWS + w * 32;
+  int si_piece = 0;           // running piece number (trace stamps only)
+  SI_STAMP(0);
 
   // ---- the wave's 32 rows as two B-operand sets: lane (fr, fq), set rs holds x[m_w0 + 16 rs + fr][64 t5 + 32 u + 8 fq .. + 7]
   vec8<T> xf[2][KL][2];
@@ -79,10 +92,18 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lptr_t)(smem + slot * SI_SLOT + (i * 64 + w * 8) * 128), 16, live ? vrow : OOB,
                                              n * 64 * C * 2 + i * 128, 0, 0);
   };
+  const int nq = P.NQ / 64;                // pieces of the second stage: a multiple of 3, so every piece's slot is a compile-time constant
+#ifdef SI_NO_ROTATE
+  const int p0 = 0, n0 = 0;
+#else
+  const int p0 = (blockIdx.x >> 3) % KL, n0 = (blockIdx.x >> 3) % nq;
+#endif
+#define PP(i) ((p0 + (i)) % KL)
+#define QN(i) ((n0 + (i)) % nq)
 #pragma unroll
-  for (int i = 0; i < KL; ++i) issue_p(0, 0, i);
+  for (int i = 0; i < KL; ++i) issue_p(0, PP(0), i);
 #pragma unroll
-  for (int i = 0; i < KL; ++i) issue_p(1, 1, i);
+  for (int i = 0; i < KL; ++i) issue_p(1, PP(1), i);
 
   const int sw = (fr >> 1) & 7;
   auto frag = [&](const char* base, int row, int chunk) -> vec8<T> {
@@ -90,17 +111,35 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
   };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #define SI_FENCE() __builtin_amdgcn_sched_barrier(0)
+// timing experiments of developer variants (tools/build_variant.sh x -DSI_DBG_NODMA ...): results are garbage, only the clock matters
+#ifdef SI_DBG_NODMA
+#define SI_DBG_DMA(X)
+#else
+#define SI_DBG_DMA(X) X
+#endif
+#ifdef SI_DBG_NOMFMA
+#define SI_DBG_MFMA(X) acc[0][jd][0] += (float)fa[ks & 1][jd][0];
+#else
+#define SI_DBG_MFMA(X) X
+#endif
 
-  // one piece in slot SLOT: 10 k-steps x (4 fragment reads, 8 MFMAs), fragment reads one k-step ahead, one LDS-DMA instruction of the
-  // piece after next (ISSUE, uses ks) after each of the first five k-steps; XB = the B operands (xf | xn); NWAIT = vector memory
-  // operations younger than this piece's loads (stores of the two previous pieces + the next piece's loads); then the epilogue EPI(acc)
-#define SI_PIECE(SLOT, XB, NWAIT, ISSUE, EPI)                                                                                   \
+  // one piece in slot SLOT: 10 k-steps x (4 fragment reads, 8 MFMAs) into accumulator set CUR, fragment reads one k-step ahead, one LDS-DMA
+  // instruction of the piece after next (ISSUE, uses ks) after each of the first five k-steps; XB = the B operands; NWAIT = vector memory
+  // operations younger than this piece's loads.  The PREVIOUS piece's accumulators (set CUR ^ 1) are emitted WHILE this one multiplies
+  // (PREV(u), u = 0 .. 3, one 16-row x 32-column unit after each of k-steps 5 .. 8): all eight waves of the block run the same piece between
+  // two barriers, so an epilogue that followed its own k-loop left the matrix pipes idle for its whole length (measured: 77 us, of which 20
+  // matrix, 21 stores, 36 everything else, none of it overlapped).
+#define SI_PIECE(SLOT, XB, NWAIT, ISSUE, CUR, PREV)                                                                             \
   {                                                                                                                             \
+    SI_STAMP(2 + 3 * si_piece);                                                                                                 \
     xa_wait_vmcnt<NWAIT>();                                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
+    SI_STAMP(3 + 3 * si_piece);                                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                               \
+    SI_STAMP(4 + 3 * si_piece);                                                                                                 \
+    ++si_piece;                                                                                                                 \
     const char* Ws = smem + (SLOT) * SI_SLOT;                                                                                   \
-    f32x4 acc[2][4] = {{z4, z4, z4, z4}, {z4, z4, z4, z4}};                                                                     \
+    f32x4 (&acc)[2][4] = accs[CUR];                                                                                             \
     vec8<T> fa[2][4];                                                                                                           \
     auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {                                                     \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq); \
@@ -110,43 +149,52 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
       if (ks + 1 < 10) rd(ks + 1, fa[(ks + 1) & 1]);                                                                            \
       SI_FENCE();                                                                                                               \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd) {                                                                        \
-        acc[0][jd] = lr_mfma16(fa[ks & 1][jd], XB[0][ks >> 1][ks & 1], acc[0][jd]);                                             \
-        acc[1][jd] = lr_mfma16(fa[ks & 1][jd], XB[1][ks >> 1][ks & 1], acc[1][jd]);                                             \
+        SI_DBG_MFMA(acc[0][jd] = lr_mfma16(fa[ks & 1][jd], XB[0][ks >> 1][ks & 1], ks ? acc[0][jd] : z4);)                      \
+        SI_DBG_MFMA(acc[1][jd] = lr_mfma16(fa[ks & 1][jd], XB[1][ks >> 1][ks & 1], ks ? acc[1][jd] : z4);)                      \
       }                                                                                                                         \
-      if (ks < KL) { ISSUE; }                                                                                                   \
+      SI_DBG_DMA(if (ks < KL) { ISSUE; })                                                                                       \
+      if (ks >= 5 && ks < 9) { const int u = ks - 5; PREV; }                                                                    \
       SI_FENCE();                                                                                                               \
     }                                                                                                                           \
-    EPI;                                                                                                                        \
   }
 
-  // emit 8 accumulator tiles (2 row sets x 64 columns c0 ..) of one piece: + bias (LDS row `bias`), 16 bits, 16-byte stores to dst (row
-  // stride ld elements)
-  auto emit = [&](f32x4 (&acc)[2][4], const float* bias, T* dst, int ld, int c0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        f32x4 a = acc[rs][2 * q] + *reinterpret_cast<const f32x4*>(bias + c0 + (2 * q) * 16 + 4 * fq);
-        f32x4 b = acc[rs][2 * q + 1] + *reinterpret_cast<const f32x4*>(bias + c0 + (2 * q + 1) * 16 + 4 * fq);
-        xa_swap_rows16(a, b);
-        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        const uint4 pk = lr_pack8<T>(v);
-        *reinterpret_cast<uint4*>(dst + (size_t)(m_w0 + 16 * rs + fr) * ld + c0 + (2 * q + odd) * 16 + ch8) = pk;
-      }
+  f32x4 accs[2][2][4];
+  // emit unit u (row set u >> 1, 32 columns c0 + 32 (u & 1) ..) of a piece's accumulators: + bias (LDS row `bias`), 16 bits, one 16-byte
+  // store per lane to dst (row stride ld elements)
+  auto emit_unit = [&](f32x4 (&acc)[2][4], const float* bias, T* dst, int ld, int c0, int u) __attribute__((always_inline)) {
+    const int rs = u >> 1, q = u & 1;
+    f32x4 a = acc[rs][2 * q] + *reinterpret_cast<const f32x4*>(bias + c0 + (2 * q) * 16 + 4 * fq);
+    f32x4 b = acc[rs][2 * q + 1] + *reinterpret_cast<const f32x4*>(bias + c0 + (2 * q + 1) * 16 + 4 * fq);
+    xa_swap_rows16(a, b);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const uint4 pk = lr_pack8<T>(v);
+#ifdef SI_DBG_NOSTORE      // (timing experiment, tools/build_variant.sh: keep the arithmetic, drop the store)
+    if (pk.x == 0x12345678u && pk.y == 0x9abcdef0u)
+#endif
+    *reinterpret_cast<uint4*>(dst + (size_t)(m_w0 + 16 * rs + fr) * ld + c0 + (2 * q + odd) * 16 + ch8) = pk;
   };
+#define SI_NONE do { } while (0)
 
   // ================= stage 1: x1 = h Wp^T + bp ===========================================================================
+  // The order of the column pieces is free (each is emitted on its own): block b starts at piece (b / 8) mod 5 resp. mod nq and wraps,
+  // so the ~32 blocks an XCD runs at once (block ids b = xcd mod 8) ask its L2 for DIFFERENT weight lines at any moment instead of all
+  // for the same 40 KB.
+  // NWAIT: in piece i the loads of piece i + 2 are issued (5, k-steps 0 .. 4), then the stores of piece i - 1 (4, k-steps 5 .. 8)
   T* x1 = reinterpret_cast<T*>(P.x1);
-  SI_PIECE(0, xf, 5, issue_p(2, 2, ks), emit(acc, par, x1, C, 0));
-  SI_PIECE(1, xf, 9, issue_p(0, 3, ks), emit(acc, par, x1, C, 64));
-  SI_PIECE(2, xf, 13, issue_p(1, 4, ks), emit(acc, par, x1, C, 128));
-  SI_PIECE(0, xf, 13, issue_q(2, 0, ks), emit(acc, par, x1, C, 192));
-  SI_PIECE(1, xf, 13, issue_q(0, 1, ks), emit(acc, par, x1, C, 256));
+  SI_PIECE(0, xf, 5, issue_p(2, PP(2), ks), 0, SI_NONE);
+  SI_PIECE(1, xf, 5, issue_p(0, PP(3), ks), 1, emit_unit(accs[0], par, x1, C, PP(0) * 64, u));
+  SI_PIECE(2, xf, 9, issue_p(1, PP(4), ks), 0, emit_unit(accs[1], par, x1, C, PP(1) * 64, u));
+  SI_PIECE(0, xf, 13, issue_q(2, QN(0), ks), 1, emit_unit(accs[0], par, x1, C, PP(2) * 64, u));
+  SI_PIECE(1, xf, 13, issue_q(0, QN(1), ks), 0, emit_unit(accs[1], par, x1, C, PP(3) * 64, u));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) emit_unit(accs[0], par, x1, C, PP(4) * 64, u);
 
   // ---- the wave's x1 rows come back as the second stage's B operands (natural k order): they left rounded to 16 bits, which is what
   //      the unfused path normalises; the lines were written by this wave (vmcnt(0): its stores have reached the L2, and every older
   //      operation with them) and never read before, so the loads cannot find a stale copy in this CU's L1.  Two-pass LayerNorm in registers.
+  SI_STAMP(62);
   xa_wait_vmcnt<0>();
+  SI_STAMP(63);
 #pragma unroll
   for (int rs = 0; rs < 2; ++rs) {
     const T* xrow = x1 + (size_t)(m_w0 + 16 * rs + fr) * C + 8 * fq;
@@ -195,15 +243,32 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
 
   // ================= stage 2: qkv = xn Wqkv^T + bqkv, 64 columns per piece ================================================
   T* qkv = reinterpret_cast<T*>(P.qkv);
-  const int nq = P.NQ / 64;                // pieces of this stage: a multiple of 3, so every piece's slot is a compile-time constant
+  // this block's n-th .. (n + 2)-th pieces in slots 2, 0, 1 (five pieces of stage 1: 5 % 3 == 2), accumulator sets 1, 0, 1 / 0, 1, 0 by the
+  // parity of n; the previous piece's columns are emitted inside each
+#define SI_TRIPLE(n, W0, W1, W2, A, FIRST)                                                                                                  \
+  SI_PIECE(2, xf, W0, issue_q(1, QN((n) + 2), ks, (n) + 2 < nq), A, if (!(FIRST)) emit_unit(accs[(A) ^ 1], par + C, qkv, P.ld_qkv, QN((n) - 1) * 64, u)); \
+  SI_PIECE(0, xf, W1, issue_q(2, QN((n) + 3), ks, (n) + 3 < nq), (A) ^ 1, emit_unit(accs[A], par + C, qkv, P.ld_qkv, QN(n) * 64, u));        \
+  SI_PIECE(1, xf, W2, issue_q(0, QN((n) + 4), ks, (n) + 4 < nq), A, emit_unit(accs[(A) ^ 1], par + C, qkv, P.ld_qkv, QN((n) + 1) * 64, u));
+  // (after the reload nothing is in flight: the first two waits are formal, the third sees only one piece's stores behind its loads)
+  SI_TRIPLE(0, 13, 13, 9, 0, true)
 #pragma unroll 1
-  for (int n = 0; n < nq; n += 3) {        // pieces n, n + 1, n + 2 in slots 2, 0, 1 (five pieces of stage 1: 5 % 3 == 2)
-    SI_PIECE(2, xf, 13, issue_q(1, n + 2, ks, n + 2 < nq), emit(acc, par + C, qkv, P.ld_qkv, n * 64));
-    SI_PIECE(0, xf, 13, issue_q(2, n + 3, ks, n + 3 < nq), emit(acc, par + C, qkv, P.ld_qkv, (n + 1) * 64));
-    SI_PIECE(1, xf, 13, issue_q(0, n + 4, ks, n + 4 < nq), emit(acc, par + C, qkv, P.ld_qkv, (n + 2) * 64));
+  for (int n = 3; n < nq; n += 6) {        // two triples per trip: the accumulator parity repeats every two
+    SI_TRIPLE(n, 13, 13, 13, 1, false)
+    if (n + 3 < nq) { SI_TRIPLE(n + 3, 13, 13, 13, 0, false) }
   }
+  if ((nq / 3) & 1) {                      // the last piece's columns
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit_unit(accs[0], par + C, qkv, P.ld_qkv, QN(nq - 1) * 64, u);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit_unit(accs[1], par + C, qkv, P.ld_qkv, QN(nq - 1) * 64, u);
+  }
+#undef SI_TRIPLE
+  SI_STAMP(1);                             // (all pieces multiplied and emitted)
   xa_wait_vmcnt<0>();                      // (the dead prefetches of the last two pieces)
 #undef SI_PIECE
+#undef PP
+#undef QN
 #undef SI_FENCE
 #endif
 }
@@ -221,6 +286,9 @@ static int stin_block_t(const lr_stin_args* a, lr_stream_t s) {
   StinParams P;
   P.x = a->x; P.wp = a->wp; P.bp = a->bp; P.wqkv = a->wqkv; P.bqkv = a->bqkv; P.x1 = a->x1; P.qkv = a->qkv;
   P.M = a->M; P.NQ = a->NQ; P.ld_qkv = a->ld_qkv; P.eps = a->ln_eps;
+#ifdef SI_TRACE
+  P.trace = g_si_trace;
+#endif
   const size_t smem = 3 * SI_SLOT + (size_t)(SI_C + a->NQ) * sizeof(float);
   static unsigned long long attr_done = 0;
   if (lr_attr_needed(&attr_done))

@@ -49,6 +49,13 @@ __global__ __launch_bounds__(XB_THREADS) void xattn640_kernel(const Xattn640Para
   }
   const int m0 = bid * XB_ROWS;
   const int b = m0 / P.HW;
+#ifndef XB_ROTATE      // measured (profiles/r06_rotation_ab.txt): 61.9 vs 61.5 us plain, 71.1 vs 73.8 us with PRE -- within the run-to-run spread; off
+  const int h0 = 0;
+#else
+  // first head of this block's cyclic head order (see the head loop): a function of the block's position INSIDE its sample, so a row's
+  // bits do not depend on the batch size or on which sample / rank carries it (consecutive blocks run on the same XCD after the remap)
+  const int h0 = ((m0 - b * P.HW) / XB_ROWS) % XB_HEADS;
+#endif
   const int m_w0 = m0 + w * 16;
 
   // ---- this wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 32 u + 8 fq .. + 7]
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(XB_THREADS) void xattn640_kernel(const Xattn640Para
     for (int i = 0; i < 10; ++i) issue_mat(rsP, 2, 0, 320, i);
   } else {                  // the first head's query projection slice
 #pragma unroll
-    for (int i = 0; i < 10; ++i) issue_mat(rsQ, 0, 0, 0, i);
+    for (int i = 0; i < 10; ++i) issue_mat(rsQ, 0, h0 * 64, 0, i);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) issue_mat(rsQ, 1, 0, 320, i);
+    for (int i = 0; i < 10; ++i) issue_mat(rsQ, 1, h0 * 64, 320, i);
   }
 
   // ---- LayerNorm of the rows in registers (two-pass), gamma / beta live in Wq / bq
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(XB_THREADS) void xattn640_kernel(const Xattn640Para
       // two pieces ahead: Wo1 pieces 2 .. 19, then the first head's two Wq pieces
       XB_MAT_STEP(Ws, 5 * kh, acc[4 * p], acc[4 * p + 1], acc[4 * p + 2], acc[4 * p + 3],
                   { if (j + 2 < 2 * KL) issue_mat(rsP, (j + 3) % 3, 64 * ((j + 2) >> 1), 320 * ((j + 2) & 1), ks);
-                    else issue_mat(rsQ, j + 2 - 2 * KL, 0, 320 * (j + 2 - 2 * KL), ks); });
+                    else issue_mat(rsQ, j + 2 - 2 * KL, h0 * 64, 320 * (j + 2 - 2 * KL), ks); });
     }
     // x1 = acc + bo1 + x, rounded to fp16 (what the unfused path stores); LayerNorm of the rounded rows; B operands in accumulator order
     float s = 0.f;
@@ -220,9 +227,13 @@ __global__ __launch_bounds__(XB_THREADS) void xattn640_kernel(const Xattn640Para
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  // The heads are independent terms of out^T: block b starts at head h0 = (b / 8) mod 10 and wraps, so the ~32 blocks an XCD runs at once
+  // stream DIFFERENT weight pieces from its L2 at any moment instead of all asking for the same 40 KB.
 #pragma unroll 1
-  for (int h = 0; h < XB_HEADS; ++h) {
-    const bool more = h + 1 < XB_HEADS;
+  for (int hi = 0; hi < XB_HEADS; ++hi) {
+    const int h = hi + h0 < XB_HEADS ? hi + h0 : hi + h0 - XB_HEADS;
+    const int hn = h + 1 < XB_HEADS ? h + 1 : 0;      // the head after this one
+    const bool more = hi + 1 < XB_HEADS;
     // ================= Q0 / Q1: q_h^T = Wq_h xn^T  (two k halves of 10 k-steps x 4 MFMAs) =================================
     f32x4 qa[4] = {z4, z4, z4, z4};
     xa_wait_vmcnt<10>();                      // Q0 landed (Q1 in flight)
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(XB_THREADS) void xattn640_kernel(const Xattn640Para
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           acc[20 * nh + 4 * (g % 5) + q] = lr_mfma16(fa[g & 1][q], g < 5 ? ob0 : ob1, acc[20 * nh + 4 * (g % 5) + q]);
-        issue_mat(rsQ, nh, (h + 1) * 64, 320 * nh, g, more);      // Wq_{h+1}, k half nh -> slot nh
+        issue_mat(rsQ, nh, hn * 64, 320 * nh, g, more);      // Wq of the next head, k half nh -> slot nh
         XB_FENCE();
       }
     }

@@ -231,6 +231,8 @@ class PackedST:
 
     def _build_ff_proj(self):
         if self._ff_proj is None and self._ff_src is not None:
+            # host fp64 matmuls and device <-> host copies: never inside a stream capture (UNetModel.finalize_inference runs this up front)
+            assert not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()), "PackedST.ff_proj_w built inside a graph capture: call UNetModel.finalize_inference() first"
             proj_out, ff2, dt = self._ff_src
             wp = proj_out.weight.detach().float()
             wp = wp.reshape(wp.shape[0], wp.shape[1])
@@ -262,14 +264,22 @@ def linear(x, pl: PackedLinear, resid=None, M=None, want_stats=False):
     return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid, want_stats=want_stats)
 
 
+def _PLAN_SCALE_ONE():
+    """(the row-resident kernels are row-local: every plan-scale gives the same bits, but keep the half-batch prefix on the tiled path)"""
+    return True
+
+
 def fold_ok(x):
     """The LayerNorm-folded GEMMs are inference kernels (no backward): use them unless autograd needs the LayerNorm."""
     return LN_FOLD and not (torch.is_grad_enabled() and x.requires_grad)
 
 
-def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear):
+def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear, wide=False):
     """Linear(LayerNorm(x)).  st: per-row (sum, sumsq) partials of x from the GEMM that produced it, or None.
-    With st the LayerNorm is folded into the GEMM (no normalised tensor is written); otherwise the LayerNorm kernel runs."""
+    With st the LayerNorm is folded into the GEMM (no normalised tensor is written); otherwise the LayerNorm kernel runs.
+    wide: a projection several times wider than x (the fused q|k|v) -- at C = 640 the row-resident kernel takes it."""
+    if wide and pl.wf is not None and fold_ok(x) and _PLAN_SCALE_ONE() and ops.rowlin_ok(x.shape[0], x.shape[1], pl.wf.shape[0]):
+        return ops.rowlin(x, pl.wf, pl.bf, eps=pl.eps)
     if st is not None and pl.wf is not None and fold_ok(x):
         return ops.gemm_conv(x, pl.wf, B=1, H=1, W=x.shape[0], taps=1, bias=pl.bf, ln=(st, pl.eps, pl.cs))
     return linear(ops.layer_norm(x, pn.g, pn.b, pn.eps), pl)
@@ -347,10 +357,11 @@ def attention_plain(x, ctx, pa: PackedAttn, B, L, Lc=None):
     return linear(a, pa.out)
 
 
-def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None):
+def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None, wide=False):
     """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None); qkv: the projection when its producer already
-    made it (ops.stin_block)."""
-    qkv = ln_linear(x, st, pn, pa.qkv) if qkv is None else qkv
+    made it (ops.stin_block); wide: single-view blocks let the row-resident kernel take the projection (the multi-view forms keep the
+    LayerNorm-folded GEMM, whose arithmetic the sharded path reproduces bit for bit)."""
+    qkv = ln_linear(x, st, pn, pa.qkv, wide=wide) if qkv is None else qkv
     a = ops.attention_qkv(qkv, B, pa.heads, L, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
@@ -387,11 +398,11 @@ def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False, qk
     pa1, pa2 = pt.attn1, pt.attn2
     if dup:
         with plan_batch_scale(2):
-            qkv = ln_linear(x, st, pt.n1, pa1.qkv) if qkv0 is None else qkv0
+            qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide=True) if qkv0 is None else qkv0
         a = dup2(ops.attention_qkv(qkv, N // 2, pa1.heads, L, pa1.dim_head ** -0.5))
         x = dup2(x)
     else:
-        qkv = ln_linear(x, st, pt.n1, pa1.qkv) if qkv0 is None else qkv0
+        qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide=True) if qkv0 is None else qkv0
         a = ops.attention_qkv(qkv, N, pa1.heads, L, pa1.dim_head ** -0.5)
     return ops.xattn_block(x, pa2.xq_pi, pa2.q.bf, kv[2], kv[3], pa2.xwo, pa2.out.b, HW=L, heads=pa2.heads, Lc=Lc, eps=pa2.q.eps,
                            scale=pa2.dim_head ** -0.5, want_stats=want_stats, pre=(a, pa1.out.w, pa1.out.b))
@@ -442,9 +453,9 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         return _ffn(x, st, pt, want_stats, post, use_ffn)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
-            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws, qkv=qkv0)
+            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws, qkv=qkv0, wide=True)
     elif pt.view_num is None:
-        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws, qkv=qkv0)
+        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws, qkv=qkv0, wide=True)
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
         x = _mv_sharded_self_attention(x, pt, N, L, st)
         ws = False
@@ -497,7 +508,10 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
         ws = want_stats and fold_ok(x)
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, want_stats=ws)
         return y if ws else (y, None)
-    if st is not None:
+    if fold_ok(x) and ops.rowlin_ok(x.shape[0], x.shape[1], pt.geglu_wf.shape[0]):
+        # C = 640: LayerNorm + GEGLU projection + gate with the rows resident in registers (lr_rowlin_f16)
+        g = ops.rowlin(x, pt.geglu_wf, pt.geglu_bf, eps=pt.n3.eps, geglu=True)
+    elif st is not None:
         g = ops.gemm_conv(x, pt.geglu_wf, B=1, H=1, W=x.shape[0], taps=1, bias=pt.geglu_bf, geglu=True,
                           ln=(st, pt.n3.eps, pt.geglu_cs))
     else:

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import FfnArgs, GemmArgs, StinArgs, XattnArgs
+from ._lib import FfnArgs, GemmArgs, RowlinArgs, StinArgs, XattnArgs
 
 GN_CHUNKS = 256
 # per-group GroupNorm partials from the producers' epilogues (no lr_groupnorm_finalize launch); LEFTREFILL_GN_GROUPS=0 keeps the
@@ -38,6 +38,8 @@ PLAN_LOG = os.environ.get("LEFTREFILL_PLAN_LOG", "0") == "1"
 # at once), 0 = by the separate fixed-order reduce launch
 SPLITK_MODE = int(os.environ.get("LEFTREFILL_SPLITK_MODE", "0"))      # (1 needs a developer build of the library)
 _untabulated = set()
+# shape keys of the GEMM calls since the sets were last cleared, by whether the in-tree table knew them (bench.py batch_sensitivity)
+TABLE_HITS, TABLE_MISSES = set(), set()
 # developer hooks of tools/tune_in_step.py (None in the product): PLAN_TRIAL maps a table key to the (tile_m, tile_n, splits, pipe) to try
 # instead of the table's plan (splits 0 = the library's static choice for that tile; a plan the library refuses falls back to the table's);
 # LAUNCH_HOOK(key, phase, plan) is called right before (0) and after (1) the launch
@@ -345,6 +347,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         # (a conv with the pointwise extension is planned like the plain conv: the table knows that shape)
         key = tile_key(M * scale, Nw, Kw - Cs1 - Cs2, taps, stride, up, geglu, C2 > 0, asym, gelu, ln is not None, want_stats)
         best = tile_cache().get(key)
+        (TABLE_HITS if best is not None else TABLE_MISSES).add(key)
         if best is None and PLAN_LOG and key not in _untabulated:      # developer aid: which shapes fall back to the static heuristic
             _untabulated.add(key)
             import sys
@@ -365,7 +368,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
         if best is not None:
             a.tile_m, a.tile_n, a.splits = best[:3]
             a.pipe = best[3] if len(best) > 3 else 0
-            if a.pipe == 8 and (W % 16 or (H % 16 and not (H == 8 and M % 256 == 0))):      # the table is keyed by M: the halo-tile instance needs 16 x 16 pixel tiles (or pairs of 8-line images),
+            if a.pipe == 8 and (W % 16 or (H % 16 and not (H == 8 and M % 256 == 0 and (M * scale) % 256 == 0))):      # the table is keyed by M: the halo-tile instance needs 16 x 16 pixel tiles (or pairs of 8-line images; decided for the planned batch AND this call),
                 a.pipe = 0                              # any other latent of the same size takes the tile's gather instance
         if skip is not None and best is None:      # static heuristic: ask the library, then make sure the tile is a pipelined one
             plan = (ctypes.c_int32 * 4)()
@@ -631,6 +634,36 @@ def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None):
     a.M, a.C, a.NQ, a.ld_qkv, a.ln_eps = M, C, NQ, qkv.stride(0), float(eps)
     _lib.check(_fn(lib, "lr_stin_block_f16", x.dtype)(a, _stream()), "stin_block")
     return x1, qkv
+
+
+ROWLIN_C, ROWLIN_ROWS = 640, 128
+# LEFTREFILL_ROWLIN=0 keeps the LayerNorm-folded tiled GEMMs for the q|k|v and GEGLU projections at C = 640
+ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
+
+
+def rowlin_ok(M, C, N):
+    """Shapes lr_rowlin_f16 takes (everything else keeps the LayerNorm-folded GEMM)."""
+    return ROWLIN and C == ROWLIN_C and M % ROWLIN_ROWS == 0 and N > 0 and N % 64 == 0
+
+
+def rowlin(x, w, bias, *, eps, geglu=False, out=None):
+    """LayerNorm(x) w^T + bias (geglu: value * gelu(gate) of the interleaved rows) with the rows resident in registers (lr_rowlin_f16):
+    the wide short-K projections of a C = 640 block.  w / bias: packing.fold_layernorm (GEGLU: in packing.geglu_perm row order)."""
+    lib = _lib.load()
+    _chk16(x, "x")
+    M, C = x.shape
+    N = w.shape[0]
+    assert rowlin_ok(M, C, N), (M, C, N)
+    assert w.dtype == x.dtype and w.is_contiguous() and w.shape == (N, C) and bias.dtype == torch.float32 and bias.numel() == N
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, n_out, device=x.device, dtype=x.dtype)
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype
+    a = RowlinArgs()
+    a.x, a.w, a.bias, a.out = _p(x), _p(w), _p(bias), _p(out)
+    a.M, a.C, a.N, a.ld_out, a.geglu, a.ln_eps = M, C, N, out.stride(0), int(bool(geglu)), float(eps)
+    _lib.check(_fn(lib, "lr_rowlin_f16", x.dtype)(a, _stream()), "rowlin")
+    return out
 
 
 FFN_C, FFN_ROWS, FFN_MAX_H = 320, 128, 2048

@@ -376,6 +376,12 @@ def ffn_block(*a, **k):
     return ops.ffn_block(*a, **k)
 
 
+def rowlin(*a, **k):
+    """Row-resident LayerNorm + Linear at C = 640: inference only, looked up on `ops` at call time (see xattn_block)."""
+    assert not _needs_grad(a[0])
+    return ops.rowlin(*a, **k)
+
+
 def stin_block(*a, **k):
     """Fused SpatialTransformer entry (proj_in + LayerNorm + q|k|v): inference only, looked up on `ops` at call time (see xattn_block)."""
     assert not _needs_grad(a[0])

@@ -1,0 +1,126 @@
+"""GPU parity of the row-resident LayerNorm + Linear at C = 640 (lr_rowlin_f16) against the CPU oracle.
+
+Reference semantics: `self.norm1(x)` + the fused to_q / to_k / to_v of attn1 (ldm/modules/attention.py:280, 168-172) and `self.norm3(x)` +
+GEGLU.proj + `x * F.gelu(gate)` (attention.py:282, 51-58); oracle: unet_ref.layer_norm + fp32 linear (+ exact-erf GELU gate) on the
+fp16-rounded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_spec as G, unet_ref, weights  # noqa: E402
+from tests.test_gpu_ops import dev, h16, report  # noqa: E402
+
+C = 640
+
+
+def _params(tag, N):
+    w = h16(torch.from_numpy(weights.fill_like(f"rowlin.{tag}.weight", (N, C))))
+    b = torch.from_numpy(weights.fill_like(f"rowlin.{tag}.bias", (N,)))
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like(f"rowlin.{tag}.norm.weight", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like(f"rowlin.{tag}.norm.bias", (C,), kind="unit"))
+    return w, b, gamma, beta
+
+
+@pytest.mark.parametrize("M,N", [(128, 1920), (256, 1920), (384, 64), (2048, 1920), (1152, 320)])
+def test_rowlin_plain_vs_oracle(M, N):
+    from leftrefill_amd import ops, packing
+    d = dev()
+    w, b, gamma, beta = _params("p", N)
+    x = h16(G.T(f"rowlin.{M}.{N}.x", (M, C)) * 1.3 + 0.2)
+    ref = F.linear(unet_ref.layer_norm(x, gamma, beta), w, b)
+    wf, bf, _cs = packing.fold_layernorm(w, b, gamma, beta)
+    out = ops.rowlin(x.half().to(d), wf.to(d), bf.to(d), eps=1e-5)
+    report(f"rowlin M{M} N{N}", out, ref, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,H", [(128, 2560), (512, 2560), (256, 64), (2048, 2560)])
+def test_rowlin_geglu_vs_oracle(M, H):
+    """value * gelu(gate) of the interleaved projection (packing.geglu_perm), H output columns."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    w, b, gamma, beta = _params("g", 2 * H)
+    x = h16(G.T(f"rowlin.g.{M}.{H}.x", (M, C)) * 1.1 - 0.1)
+    y = F.linear(unet_ref.layer_norm(x, gamma, beta), w, b)
+    ref = y[:, :H] * F.gelu(y[:, H:])
+    wf, bf, _cs = packing.fold_layernorm(w, b, gamma, beta)
+    perm = packing.geglu_perm(H)
+    out = ops.rowlin(x.half().to(d), wf[perm].contiguous().to(d), bf[perm].contiguous().to(d), eps=1e-5, geglu=True)
+    # (the normalised rows are rounded to 16 bits before the product, and value x gate multiplies two such results: one element in 1.3 M
+    # reached 5.2e-3 at |out| ~ 6)
+    report(f"rowlin geglu M{M} H{H}", out, ref, atol=6e-3)
+
+
+def test_rowlin_hot_shapes_reruns_and_tiled_gemm():
+    """configs[1] level-1 shapes (M = 8 x 2048): bit-identical reruns (stores and LDS-DMA loads share the counted vmcnt waits), sampled
+    rows against the oracle, and agreement with the LayerNorm-folded tiled GEMMs they replace."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    M = 16384
+    g = torch.Generator().manual_seed(21)
+    x = h16(torch.randn(M, C, generator=g) * 1.2)
+    xd = x.half().to(d)
+    xf = x.float()
+    st = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).reshape(M, 1, 2).contiguous().to(d)
+    rows = torch.arange(0, M, 41)
+    for geglu, N in ((False, 1920), (True, 5120)):
+        w, b, gamma, beta = _params("hot%d" % geglu, N)
+        wf, bf, cs = packing.fold_layernorm(w, b, gamma, beta)
+        if geglu:
+            perm = packing.geglu_perm(N // 2)
+            wf, bf, cs = wf[perm].contiguous(), bf[perm].contiguous(), cs[perm].contiguous()
+        wf, bf, cs = wf.to(d), bf.to(d), cs.to(d)
+        outs = [ops.rowlin(xd, wf, bf, eps=1e-5, geglu=geglu) for _ in range(4)]
+        assert all(torch.equal(o, outs[0]) for o in outs[1:])
+        y = F.linear(unet_ref.layer_norm(x[rows], gamma, beta), w, b)
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:]) if geglu else y
+        report(f"rowlin hot geglu={geglu}", outs[0][rows.to(d)], ref, atol=3e-3)
+        tiled = ops.gemm_conv(xd, wf, B=1, H=1, W=M, taps=1, bias=bf, geglu=geglu, ln=(st, 1e-5, cs))
+        err = (tiled.float() - outs[0].float()).abs().max().item()
+        print(f"[rowlin vs tiled GEMM geglu={geglu}] max abs diff {err:.3e} at |out| {tiled.float().abs().max().item():.2f}")
+        assert err <= 6e-3 * max(1.0, tiled.float().abs().max().item())
+
+
+def test_rowlin_unsupported_shapes_are_reported():
+    from leftrefill_amd import ops
+    assert ops.rowlin_ok(16384, 640, 1920) and ops.rowlin_ok(2048, 640, 5120)
+    assert not ops.rowlin_ok(16384 + 64, 640, 1920)      # ragged rows
+    assert not ops.rowlin_ok(65536, 320, 960)            # other widths keep their own paths
+    assert not ops.rowlin_ok(4096, 1280, 3840)
+
+
+def test_transformer_block_rowlin_equals_tiled_path():
+    """engine.transformer_block at C = 640 with the row-resident projections vs the LayerNorm-folded tiled GEMMs."""
+    import importlib
+    from leftrefill_amd import engine, ops
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(4)
+    d = dev()
+    blk = att.BasicTransformerBlock(640, 10, 64, context_dim=1024).to(d).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.04)
+        for n_ in (blk.norm1, blk.norm2, blk.norm3):
+            n_.weight.add_(1.0)
+    pt = engine.PackedTBlock(blk)
+    B, L, Lc = 2, 256, 77
+    x = torch.randn(B * L, 640, device=d).half()
+    xf = x.float()
+    st = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).reshape(B * L, 1, 2).contiguous()
+    ctx = torch.randn(B * Lc, 1024, device=d).half()
+    kv = ops.gemm_conv(ctx, pt.attn2.kv.w, B=1, H=1, W=B * Lc, taps=1)
+    ent = (kv, None, ops.gemm_conv(ctx, pt.attn2.xk, B=1, H=1, W=B * Lc, taps=1), ops.xattn_pack_vt(kv[:, 640:], B, 10, Lc))
+    outs = []
+    for flag in (True, False):
+        ops.ROWLIN = flag
+        try:
+            with torch.no_grad():
+                outs.append(engine.transformer_block(x, ctx, pt, B, L, Lc, kv=ent, st=st)[0].float().cpu())
+        finally:
+            ops.ROWLIN = True
+    err = (outs[0] - outs[1]).abs().max().item()
+    print(f"[row-resident vs tiled projections] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
+    assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())

@@ -573,3 +573,81 @@ def test_multiview_canvas_sharding_gloo(world):
         p.join(60)
     assert [r for r, _ in res] == list(range(world))
     assert all(err < 1e-5 for _, err in res), res
+
+
+# ---- index tables of the sharded multi-view block against the torch glue, with DISTINCT canvases per rank ----------
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("split", [True, False])
+def test_mv_shard_plan_tables_match_torch_glue_with_distinct_rank_canvases(world, split):
+    """The row-copy tables of leftrefill_amd.dist.mv_shard_plan (seq_src, own_src, ref / tgt write-back) applied with index_select to
+    a canvas-major message whose canvases all differ, against mv_sequence_from_canvases / mv_own_rows[_split] / mv_gather_target's
+    layout / mv_canvas_from_own -- the simulated-peer GPU test delivers copies of the local rows and could not see a wrong canvas or
+    rank index (reference semantics: ldm/modules/multiview_attention.py:436-462)."""
+    from leftrefill_amd import dist as lrd
+    v, b, s, C = world, 2, 4, 3
+    s2, T = s * s, 2 * s * s
+    g = torch.Generator().manual_seed(100 * world + int(split))
+    canv = torch.randn(v, b, T, C, generator=g)               # canvas j of local sample bi, as rank j sends it
+    msg = canv.reshape(v * b * T, C)                          # canvas-major receive buffer [v][b][T]
+    x_all = canv.transpose(0, 1).contiguous()                 # [b, v, T, C]
+    seq_ref = lrd.mv_sequence_from_canvases(x_all, s)
+    for rank in range(world):
+        p = lrd.mv_shard_plan(b, v, s, rank, split, "cpu")
+        assert torch.equal(msg[p["seq_src"].long()], seq_ref.reshape(-1, C))
+        own_ref = lrd.mv_own_rows_split(seq_ref, rank, s, v) if split else lrd.mv_own_rows(seq_ref, rank, s)
+        assert p["Lo"] == own_ref.shape[1]
+        assert torch.equal(msg[p["own_src"].long()], own_ref.reshape(-1, C))
+        if not split:
+            continue
+        n = p["n"]
+        y = torch.randn(b, p["Lo"], C, generator=g)           # this rank's new rows [target slice `rank`, ref_rank]
+        yts = torch.randn(v, b, n, C, generator=g)            # the all-gathered target slices [v][b][n] (rank-major message)
+        yts[rank] = y[:, :n]
+        tgt_full = yts.permute(1, 0, 2, 3).reshape(b, v * n, C)      # what mv_gather_target returns
+        canvas_ref = lrd.mv_canvas_from_own(torch.cat([tgt_full, y[:, n:]], dim=1), s)
+        out = torch.full((b * T, C), float("nan"))
+        out[p["ref_dst"].long()] = y.reshape(-1, C)[p["ref_src"].long()]
+        out[p["tgt_dst"].long()] = yts.reshape(-1, C)[p["tgt_src"].long()]
+        assert torch.equal(out, canvas_ref.reshape(-1, C)), (world, rank)
+
+
+# ---- bench.py's multi-GPU first-contact checks, run over gloo on CPU ranks -------------------------------------------------------
+def _selftest_worker(rank, world, port, q, fail):
+    import importlib.util
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if fail:
+        os.environ["LR_BENCH_SELFTEST_FAIL"] = fail
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("lr_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = bench.dist_selftest(rank, world, torch.device("cpu"), "gloo", share=False)
+    q.put((rank, st))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [None, "all_reduce_sum"])
+def test_bench_dist_selftest_gloo_world2(fail):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_selftest_worker, args=(r, 2, port, q, fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in range(2):
+        st = res[r]
+        if fail is None:
+            assert st["ok"] and st["stages"]["all_gather_rank_stamp"]["ranks_seen"] == [0, 1] and st["stages"]["device_uniqueness"]["ok"]
+        else:
+            assert not st["ok"] and st["failed_stage"] == fail and "forced failure" in st["stages"][fail]["error"]
+            assert st["stages"]["all_gather_into_tensor_f16"]["ok"]

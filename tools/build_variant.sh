@@ -16,7 +16,7 @@ objs=""
 for s in $all; do
   if [ -n "$VARIANT_SRCS" ] && ! echo " $VARIANT_SRCS " | grep -q " $s "; then objs="$objs leftrefill_amd/build/$s.o"; continue; fi
   extra=""
-  case $s in attention|attention_bwd|xattn_block|ffn_block|stin_block) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac
+  case $s in attention|attention_bwd|xattn_block|ffn_block|stin_block|rowlin) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DLR_DEV_VARIANTS $extra "$@" -c leftrefill_amd/csrc/$s.hip -o /tmp/lrv_$name/$s.o &
   objs="$objs /tmp/lrv_$name/$s.o"
 done
