@@ -282,11 +282,11 @@ typedef struct lr_stin_args {
 } lr_stin_args;
 int lr_stin_block_f16(const lr_stin_args* args, lr_stream_t s);
 
-/* ---- row-resident LayerNorm + Linear (C = 640: level 1 of the SD2 UNet; ABI 24) ---------------------------------------------
+/* ---- row-resident [LayerNorm +] Linear (C = 640 | 1280: levels 1 / 2 of the SD2 UNet; ABI 24) ---------------------------------
  * replaces: `self.norm1(x)` + attn1's fused `to_q / to_k / to_v` (attention.py:280, 168-172; geglu = 0, N = 3 C) and `self.norm3(x)` +
  *           GEGLU.proj + `x * F.gelu(gate)` (attention.py:282, 51-58; geglu = 1, N = 8 C -> 4 C output columns) where the tiled GEMM's
  *           K loop is only 10 steps long:   out = [gate of] LayerNorm(x) w^T + bias,  rows held in registers, weights streamed.
- *   x [M][640], M % 128 == 0;  w [N][640] = weight * gamma (LayerNorm folded along K), bias [N] = W beta + b (fp32); N % 64 == 0;
+ *   x [M][C], C = 640 | 1280 (levels 1 / 2), M % 128 == 0;  w [N][C] = weight * gamma (LayerNorm folded along K), bias [N] = W beta + b (fp32); N % 64 == 0;
  *   geglu = 1: w / bias rows interleaved in 16-row groups [u16 | g16 | ...] (the layout of lr_gemm_args.geglu == 1), out [M][N / 2];
  *   out [M][ld_out].  The LayerNorm is two-pass in registers on the 16-bit x (no producer statistics needed).
  * Other widths / ragged M: LR_E_UNSUPPORTED -- callers keep the LayerNorm-folded GEMM. */
@@ -294,6 +294,7 @@ typedef struct lr_rowlin_args {
   const lr_half* x; const lr_half* w; const float* bias; lr_half* out;
   int32_t M, C, N, ld_out, geglu;
   float ln_eps;
+  int32_t ln;      /* 1: LayerNorm the rows first (w / bias carry gamma / beta); 0: plain Linear (SpatialTransformer.proj_in, attention.py:405-408) */
 } lr_rowlin_args;
 int lr_rowlin_f16(const lr_rowlin_args* args, lr_stream_t s);
 

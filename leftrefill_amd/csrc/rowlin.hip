@@ -15,10 +15,15 @@
 // 128 rows); what goes away are the per-tile bubbles.
 #include "chain_common.h"
 
-#define RL_C 640
 #define RL_ROWS 128
 #define RL_THREADS 512
 #define RL_SLOT 40960
+#ifndef RL_DMA_AUX
+#define RL_DMA_AUX 0           // cache policy of the weight stream's LDS-DMA (nt = 2 measured: 59.0 vs 54.0 / 136.6 vs 136.3 us: no gain)
+#endif
+#ifndef RL_DEPTH
+#define RL_DEPTH 1             // k-steps a fragment read runs ahead of its MFMAs (measured at M = 16384: depth 1 / 2 / 3 / 4 = 50.6 / 51.2 / 51.6 / 53.1 us
+#endif                         // for q|k|v, 119.6 / 128.6 / 130.4 / 130.7 us for GEGLU -- the read latency is not what the loop waits for)
 #define RL_MAX_SLICE 2560      // weight rows per block whose bias fits the LDS region behind the ring
 
 struct RowlinParams {
@@ -27,10 +32,12 @@ struct RowlinParams {
   float eps;
 };
 
-template <typename T, bool GEGLU>
+// C = 640 | 1280 (levels 1 / 2: two / four 320-k steps per 64-column piece); LN = false: a plain Linear (SpatialTransformer.proj_in)
+template <typename T, int C, bool GEGLU, bool LN>
 __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int C = RL_C, KL = C / 64;      // 10 sub-tiles of 64 k, 5 per step
+  constexpr int KL = C / 64;                // sub-tiles of 64 k, 5 per step
+  constexpr int NKS = C / 320;              // steps per piece
   constexpr int S = GEGLU ? 1 : 2;          // 16-byte stores per lane and piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* par = reinterpret_cast<float*>(smem + 3 * RL_SLOT);      // bias of this block's weight rows
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
   const unsigned vrow = (unsigned)((lrow * C + lchunk * 8) * 2);
   auto issue = [&](int slot, int g, int kh, int i, bool live) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(smem + slot * RL_SLOT + (i * 64 + w * 8) * 128), 16, live ? vrow : OOB,
-                                             (g * 64 * C + 320 * kh + i * 64) * 2, 0, 0);
+                                             (g * 64 * C + 320 * kh + i * 64) * 2, 0, RL_DMA_AUX);
   };
   auto piece_of = [&](int j) -> int { const int q = j0 + j; return g_base + (q < np ? q : q - np); };
   {
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
   }
 
   // ---- LayerNorm of the rows in registers (two-pass; gamma / beta live in W / bias)
-  {
+  if constexpr (LN) {
     float s = 0.f;
 #pragma unroll
     for (int t5 = 0; t5 < KL; ++t5)
@@ -136,30 +143,48 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
     }
     xa_swap_rows16(a, c);
     const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-    *reinterpret_cast<uint4*>(outp + (size_t)(m_w0 + fr) * P.ld_out + col) = lr_pack8<T>(v);
+    const uint4 pk = lr_pack8<T>(v);
+#ifdef RL_DBG_NOSTORE
+    if (pk.x == 0x12345678u && pk.y == 0x9abcdef0u)
+#endif
+    *reinterpret_cast<uint4*>(outp + (size_t)(m_w0 + fr) * P.ld_out + col) = pk;
   };
 
 #define RL_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // one step in ring slot `slot` (runtime): k half KH of the current piece into acc; fragment reads one k-step ahead; the five LDS-DMA of
-  // the step after next (same k half of the NEXT piece -> slot2) after k-steps 0 .. 4; EMIT at k-steps 5 and 7 (the previous piece's units)
-#define RL_STEP(KH, NWAIT_EARLY, EARLY, EMIT)                                                                                      \
+// timing experiments of developer variants (tools/build_variant.sh x -DRL_DBG_NODMA ...): results are garbage, only the clock matters
+#ifdef RL_DBG_NODMA
+#define RL_DBG_DMA(X)
+#else
+#define RL_DBG_DMA(X) X
+#endif
+#ifdef RL_DBG_NOMFMA
+#define RL_DBG_MFMA(X) acc[jd][0] += (float)fa[ks % (RL_DEPTH + 1)][jd][0];
+#else
+#define RL_DBG_MFMA(X) X
+#endif
+
+  // one step in ring slot `slot` (runtime): k slice KH (320 k) of the current piece into acc; fragment reads one k-step ahead; the five
+  // LDS-DMA of the step after next (slice KH + 2 of this piece, or slice KH + 2 - NKS of the NEXT piece -> slot2) after k-steps 0 .. 4;
+  // EMIT at k-steps 5 and 7 (the previous piece's units).  LATE: the stores of the previous piece are among the operations younger than
+  // this step's loads (they are issued in a piece's first step)
+#define RL_STEP(KH, LATE, EMIT)                                                                                                    \
   {                                                                                                                                \
-    if (EARLY) xa_wait_vmcnt<NWAIT_EARLY>(); else xa_wait_vmcnt<5 + S>();                                                          \
+    if (LATE) xa_wait_vmcnt<5 + S>(); else xa_wait_vmcnt<5>();                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                                  \
     const char* Ws = smem + slot * RL_SLOT;                                                                                        \
     const int slot2 = slot == 0 ? 2 : slot - 1;      /* (slot + 2) % 3 */                                                          \
-    vec8<T> fa[2][4];                                                                                                              \
+    vec8<T> fa[RL_DEPTH + 1][4];                                                                                                   \
     auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {                                                        \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq);   \
     };                                                                                                                             \
-    rd(0, fa[0]);                                                                                                                  \
+    _Pragma("unroll") for (int d_ = 0; d_ < RL_DEPTH; ++d_) rd(d_, fa[d_]);                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 10; ++ks) {                                                                            \
-      if (ks + 1 < 10) rd(ks + 1, fa[(ks + 1) & 1]);                                                                               \
+      if (ks + RL_DEPTH < 10) rd(ks + RL_DEPTH, fa[(ks + RL_DEPTH) % (RL_DEPTH + 1)]);                                             \
       RL_FENCE();                                                                                                                  \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd)                                                                             \
-        acc[jd] = lr_mfma16(fa[ks & 1][jd], xf[5 * (KH) + (ks >> 1)][ks & 1], ((KH) == 0 && ks == 0) ? z4 : acc[jd]);              \
-      if (ks < 5) issue(slot2, g_next, KH, ks, more);                                                                              \
+        RL_DBG_MFMA(acc[jd] = lr_mfma16(fa[ks % (RL_DEPTH + 1)][jd], xf[5 * (KH) + (ks >> 1)][ks & 1], ((KH) == 0 && ks == 0) ? z4 : acc[jd]);) \
+      RL_DBG_DMA(if (ks < 5) { if constexpr ((KH) + 2 < NKS) issue(slot2, g, (KH) + 2, ks, true); else issue(slot2, g_next, (KH) + 2 - NKS, ks, more); }) \
       if (ks == 5) { const int u = 0; EMIT; }                                                                                      \
       if (ks == 7) { const int u = 1; EMIT; }                                                                                      \
       RL_FENCE();                                                                                                                  \
@@ -174,9 +199,18 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
     const int g = piece_of(j);
     const bool more = j + 1 < np;
     const int g_next = more ? piece_of(j + 1) : g;
-    // vector memory operations younger than a step's loads: the next step's 5 loads + the previous piece's S stores (none yet for the first steps)
-    RL_STEP(0, 5, j < 2, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
-    RL_STEP(1, 5, j < 1, { });
+    // vector memory operations younger than a step's loads: the next step's 5 loads, and the previous piece's S stores when the piece's
+    // first step (where they are issued) lies between the two -- two steps per piece: the first step from the third piece on, the second
+    // from the second piece on; four steps per piece: the second and third step from the second piece on
+    if constexpr (NKS == 2) {
+      RL_STEP(0, j >= 2, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
+      RL_STEP(1, j >= 1, { });
+    } else {
+      RL_STEP(0, false, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
+      RL_STEP(1, j >= 1, { });
+      RL_STEP(2, j >= 1, { });
+      RL_STEP(3, false, { });
+    }
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) prev[jd] = acc[jd];
     g_prev = g;
@@ -204,34 +238,50 @@ static int rowlin_ny(int M, int N) {
   return ny;
 }
 
+template <typename T, int C, bool GEGLU, bool LN>
+static int rowlin_launch(const RowlinParams& P, hipStream_t st) {
+  const size_t smem = 3 * RL_SLOT + (size_t)RL_MAX_SLICE * sizeof(float);
+  static unsigned long long attr_done = 0;
+  if (lr_attr_needed(&attr_done))
+    hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, C, GEGLU, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((rowlin_kernel<T, C, GEGLU, LN>), dim3((P.M / RL_ROWS) * P.ny), dim3(RL_THREADS), smem, st, P);
+  return lr_launch_status();
+}
+
 template <typename T>
 static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   if (!a || !a->x || !a->w || !a->bias || !a->out) return LR_E_ARG;
-  if (a->M <= 0 || a->N <= 0 || (a->geglu != 0 && a->geglu != 1)) return LR_E_ARG;
-  if (a->C != RL_C || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+  if (a->M <= 0 || a->N <= 0 || (a->geglu != 0 && a->geglu != 1) || (a->ln != 0 && a->ln != 1)) return LR_E_ARG;
+  // C = 1280 (level 2: 4096 rows) is compiled in developer builds only -- measured and lost to the tiled GEMM there: 31.9 vs 24.5 us
+  // (N = 1280), 58.2 vs 54.8 (q|k|v), 128 vs 113 (GEGLU): 32 row blocks leave 5 .. 8 column slices of a few pieces each, and the slices
+  // re-load the rows (profiles/r06_rowlin_microbench.txt)
+#ifdef LR_DEV_VARIANTS
+  if ((a->C != 640 && a->C != 1280) || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+#else
+  if (a->C != 640 || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+#endif
+  if (a->geglu && !a->ln) return LR_E_UNSUPPORTED;      // (the gated projection always follows norm3)
   const int n_out = a->geglu ? a->N / 2 : a->N;
   if (a->ld_out < n_out || a->ld_out % 8) return LR_E_ALIGN;
   if (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->bias | (uintptr_t)a->out) & 15) return LR_E_ALIGN;
-  if ((int64_t)a->N * RL_C * 2 >= ((int64_t)1 << 31)) return LR_E_UNSUPPORTED;
+  if ((int64_t)a->N * a->C * 2 >= ((int64_t)1 << 31)) return LR_E_UNSUPPORTED;
   RowlinParams P;
   P.x = a->x; P.w = a->w; P.bias = a->bias; P.out = a->out;
   P.M = a->M; P.N = a->N; P.ld_out = a->ld_out; P.eps = a->ln_eps;
   P.ny = rowlin_ny(a->M, a->N);
   P.np = a->N / 64 / P.ny;
   if (P.np * 64 > RL_MAX_SLICE) return LR_E_UNSUPPORTED;
-  const size_t smem = 3 * RL_SLOT + (size_t)RL_MAX_SLICE * sizeof(float);
-  static unsigned long long attr_done[2] = {0, 0};
-  const dim3 grid((a->M / RL_ROWS) * P.ny), block(RL_THREADS);
-  if (a->geglu) {
-    if (lr_attr_needed(&attr_done[1]))
-      hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((rowlin_kernel<T, true>), grid, block, smem, (hipStream_t)s, P);
-  } else {
-    if (lr_attr_needed(&attr_done[0]))
-      hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((rowlin_kernel<T, false>), grid, block, smem, (hipStream_t)s, P);
+  hipStream_t st = (hipStream_t)s;
+  if (a->C == 640) {
+    if (a->geglu) return rowlin_launch<T, 640, true, true>(P, st);
+    return a->ln ? rowlin_launch<T, 640, false, true>(P, st) : rowlin_launch<T, 640, false, false>(P, st);
   }
-  return lr_launch_status();
+#ifdef LR_DEV_VARIANTS
+  if (a->geglu) return rowlin_launch<T, 1280, true, true>(P, st);
+  return a->ln ? rowlin_launch<T, 1280, false, true>(P, st) : rowlin_launch<T, 1280, false, false>(P, st);
+#else
+  return LR_E_UNSUPPORTED;
+#endif
 }
 
 extern "C" int lr_rowlin_f16(const lr_rowlin_args* a, lr_stream_t s) { return rowlin_t<f16>(a, s); }

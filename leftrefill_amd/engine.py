@@ -274,11 +274,11 @@ def fold_ok(x):
     return LN_FOLD and not (torch.is_grad_enabled() and x.requires_grad)
 
 
-def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear, wide=False):
+def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear, wide=None):
     """Linear(LayerNorm(x)).  st: per-row (sum, sumsq) partials of x from the GEMM that produced it, or None.
     With st the LayerNorm is folded into the GEMM (no normalised tensor is written); otherwise the LayerNorm kernel runs.
-    wide: a projection several times wider than x (the fused q|k|v) -- at C = 640 the row-resident kernel takes it."""
-    if wide and pl.wf is not None and fold_ok(x) and _PLAN_SCALE_ONE() and ops.rowlin_ok(x.shape[0], x.shape[1], pl.wf.shape[0]):
+    wide: "qkv" | "q" -- the kind of projection (ops.ROWLIN_WIDTHS) the row-resident kernel may take at this width."""
+    if wide and pl.wf is not None and fold_ok(x) and _PLAN_SCALE_ONE() and ops.rowlin_ok(x.shape[0], x.shape[1], pl.wf.shape[0], wide):
         return ops.rowlin(x, pl.wf, pl.bf, eps=pl.eps)
     if st is not None and pl.wf is not None and fold_ok(x):
         return ops.gemm_conv(x, pl.wf, B=1, H=1, W=x.shape[0], taps=1, bias=pl.bf, ln=(st, pl.eps, pl.cs))
@@ -357,7 +357,7 @@ def attention_plain(x, ctx, pa: PackedAttn, B, L, Lc=None):
     return linear(a, pa.out)
 
 
-def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None, wide=False):
+def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None, wide=None):
     """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None); qkv: the projection when its producer already
     made it (ops.stin_block); wide: single-view blocks let the row-resident kernel take the projection (the multi-view forms keep the
     LayerNorm-folded GEMM, whose arithmetic the sharded path reproduces bit for bit)."""
@@ -398,11 +398,11 @@ def self_then_cross_attention(x, st, pt, N, L, Lc, kv, want_stats, dup=False, qk
     pa1, pa2 = pt.attn1, pt.attn2
     if dup:
         with plan_batch_scale(2):
-            qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide=True) if qkv0 is None else qkv0
+            qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide="qkv") if qkv0 is None else qkv0
         a = dup2(ops.attention_qkv(qkv, N // 2, pa1.heads, L, pa1.dim_head ** -0.5))
         x = dup2(x)
     else:
-        qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide=True) if qkv0 is None else qkv0
+        qkv = ln_linear(x, st, pt.n1, pa1.qkv, wide="qkv") if qkv0 is None else qkv0
         a = ops.attention_qkv(qkv, N, pa1.heads, L, pa1.dim_head ** -0.5)
     return ops.xattn_block(x, pa2.xq_pi, pa2.q.bf, kv[2], kv[3], pa2.xwo, pa2.out.b, HW=L, heads=pa2.heads, Lc=Lc, eps=pa2.q.eps,
                            scale=pa2.dim_head ** -0.5, want_stats=want_stats, pre=(a, pa1.out.w, pa1.out.b))
@@ -421,10 +421,10 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
                                scale=pa.dim_head ** -0.5, want_stats=want_stats)
     if dup:
         with plan_batch_scale(2):
-            q = ln_linear(x, st, pn, pa.q)
+            q = ln_linear(x, st, pn, pa.q, wide="q")
         q, x = dup2(q), dup2(x)
     else:
-        q = ln_linear(x, st, pn, pa.q)
+        q = ln_linear(x, st, pn, pa.q, wide="q")
     vt = None
     if kv is None:
         kv = linear(ctx, pa.kv)
@@ -453,9 +453,9 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
         return _ffn(x, st, pt, want_stats, post, use_ffn)
     if pt.view_num is None and dup:
         with plan_batch_scale(2):
-            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws, qkv=qkv0, wide=True)
+            x = self_attention(x, st, pt.n1, pt.attn1, N // 2, L, want_stats=ws, qkv=qkv0, wide="qkv")
     elif pt.view_num is None:
-        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws, qkv=qkv0, wide=True)
+        x = self_attention(x, st, pt.n1, pt.attn1, N, L, want_stats=ws, qkv=qkv0, wide="qkv")
     elif pt.concat_target and not pt.no_rearrange and MV_SHARDED:
         x = _mv_sharded_self_attention(x, pt, N, L, st)
         ws = False
@@ -508,7 +508,7 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
         ws = want_stats and fold_ok(x)
         y = ops.ffn_block(x, pt.geglu_wf, pt.geglu_bf, pt.ff2_x, pt.ff2.b, eps=pt.n3.eps, want_stats=ws)
         return y if ws else (y, None)
-    if fold_ok(x) and ops.rowlin_ok(x.shape[0], x.shape[1], pt.geglu_wf.shape[0]):
+    if fold_ok(x) and ops.rowlin_ok(x.shape[0], x.shape[1], pt.geglu_wf.shape[0], "geglu"):
         # C = 640: LayerNorm + GEGLU projection + gate with the rows resident in registers (lr_rowlin_f16)
         g = ops.rowlin(x, pt.geglu_wf, pt.geglu_bf, eps=pt.n3.eps, geglu=True)
     elif st is not None:
@@ -679,6 +679,12 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
                 # columns multiply
                 pq = ps.blocks[0].attn1.qkv
                 h, qkv0 = ops.stin_block(h, ps.proj_in.w, ps.proj_in.b, pq.wf, pq.bf, eps=pq.eps)
+                ws = False
+            elif (fold_ok(h) and ps.proj_in.b is not None and ps.proj_in.w.shape == (h.shape[1], h.shape[1]) and ps.blocks
+                  and ps.blocks[0].view_num is None and ops.rowlin_ok(h.shape[0], h.shape[1], h.shape[1], "in")):
+                # proj_in with the rows resident in registers (levels 1 / 2); its consumers normalise their rows themselves or take the
+                # LayerNorm kernel (multi-view forms), so no row statistics ride on it
+                h = ops.rowlin(h, ps.proj_in.w, ps.proj_in.b, ln=False)
                 ws = False
             else:
                 ws = fold_ok(h)

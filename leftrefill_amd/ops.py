@@ -636,24 +636,30 @@ def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None):
     return x1, qkv
 
 
-ROWLIN_C, ROWLIN_ROWS = 640, 128
-# LEFTREFILL_ROWLIN=0 keeps the LayerNorm-folded tiled GEMMs for the q|k|v and GEGLU projections at C = 640
+ROWLIN_ROWS = 128
+# widths the row-resident kernel takes, by kind of projection: "qkv" (LayerNorm + fused q|k|v), "q" (LayerNorm + attn2.to_q), "in" (plain
+# proj_in), "geglu" (LayerNorm + gated projection).  Level 1 only: at level 2 (C = 1280, 4096 rows) it was measured and lost to the tiled
+# GEMM (31.9 vs 24.5 us at N = 1280, 58.2 vs 54.8 q|k|v, 128 vs 113 GEGLU; profiles/r06_rowlin_microbench.txt) -- that instance is
+# compiled in developer builds only.
+ROWLIN_WIDTHS = {"qkv": (640,), "q": (), "in": (640,), "geglu": (640,)}
+ROWLIN_MIN_ROWS = 2048      # below this the column slices of a launch cannot fill the chip
+# LEFTREFILL_ROWLIN=0 keeps the tiled GEMMs everywhere
 ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
 
 
-def rowlin_ok(M, C, N):
-    """Shapes lr_rowlin_f16 takes (everything else keeps the LayerNorm-folded GEMM)."""
-    return ROWLIN and C == ROWLIN_C and M % ROWLIN_ROWS == 0 and N > 0 and N % 64 == 0
+def rowlin_ok(M, C, N, kind="qkv"):
+    """Shapes / uses lr_rowlin_f16 takes (everything else keeps the [LayerNorm-folded] GEMM)."""
+    return ROWLIN and C in ROWLIN_WIDTHS.get(kind, ()) and M % ROWLIN_ROWS == 0 and M >= ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0
 
 
-def rowlin(x, w, bias, *, eps, geglu=False, out=None):
+def rowlin(x, w, bias, *, eps=1e-5, geglu=False, ln=True, out=None):
     """LayerNorm(x) w^T + bias (geglu: value * gelu(gate) of the interleaved rows) with the rows resident in registers (lr_rowlin_f16):
     the wide short-K projections of a C = 640 block.  w / bias: packing.fold_layernorm (GEGLU: in packing.geglu_perm row order)."""
     lib = _lib.load()
     _chk16(x, "x")
     M, C = x.shape
     N = w.shape[0]
-    assert rowlin_ok(M, C, N), (M, C, N)
+    assert C in (640, 1280) and M % ROWLIN_ROWS == 0 and N % 64 == 0, (M, C, N)      # (1280: developer builds of the library only)
     assert w.dtype == x.dtype and w.is_contiguous() and w.shape == (N, C) and bias.dtype == torch.float32 and bias.numel() == N
     n_out = N // 2 if geglu else N
     if out is None:
@@ -661,7 +667,7 @@ def rowlin(x, w, bias, *, eps, geglu=False, out=None):
     assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype
     a = RowlinArgs()
     a.x, a.w, a.bias, a.out = _p(x), _p(w), _p(bias), _p(out)
-    a.M, a.C, a.N, a.ld_out, a.geglu, a.ln_eps = M, C, N, out.stride(0), int(bool(geglu)), float(eps)
+    a.M, a.C, a.N, a.ld_out, a.geglu, a.ln_eps, a.ln = M, C, N, out.stride(0), int(bool(geglu)), float(eps), int(bool(ln))
     _lib.check(_fn(lib, "lr_rowlin_f16", x.dtype)(a, _stream()), "rowlin")
     return out
 

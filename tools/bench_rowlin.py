@@ -12,10 +12,13 @@ from tools.bench_xattn import time_seq  # noqa: E402
 
 def main():
     d = torch.device("cuda:0")
-    C, M = 640, 16384
     g = torch.Generator(device="cpu").manual_seed(0)
-    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
-    for geglu, N in ((False, 1920), (True, 5120)):
+    from leftrefill_amd import _lib
+    shapes = [(640, 16384, False, 1920), (640, 16384, True, 5120), (640, 16384, False, 640)]
+    if _lib.dev_variants():      # the level-2 instance exists in developer builds only (measured, lost)
+        shapes += [(1280, 4096, False, 1280), (1280, 4096, False, 3840), (1280, 4096, True, 10240)]
+    for C, M, geglu, N in shapes:
+        gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
         w = torch.randn(N, C, generator=g) / C ** 0.5
         b = torch.randn(N, generator=g)
         wf, bf, cs = packing.fold_layernorm(w, b, gamma, beta)
@@ -34,7 +37,7 @@ def main():
         fused = lambda i: ops.rowlin(xs[i], wf, bf, eps=1e-5, geglu=geglu, out=outs[i])
         plain = lambda i: ops.gemm_conv(xs[i], wf, B=1, H=1, W=M, taps=1, bias=bf, geglu=geglu, ln=(sts[i], 1e-5, cs), out=outs[i])
         flops = 2.0 * M * C * N
-        print(f"M={M} N={N} geglu={geglu}")
+        print(f"M={M} N={N} K={C} geglu={geglu}")
         for name, fn in (("row-resident", fused), ("tiled GEMM", plain)):
             fn(0)
             torch.cuda.synchronize()
