@@ -721,6 +721,13 @@ def measure_traffic(launches):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def emit_json_line(obj):
+    """One JSON line on stdout as ONE write: several ranks may report at the same moment, and print() writes the text and the newline
+    separately (two ranks' lines were seen glued together)."""
+    sys.stdout.flush()
+    os.write(1, (json.dumps(obj) + "\n").encode())
+
+
 def dist_selftest(rank, world, device, backend, share):
     """First-contact checks of the multi-GPU job, before anything is timed: every stage is a named entry, the first
     failure is what the JSON line reports.  Semantics the collectives must reproduce: the all-gather before the re-arranged cross-view
@@ -846,7 +853,7 @@ def main():
                "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": {"stage": _STAGE[0], "rank": rank, "type": type(e).__name__,
                                                                          "detail": str(e)[:500], "traceback_tail": traceback.format_exc()[-1500:]}}
         if rank == 0 or _STAGE[0] in ("init_process_group", "selftest"):
-            print(json.dumps(err), flush=True)
+            emit_json_line(err)
         print(f"[bench rank {rank}] failed in stage {_STAGE[0]}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         sys.exit(1)
 
@@ -928,9 +935,9 @@ def _main():
         _STAGE[0] = "selftest"
         selftest = dist_selftest(rank, world, torch.device("cuda", torch.cuda.current_device()), backend, share)
         if not selftest["ok"]:      # every rank prints its own view: the collective that would gather them is what failed
-            print(json.dumps({"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": None,
-                              "unit": "images/s", "n_gpus": world,
-                              "error": {"stage": "selftest:" + selftest["failed_stage"], "rank": rank, "selftest": selftest}}), flush=True)
+            emit_json_line({"metric": "512x1024 stitched images/sec @ 50 DDIM steps, cfg=2.5; per-UNet-step ms", "value": None,
+                            "unit": "images/s", "n_gpus": world,
+                            "error": {"stage": "selftest:" + selftest["failed_stage"], "rank": rank, "selftest": selftest}})
             sys.exit(1)
     else:
         torch.cuda.set_device(0)
@@ -1003,8 +1010,8 @@ def _main():
         if not all(flags):
             selftest.update(ok=False, failed_stage="mv_graph_vs_eager")
             if rank == 0:
-                print(json.dumps({"metric": "multi-view samples/sec", "value": None, "unit": "samples/s", "n_gpus": world,
-                                  "error": {"stage": "selftest:mv_graph_vs_eager", "selftest": selftest}}), flush=True)
+                emit_json_line({"metric": "multi-view samples/sec", "value": None, "unit": "samples/s", "n_gpus": world,
+                                "error": {"stage": "selftest:mv_graph_vs_eager", "selftest": selftest}})
             sys.exit(1)
     # one-time preparation, like building the model: tile autotune + hipGraph capture for this shape (a 4-step sampling),
     # so that --warmup 0 does not put them inside the timed region

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   const int nch_all = ncm + ((P.C3 + P.C4) >> 6);                    // chunks: the 3x3 part, then the pointwise extension (one tap each)
   // split-K (blockIdx.y): whole chunks [c_begin, nch) per slice, fp32 partial tiles to P.ws, epilogue in splitk_reduce_kernel
   const int c_per = (nch_all + P.splits - 1) / P.splits;
-  const int c_begin = blockIdx.y * c_per;
+  const int c_begin = min((int)blockIdx.y * c_per, nch_all);         // (a slice beyond the last chunk is empty: nsteps = 0)
   const int nch = min(nch_all, c_begin + c_per);
   const int nsteps = (min(nch, ncm) - min(c_begin, ncm)) * 9 + (max(nch, ncm) - max(c_begin, ncm));
   auto issue_patch = [&](const int ci) __attribute__((always_inline)) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
 
   LR_STAMP(0);
   stage_params<BN, PAR_LD>(P, par, n0, w, lane, 0);
-  issue_patch(c_begin);
+  if (nsteps > 0) issue_patch(c_begin);  // (block-uniform)
   int wci = c_begin, wtap = 0;           // K-step whose weights are issued next
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE - 1; ++sidx) {
@@ -305,7 +305,8 @@ int lr_launch_conv_halo(const GemmParams& P, int tile_n, hipStream_t st) {
       P.wt_bstride || P.st_out || ((P.H & 15) && !(P.H == 8 && P.M % 256 == 0)) || (P.W & 15) || P.Hs != P.H || P.Ws != P.W)
     return LR_E_UNSUPPORTED;
   if ((long long)P.M >= (1ll << 28)) return LR_E_UNSUPPORTED;      // the patch loader packs (pixel index | chunk << 28) into one register
-  if (P.splits > (P.C1 + P.C2 + P.C3 + P.C4) / 64) return LR_E_ARG;      // a K slice owns at least one 64-channel chunk
+  // (splits above the number of 64-channel chunks are legal: the surplus slices own no chunk and write zero partials -- made explicit in the
+  // kernel, ADVICE r5: c_begin is clamped, an empty slice issues no patch load and runs no K-step)
   if (tile_n == 320) return P.bf16 ? launch_halo_t<320, 2, 2, bf16>(P, st) : launch_halo_t<320, 2, 2, f16>(P, st);
   if (tile_n == 160) return P.bf16 ? launch_halo_t<160, 4, 3, bf16>(P, st) : launch_halo_t<160, 4, 3, f16>(P, st);
   return LR_E_UNSUPPORTED;
