@@ -32,13 +32,17 @@ struct RowlinParams {
   float eps;
 };
 
-// C = 640 | 1280 (levels 1 / 2: two / four 320-k steps per 64-column piece); LN = false: a plain Linear (SpatialTransformer.proj_in)
+// C = 320 | 640 | 1280 (levels 0 / 1 / 2: one / two / four 320-k steps per 64-column piece); LN = false: a plain Linear (proj_in).
+// C = 320: every wave owns 32 rows as TWO B-operand sets (each weight fragment feeds two MFMAs; 256-row blocks, like stin_block.hip).
 template <typename T, int C, bool GEGLU, bool LN>
 __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KL = C / 64;                // sub-tiles of 64 k, 5 per step
   constexpr int NKS = C / 320;              // steps per piece
-  constexpr int S = GEGLU ? 1 : 2;          // 16-byte stores per lane and piece
+  constexpr int RS = C == 320 ? 2 : 1;      // 16-row sets per wave
+  constexpr int UPR = GEGLU ? 1 : 2;        // emission units (one 16-byte store per lane each) per row set and piece
+  constexpr int NU = RS * UPR;              // ... per piece
+  constexpr int S = NU;                     // 16-byte stores per lane and piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* par = reinterpret_cast<float*>(smem + 3 * RL_SLOT);      // bias of this block's weight rows
 
@@ -47,18 +51,21 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
   const int fr = lane & 15, fq = lane >> 4;
   const int odd = fq & 1, ch8 = (fq >> 1) * 8;
   const int rb = blockIdx.x / P.ny, y = blockIdx.x - rb * P.ny;
-  const int m_w0 = rb * RL_ROWS + w * 16;
+  const int m_w0 = rb * (RL_ROWS * RS) + w * 16 * RS;
   const int np = P.np;
   const int g_base = y * np;                // first piece (64 weight rows) of this block's slice
   const int j0 = rb % np;                   // the order of the pieces is free: neighbouring row blocks start at different pieces
 
-  // ---- the wave's 16 rows in B-operand form: lane (fr, fq) holds x[m_w0 + fr][64 t5 + 32 u + 8 fq .. + 7]
-  const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + fr) * C + 8 * fq;
-  vec8<T> xf[KL][2];
+  // ---- the wave's rows in B-operand form: lane (fr, fq), set rs holds x[m_w0 + 16 rs + fr][64 t5 + 32 u + 8 fq .. + 7]
+  vec8<T> xf[RS][KL][2];
 #pragma unroll
-  for (int t5 = 0; t5 < KL; ++t5)
+  for (int rs = 0; rs < RS; ++rs) {
+    const T* xrow = reinterpret_cast<const T*>(P.x) + (size_t)(m_w0 + 16 * rs + fr) * C + 8 * fq;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xf[t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
+    for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) xf[rs][t5][u] = *reinterpret_cast<const vec8<T>*>(xrow + 64 * t5 + 32 * u);
+  }
   for (int i = t; i < np * 16; i += RL_THREADS)       // bias rows of the slice -> LDS (no register loads inside the loop below)
     *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(P.bias + (size_t)g_base * 64 + 4 * i);
 
@@ -73,47 +80,53 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
                                              (g * 64 * C + 320 * kh + i * 64) * 2, 0, RL_DMA_AUX);
   };
   auto piece_of = [&](int j) -> int { const int q = j0 + j; return g_base + (q < np ? q : q - np); };
-  {
+  {      // the first two steps: slices 0, 1 of the first piece, or (one step per piece) the first two pieces
     const int g0 = piece_of(0);
 #pragma unroll
     for (int i = 0; i < 5; ++i) issue(0, g0, 0, i, true);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) issue(1, g0, 1, i, true);
+    for (int i = 0; i < 5; ++i) {
+      if constexpr (NKS == 1) issue(1, np > 1 ? piece_of(1) : g0, 0, i, np > 1); else issue(1, g0, 1, i, true);
+    }
   }
 
   // ---- LayerNorm of the rows in registers (two-pass; gamma / beta live in W / bias)
   if constexpr (LN) {
-    float s = 0.f;
 #pragma unroll
-    for (int t5 = 0; t5 < KL; ++t5)
+    for (int rs = 0; rs < RS; ++rs) {
+      __builtin_amdgcn_sched_barrier(0);      // one row set at a time (register pressure)
+      float sm = 0.f;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += (float)xf[t5][u][i];
-    const float mean = xa_row4_sum(s) * (1.0f / C);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int t5 = 0; t5 < KL; ++t5)
+          for (int i = 0; i < 8; ++i) sm += (float)xf[rs][t5][u][i];
+      const float mean = xa_row4_sum(sm) * (1.0f / C);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[t5][u]));      // (convert again per pass: keeps 160 floats out of the register file)
-    float q2 = 0.f;
+      for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-    for (int t5 = 0; t5 < KL; ++t5)
+        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[rs][t5][u]));      // (convert again per pass: keeps the converted floats out of the register file)
+      float q2 = 0.f;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = (float)xf[t5][u][i] - mean; q2 = fmaf(d, d, q2); }
-    const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
-    const float nmr = -mean * rstd;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int t5 = 0; t5 < KL; ++t5)
+          for (int i = 0; i < 8; ++i) { const float d = (float)xf[rs][t5][u][i] - mean; q2 = fmaf(d, d, q2); }
+      const float rstd = rsqrtf(xa_row4_sum(q2) * (1.0f / C) + P.eps);
+      const float nmr = -mean * rstd;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[t5][u]));
+      for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-    for (int t5 = 0; t5 < KL; ++t5)
+        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(xf[rs][t5][u]));
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int t5 = 0; t5 < KL; ++t5)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xf[t5][u][i] = (T)fmaf((float)xf[t5][u][i], rstd, nmr);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xf[rs][t5][u][i] = (T)fmaf((float)xf[rs][t5][u][i], rstd, nmr);
+    }
   }
 
   const int sw = (fr >> 1) & 7;
@@ -122,9 +135,11 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
   };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   T* outp = reinterpret_cast<T*>(P.out);
-  // emit unit u of a finished piece (local piece index lp, global g): plain -- tiles (2 u, 2 u + 1) = 32 columns; GEGLU -- the piece's 32
-  // gated columns (u = 0 only): + bias, [gate,] 16 bits, permlane swap, one 16-byte store per lane
-  auto emit_unit = [&](const f32x4 (&acc)[4], int lp, int g, int u) __attribute__((always_inline)) {
+  // emit unit uu of a finished piece (local piece index lp, global g): row set uu / UPR; plain -- tiles (2 u, 2 u + 1) = 32 columns with
+  // u = uu % 2; GEGLU -- the piece's 32 gated columns: + bias, [gate,] 16 bits, permlane swap, one 16-byte store per lane
+  auto emit_unit = [&](const f32x4 (&accs)[RS][4], int lp, int g, int uu) __attribute__((always_inline)) {
+    const int rs = uu / UPR, u = uu % UPR;
+    const f32x4 (&acc)[4] = accs[rs];
     const float* b = par + lp * 64 + 4 * fq;
     f32x4 a, c;
     int col;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
 #ifdef RL_DBG_NOSTORE
     if (pk.x == 0x12345678u && pk.y == 0x9abcdef0u)
 #endif
-    *reinterpret_cast<uint4*>(outp + (size_t)(m_w0 + fr) * P.ld_out + col) = pk;
+    *reinterpret_cast<uint4*>(outp + (size_t)(m_w0 + 16 * rs + fr) * P.ld_out + col) = pk;
   };
 
 #define RL_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -158,22 +173,25 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
 #define RL_DBG_DMA(X) X
 #endif
 #ifdef RL_DBG_NOMFMA
-#define RL_DBG_MFMA(X) acc[jd][0] += (float)fa[ks % (RL_DEPTH + 1)][jd][0];
+#define RL_DBG_MFMA(X) acc[rs][jd][0] += (float)fa[ks % (RL_DEPTH + 1)][jd][0];
 #else
 #define RL_DBG_MFMA(X) X
 #endif
 
   // one step in ring slot `slot` (runtime): k slice KH (320 k) of the current piece into acc; fragment reads one k-step ahead; the five
-  // LDS-DMA of the step after next (slice KH + 2 of this piece, or slice KH + 2 - NKS of the NEXT piece -> slot2) after k-steps 0 .. 4;
-  // EMIT at k-steps 5 and 7 (the previous piece's units).  LATE: the stores of the previous piece are among the operations younger than
-  // this step's loads (they are issued in a piece's first step)
-#define RL_STEP(KH, LATE, EMIT)                                                                                                    \
+  // LDS-DMA of the step after next after k-steps 0 .. 4 (slice (KH + 2) % NKS of the piece (KH + 2) / NKS further on -> slot2); EMIT(u) at
+  // k-steps 5 .. (the previous piece's NU units).  NB = how many of the two previous steps were a piece's FIRST step with stores to issue
+  // (those stores are vector memory operations younger than this step's loads, like the next step's five loads)
+#define RL_STEP(KH, NB, EMIT)                                                                                                      \
   {                                                                                                                                \
-    if (LATE) xa_wait_vmcnt<5 + S>(); else xa_wait_vmcnt<5>();                                                                     \
+    { const int nb_ = (NB); if (nb_ == 2) xa_wait_vmcnt<5 + 2 * S>(); else if (nb_ == 1) xa_wait_vmcnt<5 + S>(); else xa_wait_vmcnt<5>(); } \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                                  \
     const char* Ws = smem + slot * RL_SLOT;                                                                                        \
     const int slot2 = slot == 0 ? 2 : slot - 1;      /* (slot + 2) % 3 */                                                          \
+    constexpr int po_ = ((KH) + 2) / NKS, kh2_ = ((KH) + 2) % NKS;                                                                 \
+    const int g2_ = po_ == 0 ? g : po_ == 1 ? g_next : g_next2;                                                                    \
+    const bool live2_ = po_ == 0 ? true : po_ == 1 ? more : more2;                                                                 \
     vec8<T> fa[RL_DEPTH + 1][4];                                                                                                   \
     auto rd = [&](int ks, vec8<T> (&f)[4]) __attribute__((always_inline)) {                                                        \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd) f[jd] = frag(Ws + (ks >> 1) * 64 * 128, jd * 16 + fr, 4 * (ks & 1) + fq);   \
@@ -183,49 +201,52 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
       if (ks + RL_DEPTH < 10) rd(ks + RL_DEPTH, fa[(ks + RL_DEPTH) % (RL_DEPTH + 1)]);                                             \
       RL_FENCE();                                                                                                                  \
       _Pragma("unroll") for (int jd = 0; jd < 4; ++jd)                                                                             \
-        RL_DBG_MFMA(acc[jd] = lr_mfma16(fa[ks % (RL_DEPTH + 1)][jd], xf[5 * (KH) + (ks >> 1)][ks & 1], ((KH) == 0 && ks == 0) ? z4 : acc[jd]);) \
-      RL_DBG_DMA(if (ks < 5) { if constexpr ((KH) + 2 < NKS) issue(slot2, g, (KH) + 2, ks, true); else issue(slot2, g_next, (KH) + 2 - NKS, ks, more); }) \
-      if (ks == 5) { const int u = 0; EMIT; }                                                                                      \
-      if (ks == 7) { const int u = 1; EMIT; }                                                                                      \
+        _Pragma("unroll") for (int rs = 0; rs < RS; ++rs)                                                                          \
+          RL_DBG_MFMA(acc[rs][jd] = lr_mfma16(fa[ks % (RL_DEPTH + 1)][jd], xf[rs][5 * (KH) + (ks >> 1)][ks & 1], ((KH) == 0 && ks == 0) ? z4 : acc[rs][jd]);) \
+      RL_DBG_DMA(if (ks < 5) issue(slot2, g2_, kh2_, ks, live2_);)                                                                 \
+      { constexpr int st_ = NU == 4 ? 1 : 2;                                                                                       \
+        if (ks >= 5 && (ks - 5) % st_ == 0 && (ks - 5) / st_ < NU) { const int u = (ks - 5) / st_; EMIT; } }                       \
       RL_FENCE();                                                                                                                  \
     }                                                                                                                              \
     slot = slot == 2 ? 0 : slot + 1;                                                                                               \
   }
 
-  f32x4 acc[4], prev[4];
+  f32x4 acc[RS][4], prev[RS][4];
   int slot = 0, g_prev = 0;
 #pragma unroll 1
   for (int j = 0; j < np; ++j) {
     const int g = piece_of(j);
-    const bool more = j + 1 < np;
-    const int g_next = more ? piece_of(j + 1) : g;
-    // vector memory operations younger than a step's loads: the next step's 5 loads, and the previous piece's S stores when the piece's
-    // first step (where they are issued) lies between the two -- two steps per piece: the first step from the third piece on, the second
-    // from the second piece on; four steps per piece: the second and third step from the second piece on
-    if constexpr (NKS == 2) {
-      RL_STEP(0, j >= 2, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
+    const bool more = j + 1 < np, more2 = j + 2 < np;
+    const int g_next = more ? piece_of(j + 1) : g, g_next2 = more2 ? piece_of(j + 2) : g;
+    // the previous piece's stores are issued in a piece's first step; see RL_STEP for NB
+    if constexpr (NKS == 1) {
+      RL_STEP(0, (j >= 3) + (j >= 2), { if (j > 0) emit_unit(prev, g_prev - g_base, g_prev, u); });
+    } else if constexpr (NKS == 2) {
+      RL_STEP(0, j >= 2, { if (j > 0) emit_unit(prev, g_prev - g_base, g_prev, u); });
       RL_STEP(1, j >= 1, { });
     } else {
-      RL_STEP(0, false, { if (j > 0 && (u == 0 || !GEGLU)) emit_unit(prev, g_prev - g_base, g_prev, u); });
+      RL_STEP(0, 0, { if (j > 0) emit_unit(prev, g_prev - g_base, g_prev, u); });
       RL_STEP(1, j >= 1, { });
       RL_STEP(2, j >= 1, { });
-      RL_STEP(3, false, { });
+      RL_STEP(3, 0, { });
     }
 #pragma unroll
-    for (int jd = 0; jd < 4; ++jd) prev[jd] = acc[jd];
+    for (int rs = 0; rs < RS; ++rs)
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) prev[rs][jd] = acc[rs][jd];
     g_prev = g;
   }
 #pragma unroll
-  for (int u = 0; u < (GEGLU ? 1 : 2); ++u) emit_unit(prev, g_prev - g_base, g_prev, u);
-  xa_wait_vmcnt<0>();                      // (the dead prefetches of the last piece)
+  for (int u = 0; u < NU; ++u) emit_unit(prev, g_prev - g_base, g_prev, u);
+  xa_wait_vmcnt<0>();                      // (the dead prefetches of the last pieces)
 #undef RL_STEP
 #undef RL_FENCE
 #endif
 }
 
 // column slices per row block: as many as keep ~one block per CU, dividing the number of 64-row pieces
-static int rowlin_ny(int M, int N) {
-  const int rbs = M / RL_ROWS, pieces = N / 64;
+static int rowlin_ny(int M, int N, int rows) {
+  const int rbs = M / rows, pieces = N / 64;
   int want = 256 / (rbs > 0 ? rbs : 1);
   if (want < 1) want = 1;
   int ny = 1;
@@ -244,7 +265,7 @@ static int rowlin_launch(const RowlinParams& P, hipStream_t st) {
   static unsigned long long attr_done = 0;
   if (lr_attr_needed(&attr_done))
     hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, C, GEGLU, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((rowlin_kernel<T, C, GEGLU, LN>), dim3((P.M / RL_ROWS) * P.ny), dim3(RL_THREADS), smem, st, P);
+  hipLaunchKernelGGL((rowlin_kernel<T, C, GEGLU, LN>), dim3((P.M / (C == 320 ? 2 * RL_ROWS : RL_ROWS)) * P.ny), dim3(RL_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
@@ -255,10 +276,11 @@ static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   // C = 1280 (level 2: 4096 rows) is compiled in developer builds only -- measured and lost to the tiled GEMM there: 31.9 vs 24.5 us
   // (N = 1280), 58.2 vs 54.8 (q|k|v), 128 vs 113 (GEGLU): 32 row blocks leave 5 .. 8 column slices of a few pieces each, and the slices
   // re-load the rows (profiles/r06_rowlin_microbench.txt)
+  const int rows = a->C == 320 ? 2 * RL_ROWS : RL_ROWS;
 #ifdef LR_DEV_VARIANTS
-  if ((a->C != 640 && a->C != 1280) || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+  if ((a->C != 320 && a->C != 640 && a->C != 1280) || a->M % rows || a->N % 64) return LR_E_UNSUPPORTED;
 #else
-  if (a->C != 640 || a->M % RL_ROWS || a->N % 64) return LR_E_UNSUPPORTED;
+  if ((a->C != 320 && a->C != 640) || a->M % rows || a->N % 64) return LR_E_UNSUPPORTED;
 #endif
   if (a->geglu && !a->ln) return LR_E_UNSUPPORTED;      // (the gated projection always follows norm3)
   const int n_out = a->geglu ? a->N / 2 : a->N;
@@ -268,10 +290,14 @@ static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   RowlinParams P;
   P.x = a->x; P.w = a->w; P.bias = a->bias; P.out = a->out;
   P.M = a->M; P.N = a->N; P.ld_out = a->ld_out; P.eps = a->ln_eps;
-  P.ny = rowlin_ny(a->M, a->N);
+  P.ny = rowlin_ny(a->M, a->N, rows);
   P.np = a->N / 64 / P.ny;
   if (P.np * 64 > RL_MAX_SLICE) return LR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)s;
+  if (a->C == 320) {      // level 0: the gated projection only (q|k|v and proj_in are stin_block's)
+    if (a->geglu) return rowlin_launch<T, 320, true, true>(P, st);
+    return LR_E_UNSUPPORTED;
+  }
   if (a->C == 640) {
     if (a->geglu) return rowlin_launch<T, 640, true, true>(P, st);
     return a->ln ? rowlin_launch<T, 640, false, true>(P, st) : rowlin_launch<T, 640, false, false>(P, st);

@@ -226,7 +226,7 @@ class PackedST:
         self._ff_src = None
         ff2 = st.transformer_blocks[-1].ff.net[2]
         wp = st.proj_out.weight
-        if self.proj_out_x is None and wp.shape[0] == wp.shape[1] == ff2.weight.shape[0] and wp.shape[1] % 64 == 0:
+        if wp.shape[0] == wp.shape[1] == ff2.weight.shape[0] and wp.shape[1] % 64 == 0:      # (C = 320 too: the split feed-forward path, ops.FFN_SPLIT)
             self._ff_src = (st.proj_out, ff2, compute_dtype())
 
     def _build_ff_proj(self):
@@ -434,7 +434,7 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
     return linear(a, pa.out, resid=x, want_stats=want_stats)
 
 
-def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False, post=None, qkv0=None):
+def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want_stats=False, dup=False, post=None, qkv0=None, ffn_split=False):
     """x [N*L, C]; ctx [N*Lc, Dc].  attention.py:279-283 / multiview_attention.py:431-468.
     st: per-row statistics of x from its producer (enables the LayerNorm fold); returns (x, statistics of x | None).
     dup (single-view blocks only): x carries the first N / 2 samples of a CFG batch whose halves are identical; the
@@ -443,7 +443,7 @@ def transformer_block(x, ctx, pt: PackedTBlock, N, L, Lc, kv=None, st=None, want
     # The two fused-block decisions are taken ONCE per block: they steer which producers emit row statistics, so every
     # consumer below must see the same answer.  (Both are pure functions of shapes, switches and the autograd state.)
     use_xattn = xattn_fused(x, pt.attn2, N, L, Lc, kv)
-    use_ffn = ffn_fused(x, pt, rows=N * L, ctx=ctx)      # rows of the block's output: x may still hold half of a CFG batch here (`dup`)
+    use_ffn = ffn_fused(x, pt, rows=N * L, ctx=ctx) and not ffn_split      # rows of the block's output: x may still hold half of a CFG batch here (`dup`)
     # ask the residual GEMMs for the row statistics the next LayerNorm fold needs (the fused blocks normalise their rows themselves)
     ws = fold_ok(x) and not use_xattn
     if pt.view_num is None and XATTN_PRE and use_xattn and pt.attn1.out.b is not None:
@@ -699,12 +699,15 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
         last = i + 1 == len(ps.blocks)
         post = None
-        if last and ps.proj_out_x is not None:
+        # level 0 with the split feed-forward (row-resident GEGLU projection + one composed GEMM) instead of the fused block
+        split = (last and FF_PROJ and want and pt.view_num is None and fold_ok(h) and ps._ff_src is not None
+                 and ops.rowlin_ok(act.N * act.HW, h.shape[1], pt.geglu_wf.shape[0], "geglu") and h.shape[1] == ops.FFN_C)
+        if last and ps.proj_out_x is not None and not split:
             post = (ps.proj_out_x, ps.proj_out.b, x_in, want and act.HW % ops.FFN_ROWS == 0, act.HW)
         elif last and FF_PROJ and want and ps.ff_proj_w is not None:
             post = ("compose", ps.ff_proj_w, ps.ff_proj_b, x_in, act.HW)      # proj_out composed with the last feed-forward Linear
         r = transformer_block(h, ctx, pt, act.N, act.HW, Lc, kv, st=st, want_stats=not last, dup=dup and i == 0, post=post,
-                              qkv0=qkv0 if i == 0 else None)
+                              qkv0=qkv0 if i == 0 else None, ffn_split=split)
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
             return Act(r[1], act.N, act.H, act.W, gs=r[2])
         h, st = r

@@ -642,6 +642,10 @@ ROWLIN_ROWS = 128
 # GEMM (31.9 vs 24.5 us at N = 1280, 58.2 vs 54.8 q|k|v, 128 vs 113 GEGLU; profiles/r06_rowlin_microbench.txt) -- that instance is
 # compiled in developer builds only.
 ROWLIN_WIDTHS = {"qkv": (640,), "q": (), "in": (640,), "geglu": (640,)}
+# level 0 (C = 320): the feed-forward as row-resident GEGLU projection (256-row blocks: the 1.6 MB of weights stream once per CU) + ONE GEMM
+# for ff.net[2] composed with proj_out, instead of the fused lr_ffn_block_f16 (whose 128-row blocks stream 2.7 MB each: 1.36 GB per launch
+# through the LDS-DMA path).  LEFTREFILL_FFN_SPLIT=0 keeps the fused block.
+FFN_SPLIT = os.environ.get("LEFTREFILL_FFN_SPLIT", "1") != "0"
 ROWLIN_MIN_ROWS = 2048      # below this the column slices of a launch cannot fill the chip
 # LEFTREFILL_ROWLIN=0 keeps the tiled GEMMs everywhere
 ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
@@ -649,6 +653,8 @@ ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
 
 def rowlin_ok(M, C, N, kind="qkv"):
     """Shapes / uses lr_rowlin_f16 takes (everything else keeps the [LayerNorm-folded] GEMM)."""
+    if kind == "geglu" and C == 320:
+        return ROWLIN and FFN_SPLIT and M % (2 * ROWLIN_ROWS) == 0 and M >= 8 * ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0 and N <= 2560
     return ROWLIN and C in ROWLIN_WIDTHS.get(kind, ()) and M % ROWLIN_ROWS == 0 and M >= ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0
 
 
@@ -659,7 +665,7 @@ def rowlin(x, w, bias, *, eps=1e-5, geglu=False, ln=True, out=None):
     _chk16(x, "x")
     M, C = x.shape
     N = w.shape[0]
-    assert C in (640, 1280) and M % ROWLIN_ROWS == 0 and N % 64 == 0, (M, C, N)      # (1280: developer builds of the library only)
+    assert C in (320, 640, 1280) and M % (ROWLIN_ROWS * (2 if C == 320 else 1)) == 0 and N % 64 == 0, (M, C, N)      # (1280: developer builds only; 320: GEGLU only)
     assert w.dtype == x.dtype and w.is_contiguous() and w.shape == (N, C) and bias.dtype == torch.float32 and bias.numel() == N
     n_out = N // 2 if geglu else N
     if out is None:

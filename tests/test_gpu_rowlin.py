@@ -54,7 +54,8 @@ def test_rowlin_without_layernorm_is_the_plain_linear(M, C):
     assert (out.float() - tiled.float()).abs().max().item() <= 2e-3
 
 
-@pytest.mark.parametrize("M,H,C", [(128, 2560, 640), (512, 2560, 640), (256, 64, 640), (2048, 2560, 640), (256, 5120, 1280), (128, 96, 1280)])
+@pytest.mark.parametrize("M,H,C", [(128, 2560, 640), (512, 2560, 640), (256, 64, 640), (2048, 2560, 640), (256, 5120, 1280), (128, 96, 1280),
+                                   (256, 1280, 320), (1024, 1280, 320), (512, 32, 320), (768, 96, 320)])
 def test_rowlin_geglu_vs_oracle(M, H, C):
     """value * gelu(gate) of the interleaved projection (packing.geglu_perm), H output columns."""
     from leftrefill_amd import _lib, ops, packing
@@ -87,6 +88,7 @@ def test_rowlin_hot_shapes_reruns_and_tiled_gemm():
     rows = torch.arange(0, M, 41)
     for geglu, N in ((False, 1920), (True, 5120)):
         w, b, gamma, beta = _params("hot%d" % geglu, N)
+        C = 640
         wf, bf, cs = packing.fold_layernorm(w, b, gamma, beta)
         if geglu:
             perm = packing.geglu_perm(N // 2)
@@ -146,4 +148,58 @@ def test_transformer_block_rowlin_equals_tiled_path():
             ops.ROWLIN = True
     err = (outs[0] - outs[1]).abs().max().item()
     print(f"[row-resident vs tiled projections] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
+    assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())
+
+
+def test_rowlin_level0_geglu_hot_shape():
+    """configs[1] level-0 feed-forward projection (M = 8 x 8192, C = 320, 2560 interleaved rows): reruns bit-identical, sampled rows vs oracle."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    M, C, H = 65536, 320, 1280
+    g = torch.Generator().manual_seed(31)
+    x = h16(torch.randn(M, C, generator=g) * 1.2)
+    w, b, gamma, beta = _params("hot320", 2 * H, C)
+    wf, bf, _cs = packing.fold_layernorm(w, b, gamma, beta)
+    perm = packing.geglu_perm(H)
+    wf, bf = wf[perm].contiguous().to(d), bf[perm].contiguous().to(d)
+    xd = x.half().to(d)
+    outs = [ops.rowlin(xd, wf, bf, eps=1e-5, geglu=True) for _ in range(3)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    rows = torch.arange(0, M, 67)
+    y = F.linear(unet_ref.layer_norm(x[rows], gamma, beta), w, b)
+    report("rowlin level-0 geglu", outs[0][rows.to(d)], y[:, :H] * F.gelu(y[:, H:]), atol=6e-3)
+
+
+def test_spatial_transformer_split_feed_forward_equals_fused_block():
+    """engine.spatial_transformer at C = 320: row-resident GEGLU projection + one composed GEMM (ops.FFN_SPLIT) vs the fused feed-forward block."""
+    import importlib
+    from leftrefill_amd import engine, ops
+    from leftrefill_amd.dropin import install
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(5)
+    d = dev()
+    st = att.SpatialTransformer(320, 5, 64, depth=1, context_dim=1024, use_linear=True).to(d).eval()
+    with torch.no_grad():
+        for p_ in st.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        for n_ in (st.norm, st.transformer_blocks[0].norm1, st.transformer_blocks[0].norm2, st.transformer_blocks[0].norm3):
+            n_.weight.add_(1.0)
+    ps = engine.PackedST(st)
+    N, H, W, Lc = 2, 64, 128, 77          # 16384 rows: the split path wants whole 256-row blocks and enough of them
+    x = torch.randn(N * H * W, 320, device=d).half()
+    ctx = torch.randn(N * Lc, 1024, device=d).half()
+    conv = torch.nn.Conv2d(320, 320, 3, padding=1).to(d)
+    pc = engine.PackedConv(conv)
+    outs = []
+    for flag in (True, False):
+        ops.FFN_SPLIT = flag
+        try:
+            with torch.no_grad():
+                act = engine.conv(engine.Act(x, N, H, W), pc, gn_stats=True)      # a producer with GroupNorm statistics, like a ResBlock
+                outs.append(engine.spatial_transformer(act, ctx, Lc, ps).tok.float().cpu())
+        finally:
+            ops.FFN_SPLIT = True
+    err = (outs[0] - outs[1]).abs().max().item()
+    print(f"[split vs fused feed-forward] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
     assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())

@@ -27,7 +27,7 @@ def family(name):
                            ("gemm_conv_pipe_kernelILi128", "gemm_conv_pipe_kernel<128,4,*,2,4> (4-stage)")):
         if mangled in name:
             return label
-    for key in ("gemm_conv_pipe_kernel", "gemm_conv_kernel", "xattn_block_kernel", "ffn_block_kernel", "gn_apply", "gn_stats", "gn_finalize", "layernorm",
+    for key in ("gemm_conv_pipe_kernel", "gemm_conv_kernel", "xattn_block_kernel", "xattn640_kernel", "stin_block_kernel", "rowlin_kernel", "ffn_block_kernel", "gn_apply", "gn_stats", "gn_finalize", "layernorm",
                 "splitk_reduce", "transpose_v"):
         if key in name:
             return key
