@@ -277,10 +277,13 @@ static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   // (N = 1280), 58.2 vs 54.8 (q|k|v), 128 vs 113 (GEGLU): 32 row blocks leave 5 .. 8 column slices of a few pieces each, and the slices
   // re-load the rows (profiles/r06_rowlin_microbench.txt)
   const int rows = a->C == 320 ? 2 * RL_ROWS : RL_ROWS;
+  // C = 320 (level 0: the gated projection on 256-row blocks, for a feed-forward split into projection + one composed GEMM) is a developer
+  // build instance too: measured 129.5 + 99.1 us against 220-225 us of the fused lr_ffn_block_f16, UNet step 17.92 vs 17.87 ms same box --
+  // the gate's ~300 VALU instructions per piece and wave cost as much as the piece's MFMAs and the waves run them in lockstep
 #ifdef LR_DEV_VARIANTS
   if ((a->C != 320 && a->C != 640 && a->C != 1280) || a->M % rows || a->N % 64) return LR_E_UNSUPPORTED;
 #else
-  if ((a->C != 320 && a->C != 640) || a->M % rows || a->N % 64) return LR_E_UNSUPPORTED;
+  if (a->C != 640 || a->M % rows || a->N % 64) return LR_E_UNSUPPORTED;
 #endif
   if (a->geglu && !a->ln) return LR_E_UNSUPPORTED;      // (the gated projection always follows norm3)
   const int n_out = a->geglu ? a->N / 2 : a->N;
@@ -294,10 +297,12 @@ static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   P.np = a->N / 64 / P.ny;
   if (P.np * 64 > RL_MAX_SLICE) return LR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)s;
+#ifdef LR_DEV_VARIANTS
   if (a->C == 320) {      // level 0: the gated projection only (q|k|v and proj_in are stin_block's)
     if (a->geglu) return rowlin_launch<T, 320, true, true>(P, st);
     return LR_E_UNSUPPORTED;
   }
+#endif
   if (a->C == 640) {
     if (a->geglu) return rowlin_launch<T, 640, true, true>(P, st);
     return a->ln ? rowlin_launch<T, 640, false, true>(P, st) : rowlin_launch<T, 640, false, false>(P, st);

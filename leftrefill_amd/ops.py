@@ -642,10 +642,10 @@ ROWLIN_ROWS = 128
 # GEMM (31.9 vs 24.5 us at N = 1280, 58.2 vs 54.8 q|k|v, 128 vs 113 GEGLU; profiles/r06_rowlin_microbench.txt) -- that instance is
 # compiled in developer builds only.
 ROWLIN_WIDTHS = {"qkv": (640,), "q": (), "in": (640,), "geglu": (640,)}
-# level 0 (C = 320): the feed-forward as row-resident GEGLU projection (256-row blocks: the 1.6 MB of weights stream once per CU) + ONE GEMM
-# for ff.net[2] composed with proj_out, instead of the fused lr_ffn_block_f16 (whose 128-row blocks stream 2.7 MB each: 1.36 GB per launch
-# through the LDS-DMA path).  LEFTREFILL_FFN_SPLIT=0 keeps the fused block.
-FFN_SPLIT = os.environ.get("LEFTREFILL_FFN_SPLIT", "1") != "0"
+# level 0 (C = 320), developer builds of the library only: the feed-forward as row-resident GEGLU projection (256-row blocks) + ONE GEMM for
+# ff.net[2] composed with proj_out, instead of the fused lr_ffn_block_f16.  Measured and lost: 129.5 + 99.1 us against 220-225 us, UNet step
+# 17.92 vs 17.87 ms same box (profiles/r06_ffn_split_ab.txt) -- off; LEFTREFILL_FFN_SPLIT=1 with LEFTREFILL_LIB_PATH=<developer build> enables it.
+FFN_SPLIT = os.environ.get("LEFTREFILL_FFN_SPLIT", "0") != "0"
 ROWLIN_MIN_ROWS = 2048      # below this the column slices of a launch cannot fill the chip
 # LEFTREFILL_ROWLIN=0 keeps the tiled GEMMs everywhere
 ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
@@ -654,7 +654,7 @@ ROWLIN = os.environ.get("LEFTREFILL_ROWLIN", "1") != "0"
 def rowlin_ok(M, C, N, kind="qkv"):
     """Shapes / uses lr_rowlin_f16 takes (everything else keeps the [LayerNorm-folded] GEMM)."""
     if kind == "geglu" and C == 320:
-        return ROWLIN and FFN_SPLIT and M % (2 * ROWLIN_ROWS) == 0 and M >= 8 * ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0 and N <= 2560
+        return ROWLIN and FFN_SPLIT and _lib.dev_variants() and M % (2 * ROWLIN_ROWS) == 0 and M >= 8 * ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0 and N <= 2560
     return ROWLIN and C in ROWLIN_WIDTHS.get(kind, ()) and M % ROWLIN_ROWS == 0 and M >= ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0
 
 

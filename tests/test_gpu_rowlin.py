@@ -59,8 +59,8 @@ def test_rowlin_without_layernorm_is_the_plain_linear(M, C):
 def test_rowlin_geglu_vs_oracle(M, H, C):
     """value * gelu(gate) of the interleaved projection (packing.geglu_perm), H output columns."""
     from leftrefill_amd import _lib, ops, packing
-    if C == 1280 and not _lib.dev_variants():
-        pytest.skip("the C = 1280 instance (measured, lost) is compiled in developer builds only")
+    if C != 640 and not _lib.dev_variants():
+        pytest.skip("the C = 320 / 1280 instances (measured, lost) are compiled in developer builds only")
     d = dev()
     w, b, gamma, beta = _params("g", 2 * H, C)
     x = h16(G.T(f"rowlin.g.{M}.{H}.{C}.x", (M, C)) * 1.1 - 0.1)
@@ -88,7 +88,6 @@ def test_rowlin_hot_shapes_reruns_and_tiled_gemm():
     rows = torch.arange(0, M, 41)
     for geglu, N in ((False, 1920), (True, 5120)):
         w, b, gamma, beta = _params("hot%d" % geglu, N)
-        C = 640
         wf, bf, cs = packing.fold_layernorm(w, b, gamma, beta)
         if geglu:
             perm = packing.geglu_perm(N // 2)
@@ -153,7 +152,9 @@ def test_transformer_block_rowlin_equals_tiled_path():
 
 def test_rowlin_level0_geglu_hot_shape():
     """configs[1] level-0 feed-forward projection (M = 8 x 8192, C = 320, 2560 interleaved rows): reruns bit-identical, sampled rows vs oracle."""
-    from leftrefill_amd import ops, packing
+    from leftrefill_amd import _lib, ops, packing
+    if not _lib.dev_variants():
+        pytest.skip("the C = 320 instance (measured, lost) is compiled in developer builds only")
     d = dev()
     M, C, H = 65536, 320, 1280
     g = torch.Generator().manual_seed(31)
@@ -173,7 +174,9 @@ def test_rowlin_level0_geglu_hot_shape():
 def test_spatial_transformer_split_feed_forward_equals_fused_block():
     """engine.spatial_transformer at C = 320: row-resident GEGLU projection + one composed GEMM (ops.FFN_SPLIT) vs the fused feed-forward block."""
     import importlib
-    from leftrefill_amd import engine, ops
+    from leftrefill_amd import _lib, engine, ops
+    if not _lib.dev_variants():
+        pytest.skip("the split feed-forward (measured, lost) needs the C = 320 instance of developer builds")
     from leftrefill_amd.dropin import install
     install()
     att = importlib.import_module("ldm.modules.attention")
@@ -192,6 +195,7 @@ def test_spatial_transformer_split_feed_forward_equals_fused_block():
     conv = torch.nn.Conv2d(320, 320, 3, padding=1).to(d)
     pc = engine.PackedConv(conv)
     outs = []
+    prev_split = ops.FFN_SPLIT
     for flag in (True, False):
         ops.FFN_SPLIT = flag
         try:
@@ -199,7 +203,7 @@ def test_spatial_transformer_split_feed_forward_equals_fused_block():
                 act = engine.conv(engine.Act(x, N, H, W), pc, gn_stats=True)      # a producer with GroupNorm statistics, like a ResBlock
                 outs.append(engine.spatial_transformer(act, ctx, Lc, ps).tok.float().cpu())
         finally:
-            ops.FFN_SPLIT = True
+            ops.FFN_SPLIT = prev_split
     err = (outs[0] - outs[1]).abs().max().item()
     print(f"[split vs fused feed-forward] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
     assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())

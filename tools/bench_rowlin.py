@@ -14,9 +14,9 @@ def main():
     d = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     from leftrefill_amd import _lib
-    shapes = [(640, 16384, False, 1920), (640, 16384, True, 5120), (640, 16384, False, 640), (320, 65536, True, 2560)]
-    if _lib.dev_variants():      # the level-2 instance exists in developer builds only (measured, lost)
-        shapes += [(1280, 4096, False, 1280), (1280, 4096, False, 3840), (1280, 4096, True, 10240)]
+    shapes = [(640, 16384, False, 1920), (640, 16384, True, 5120), (640, 16384, False, 640)]
+    if _lib.dev_variants():      # the level-0 / level-2 instances exist in developer builds only (measured, lost)
+        shapes += [(320, 65536, True, 2560), (1280, 4096, False, 1280), (1280, 4096, False, 3840), (1280, 4096, True, 10240)]
     for C, M, geglu, N in shapes:
         gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
         w = torch.randn(N, C, generator=g) / C ** 0.5
