@@ -279,6 +279,13 @@ typedef struct lr_stin_args {
   lr_half* x1; lr_half* qkv;
   int32_t M, C, NQ, ld_qkv;
   float ln_eps;
+  /* gn_part != NULL: x holds the RAW tokens and `x = self.norm(x)` of SpatialTransformer.forward (attention.py:399-404: GroupNorm(32, eps 1e-6,
+   * affine), no activation) is applied to the rows as they are loaded -- same arithmetic as lr_groupnorm_apply_n, bit for bit, without
+   * writing the normalised tensor.  gn_part [M / gn_hw][gn_chunks][32][2] = per-group (sum, sumsq) partials of x from its producer
+   * (lr_gemm_args.gn_group_out / lr_ffn_args.gn_group_out), gn_hw rows per sample (gn_hw % 256 == 0), gn_gamma / gn_beta [320] fp32. */
+  const float* gn_part; const float* gn_gamma; const float* gn_beta;
+  int32_t gn_chunks, gn_hw;
+  float gn_eps;
 } lr_stin_args;
 int lr_stin_block_f16(const lr_stin_args* args, lr_stream_t s);
 

@@ -74,7 +74,8 @@ class StinArgs(ctypes.Structure):
     """struct lr_stin_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("wp", c_void_p), ("bp", c_void_p), ("wqkv", c_void_p), ("bqkv", c_void_p), ("x1", c_void_p),
                 ("qkv", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("NQ", ctypes.c_int32), ("ld_qkv", ctypes.c_int32),
-                ("ln_eps", ctypes.c_float)]
+                ("ln_eps", ctypes.c_float), ("gn_part", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p),
+                ("gn_chunks", ctypes.c_int32), ("gn_hw", ctypes.c_int32), ("gn_eps", ctypes.c_float)]
 
 
 class RowlinArgs(ctypes.Structure):

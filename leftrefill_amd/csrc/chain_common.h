@@ -56,4 +56,40 @@ __device__ __forceinline__ void xa_swap_rows16(f32x4& a, f32x4& b) {
 #endif
 }
 
+// GroupNorm(32, affine) of a row-resident kernel's INPUT rows: per-channel scale / shift of sample n from the producer's per-group (sum,
+// sumsq) partials gp [samples][chunks][32][2] -> LDS tables tabA / tabB [C].  Arithmetic of gn_apply_kernel (norm.hip), operation for
+// operation -- chunk sums in fp64 by four lanes per group in the same order, mean / rstd rounded to fp32, a = rstd * gamma, b = beta - mean * a
+// -- so `(T)fmaf(x, a, b)` on the rows equals what lr_groupnorm_apply_n would have written.  Block-wide (>= 128 threads); two barriers.
+__device__ __forceinline__ void xa_gn_tables(const float* gp, int nchunks, int n, int HW, int C, const float* gamma, const float* beta,
+                                             float eps, float* tabA, float* tabB, float* s_mr /* [64] */, int t, int nthreads) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int Cg = C / 32;
+  if (t < 128) {
+    const int g = t >> 2, sub = t & 3;
+    double s = 0.0, q = 0.0;
+    const float* ps = gp + ((size_t)n * nchunks * 32 + g) * 2;
+#pragma unroll 4
+    for (int c = sub; c < nchunks; c += 4) { s += (double)ps[c * 64]; q += (double)ps[c * 64 + 1]; }
+#pragma unroll
+    for (int sh = 2; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+    if (sub == 0) {
+      const double cnt = (double)HW * (double)Cg;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mr[g] = (float)mean;
+      s_mr[32 + g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += nthreads) {
+    const int g = c / Cg;
+    const float a = s_mr[32 + g] * gamma[c];
+    tabA[c] = a;
+    tabB[c] = beta[c] - s_mr[g] * a;
+  }
+  __syncthreads();
+#endif
+}
+
 // stin_block.hip: entry of a SpatialTransformer at C = 320 (proj_in + LayerNorm + fused q|k|v projection in one launch)

@@ -33,6 +33,8 @@ struct StinParams {
   void* x1; void* qkv;
   int M, NQ, ld_qkv;          // NQ = width of the second stage (960), ld_qkv = row stride of qkv in elements
   float eps;
+  // GN: x holds the RAW tokens and the SpatialTransformer's GroupNorm(32) (attention.py:399-404) is applied to the rows as they are loaded
+  const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_chunks, gn_hw; float gn_eps;
 #ifdef SI_TRACE
   unsigned long long* trace;   // developer build only: shader-clock stamps [block][8 waves][64] (tools/trace_stin.py)
 #endif
@@ -46,7 +48,7 @@ extern "C" void lr_stin_set_trace(void* p) { g_si_trace = (unsigned long long*)p
 #define SI_STAMP(k) do { } while (0)
 #endif
 
-template <typename T>
+template <typename T, bool GN>
 __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = SI_C, KL = C / 64;      // 5 sub-tiles of 64 k
@@ -74,6 +76,28 @@ __global__ __launch_bounds__(SI_THREADS) void stin_block_kernel(const StinParams
   for (int i = t; i < (C + P.NQ) / 4; i += SI_THREADS) {      // bias rows -> LDS (no register loads inside the piece loop)
     const float* src = i < C / 4 ? P.bp + 4 * i : P.bqkv + 4 * (i - C / 4);
     *reinterpret_cast<f32x4*>(par + 4 * i) = *reinterpret_cast<const f32x4*>(src);
+  }
+  if constexpr (GN) {
+    // the block's 256 rows lie in ONE sample (gn_hw % 256 == 0): its scale / shift tables, then the rows are normalised in place and
+    // rounded to 16 bits -- the tensor lr_groupnorm_apply_n would have written, bit for bit, without the round trip through memory
+    float* tabA = par + C + P.NQ;
+    float* tabB = tabA + C;
+    xa_gn_tables(P.gn_part, P.gn_chunks, (blockIdx.x * SI_ROWS) / P.gn_hw, P.gn_hw, C, P.gn_gamma, P.gn_beta, P.gn_eps, tabA, tabB, tabB + C, t, SI_THREADS);
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+      for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c0 = 64 * t5 + 32 * u + 8 * fq;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(tabA + c0), a1 = *reinterpret_cast<const f32x4*>(tabA + c0 + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(tabB + c0), b1 = *reinterpret_cast<const f32x4*>(tabB + c0 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xf[rs][t5][u][i] = (T)fmaf((float)xf[rs][t5][u][i], a0[i], b0[i]);
+            xf[rs][t5][u][4 + i] = (T)fmaf((float)xf[rs][t5][u][4 + i], a1[i], b1[i]);
+          }
+        }
   }
 
   // ---- weight ring: piece s < 5 = rows 64 s .. of Wp, piece s >= 5 = rows 64 (s - 5) .. of Wqkv; 5 LDS-DMA instructions of 1 KiB per wave
@@ -286,14 +310,27 @@ static int stin_block_t(const lr_stin_args* a, lr_stream_t s) {
   StinParams P;
   P.x = a->x; P.wp = a->wp; P.bp = a->bp; P.wqkv = a->wqkv; P.bqkv = a->bqkv; P.x1 = a->x1; P.qkv = a->qkv;
   P.M = a->M; P.NQ = a->NQ; P.ld_qkv = a->ld_qkv; P.eps = a->ln_eps;
+  const bool gn = a->gn_part != nullptr;
+  if (gn) {
+    if (!a->gn_gamma || !a->gn_beta || a->gn_chunks <= 0 || a->gn_hw <= 0) return LR_E_ARG;
+    if (a->gn_hw % SI_ROWS || a->M % a->gn_hw) return LR_E_UNSUPPORTED;      // a block stays inside one sample
+    if (((uintptr_t)a->gn_part & 7) || (((uintptr_t)a->gn_gamma | (uintptr_t)a->gn_beta) & 3)) return LR_E_ALIGN;
+  }
+  P.gn_part = a->gn_part; P.gn_gamma = a->gn_gamma; P.gn_beta = a->gn_beta; P.gn_chunks = a->gn_chunks; P.gn_hw = a->gn_hw; P.gn_eps = a->gn_eps;
 #ifdef SI_TRACE
   P.trace = g_si_trace;
 #endif
-  const size_t smem = 3 * SI_SLOT + (size_t)(SI_C + a->NQ) * sizeof(float);
-  static unsigned long long attr_done = 0;
-  if (lr_attr_needed(&attr_done))
-    hipFuncSetAttribute(reinterpret_cast<const void*>(stin_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((stin_block_kernel<T>), dim3(a->M / SI_ROWS), dim3(SI_THREADS), smem, (hipStream_t)s, P);
+  const size_t smem = 3 * SI_SLOT + (size_t)(SI_C + a->NQ + 2 * SI_C + 64) * sizeof(float);
+  static unsigned long long attr_done[2] = {0, 0};
+  if (gn) {
+    if (lr_attr_needed(&attr_done[1]))
+      hipFuncSetAttribute(reinterpret_cast<const void*>(stin_block_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((stin_block_kernel<T, true>), dim3(a->M / SI_ROWS), dim3(SI_THREADS), smem, (hipStream_t)s, P);
+  } else {
+    if (lr_attr_needed(&attr_done[0]))
+      hipFuncSetAttribute(reinterpret_cast<const void*>(stin_block_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((stin_block_kernel<T, false>), dim3(a->M / SI_ROWS), dim3(SI_THREADS), smem, (hipStream_t)s, P);
+  }
   return lr_launch_status();
 }
 

@@ -646,6 +646,10 @@ def st_gn_fold_ok(x_in, act: Act, gs_in, ps: PackedST):
 STIN = __import__("os").environ.get("LEFTREFILL_STIN", "1") != "0"
 
 
+# the SpatialTransformer's GroupNorm applied inside that launch (needs the producer's per-group partials); LEFTREFILL_STIN_GN=0: gn_apply pass
+STIN_GN = __import__("os").environ.get("LEFTREFILL_STIN_GN", "1") != "0"
+
+
 def stin_fused(h, ps: PackedST):
     """Will the entry of the SpatialTransformer take the one-launch path (lr_stin_block_f16)?  Single-view blocks only: a multi-view
     block projects the re-arranged sequence, not the rows of h."""
@@ -672,6 +676,14 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
             ws = True
             wb, bb = ops.gn_fold_weights(gs_in[2], gs_in[3], act.N, act.HW, ps.norm.g, ps.norm.b, ps.norm.eps, ps.proj_in.w, ps.proj_in.b)
             h = ops.gemm_conv(x_in, wb, B=act.N, H=1, W=act.HW, taps=1, bias=bb, per_sample=True, want_stats=True)
+        elif (STIN_GN and stin_fused(x_in, ps) and gs_in is not None and gs_in[2] is not None and gn_fuse_ok(x_in)
+              and act.HW % ops.STIN_ROWS == 0):
+            # level 0: GroupNorm + proj_in + LayerNorm + q|k|v in ONE launch -- the rows are normalised as they are loaded (same bits as
+            # the GroupNorm-apply pass it replaces, the normalised tensor is never written)
+            pq = ps.blocks[0].attn1.qkv
+            h, qkv0 = ops.stin_block(x_in, ps.proj_in.w, ps.proj_in.b, pq.wf, pq.bf, eps=pq.eps,
+                                     gn=(gs_in[2], gs_in[3], act.HW, ps.norm.g, ps.norm.b, ps.norm.eps))
+            ws = False
         else:
             h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
             if stin_fused(h, ps):

@@ -615,10 +615,11 @@ def stin_ok(M, C, NQ):
     return C == STIN_C and M % STIN_ROWS == 0 and NQ > 0 and NQ % 192 == 0 and NQ <= 4096
 
 
-def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None):
+def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None, gn=None):
     """x1 = x wp^T + bp;  qkv = LayerNorm(x1) wqkv^T + bqkv  in one launch (lr_stin_block_f16): SpatialTransformer.proj_in and the
     LayerNorm-folded fused q|k|v projection of its block's self-attention.  wqkv / bqkv: packing.fold_layernorm of [to_q; to_k; to_v]
-    (natural column order).  Returns (x1 [M, C], qkv [M, NQ])."""
+    (natural column order).  gn = (gp [samples, chunks, 32, 2], chunks, HW, gamma, beta, eps): x is the RAW tensor and the SpatialTransformer's
+    GroupNorm is applied to the rows on the way in (what group_norm_groups would have written, bit for bit).  Returns (x1 [M, C], qkv [M, NQ])."""
     lib = _lib.load()
     _chk16(x, "x")
     M, C = x.shape
@@ -632,6 +633,14 @@ def stin_block(x, wp, bp, wqkv, bqkv, *, eps, out=None, qkv_out=None):
     a = StinArgs()
     a.x, a.wp, a.bp, a.wqkv, a.bqkv, a.x1, a.qkv = _p(x), _p(wp), _p(bp), _p(wqkv), _p(bqkv), _p(x1), _p(qkv)
     a.M, a.C, a.NQ, a.ld_qkv, a.ln_eps = M, C, NQ, qkv.stride(0), float(eps)
+    a.gn_part = a.gn_gamma = a.gn_beta = 0
+    a.gn_chunks = a.gn_hw = 0
+    a.gn_eps = 0.0
+    if gn is not None:
+        gp, chunks, hw, gamma, beta, geps = gn
+        assert gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (M // hw, chunks, 32, 2) and hw % STIN_ROWS == 0
+        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+        a.gn_part, a.gn_gamma, a.gn_beta, a.gn_chunks, a.gn_hw, a.gn_eps = _p(gp), _p(gamma), _p(beta), int(chunks), int(hw), float(geps)
     _lib.check(_fn(lib, "lr_stin_block_f16", x.dtype)(a, _stream()), "stin_block")
     return x1, qkv
 

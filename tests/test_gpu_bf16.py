@@ -244,6 +244,68 @@ def test_fused_blocks_bf16():
     report("fused feed-forward block", out2, ref2, atol=2e-2)
 
 
+def test_row_resident_kernels_bf16():
+    """bf16 instances of the round-6 kernels (lr_stin_block_bf16, lr_rowlin_bf16, lr_xattn_block_bf16 at C = 640) vs the oracle on
+    bf16-rounded operands."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    m = unet_ref._Mode("fp32")
+    # --- stin: proj_in + LayerNorm + q|k|v at C = 320
+    C, M, NQ = 320, 512, 960
+    wp = b16(torch.from_numpy(weights.fill_like("rr16.wp", (C, C))))
+    bp = torch.from_numpy(weights.fill_like("rr16.bp", (C,)))
+    wq = b16(torch.from_numpy(weights.fill_like("rr16.wq", (NQ, C))))
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like("rr16.g", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like("rr16.b", (C,), kind="unit"))
+    x = b16(G.T("rr16.x", (M, C)))
+    wf, bf, _ = packing.fold_layernorm(wq, None, gamma, beta, BF)
+    x1, qkv = ops.stin_block(x.to(BF).to(d), wp.to(BF).to(d), bp.to(d), wf.to(d), bf.to(d), eps=1e-5)
+    assert x1.dtype == BF and qkv.dtype == BF
+    report("stin x1", x1, F.linear(x, wp, bp))
+    report("stin qkv", qkv, F.linear(unet_ref.layer_norm(x1.float().cpu(), gamma, beta), wq), rel_l2=8e-3, atol=2.5e-2)
+    # --- rowlin at C = 640: q|k|v and GEGLU
+    C, M = 640, 256
+    gamma = 1.0 + 0.2 * torch.from_numpy(weights.fill_like("rr16.g6", (C,), kind="unit"))
+    beta = 0.1 * torch.from_numpy(weights.fill_like("rr16.b6", (C,), kind="unit"))
+    x = b16(G.T("rr16.x6", (M, C)))
+    w = b16(torch.from_numpy(weights.fill_like("rr16.w6", (1920, C))))
+    wf, bf, _ = packing.fold_layernorm(w, None, gamma, beta, BF)
+    out = ops.rowlin(x.to(BF).to(d), wf.to(d), bf.to(d), eps=1e-5)
+    assert out.dtype == BF
+    report("rowlin qkv", out, F.linear(unet_ref.layer_norm(x, gamma, beta), w), rel_l2=8e-3, atol=2.5e-2)
+    H = 2560
+    wg = b16(torch.from_numpy(weights.fill_like("rr16.wg", (2 * H, C))))
+    bg = torch.from_numpy(weights.fill_like("rr16.bg", (2 * H,)))
+    wff, bff, _ = packing.fold_layernorm(wg, bg, gamma, beta, BF)
+    perm = packing.geglu_perm(H)
+    og = ops.rowlin(x.to(BF).to(d), wff[perm].contiguous().to(d), bff[perm].contiguous().to(d), eps=1e-5, geglu=True)
+    u, gate = F.linear(unet_ref.layer_norm(x, gamma, beta), wg, bg).chunk(2, dim=-1)
+    report("rowlin geglu", og, u * F.gelu(gate), rel_l2=8e-3, atol=4e-2)
+    # --- fused cross-attention block at C = 640 (with the self-attention's out-projection in front)
+    heads, B, L, Lc = 10, 2, 128, 77
+    sd = {f"a.{k}.weight": b16(torch.from_numpy(weights.fill_like(f"rr16.x.{k}", (C, C if k == "to_q" else 1024)))) for k in ("to_q", "to_k", "to_v")}
+    sd["a.to_out.0.weight"] = b16(torch.from_numpy(weights.fill_like("rr16.x.to_out", (C, C))))
+    sd["a.to_out.0.bias"] = torch.from_numpy(weights.fill_like("rr16.x.to_out.b", (C,)))
+    wo1 = b16(torch.from_numpy(weights.fill_like("rr16.x.wo1", (C, C))))
+    bo1 = torch.from_numpy(weights.fill_like("rr16.x.bo1", (C,)))
+    xx = b16(G.T("rr16.xx", (B, L, C)))
+    aa = b16(G.T("rr16.aa", (B, L, C)))
+    ctx = b16(G.T("rr16.ctx", (B, Lc, 1024)))
+    x1r = xx + F.linear(aa, wo1, bo1)
+    ref = x1r + unet_ref.cross_attention(sd, "a", unet_ref.layer_norm(x1r, gamma, beta), ctx, heads, m)
+    wqf, bq, _ = packing.fold_layernorm(sd["a.to_q.weight"], None, gamma, beta, BF)
+    wq_pi = wqf[:, packing.xattn_perm(C)].contiguous()
+    xk_w, xwo = packing.pack_xattn(sd["a.to_k.weight"], sd["a.to_out.0.weight"], BF)
+    ctx_t = ctx.reshape(B * Lc, -1).to(BF).to(d)
+    k = ops.gemm_conv(ctx_t, xk_w.to(d), B=1, H=1, W=B * Lc, taps=1)
+    v = ops.gemm_conv(ctx_t, sd["a.to_v.weight"].to(BF).to(d), B=1, H=1, W=B * Lc, taps=1)
+    o = ops.xattn_block(xx.reshape(B * L, C).to(BF).to(d), wq_pi.to(d), bq.to(d), k, ops.xattn_pack_vt(v, B, heads, Lc), xwo.to(d),
+                        sd["a.to_out.0.bias"].to(d), HW=L, heads=heads, Lc=Lc, eps=1e-5, scale=0.125,
+                        pre=(aa.reshape(B * L, C).to(BF).to(d), wo1.to(BF).to(d), bo1.to(d)))
+    assert o.dtype == BF
+    report("fused cross-attention block C = 640 (+ pre)", o.reshape(B, L, C), ref, rel_l2=8e-3, atol=4e-2)
+
+
 def test_mv_gather_scatter_bf16():
     from leftrefill_amd import ops
     b, V, s, C = 2, 5, 4, 64

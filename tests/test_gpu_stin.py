@@ -114,3 +114,50 @@ def test_spatial_transformer_stin_equals_two_gemm_path():
     err = (outs[0] - outs[1]).abs().max().item()
     print(f"[stin vs two-GEMM entry] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
     assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())
+
+
+def test_stin_block_with_groupnorm_equals_groupnorm_apply_then_stin_bitwise():
+    """gn=...: the SpatialTransformer's GroupNorm (attention.py:399-404) applied to the rows inside the launch, from the producer's per-group
+    partials -- the same arithmetic as lr_groupnorm_apply_n, so x1 and qkv are BIT-identical to the two-launch form; also through
+    engine.spatial_transformer (LEFTREFILL_STIN_GN on / off)."""
+    import importlib
+    from leftrefill_amd import engine, ops, packing
+    from leftrefill_amd.dropin import install
+    d = dev()
+    N, H, W = 2, 16, 32
+    wp, bp, wq, gamma, beta = _params("gn", 960)
+    gng = (1.0 + 0.3 * G.T("stin.gn.g", (C,))).to(d)
+    gnb = (0.2 * G.T("stin.gn.b", (C,))).to(d)
+    x0 = h16(G.T("stin.gn.x", (N, C, H, W)) * 0.7 + 0.4)
+    conv_w = h16(torch.from_numpy(weights.fill_like("stin.gn.conv", (C, C, 3, 3))))
+    tok = x0.permute(0, 2, 3, 1).reshape(N * H * W, C).half().contiguous().to(d)
+    y, gs = ops.gemm_conv(tok, packing.pack_conv(conv_w).to(d), B=N, H=H, W=W, taps=9, want_gn_stats=True)
+    part, R, gp, chunks = gs
+    assert gp is not None, "the producer's plan must emit per-group partials for this shape"
+    wf, bf, _cs = packing.fold_layernorm(wq, None, gamma, beta)
+    args = (wp.half().to(d), bp.to(d), wf.to(d), bf.to(d))
+    h = ops.group_norm_groups(y, N, H * W, gng, gnb, 1e-6, False, gp, chunks)
+    x1_ref, qkv_ref = ops.stin_block(h, *args, eps=1e-5)
+    x1, qkv = ops.stin_block(y, *args, eps=1e-5, gn=(gp, chunks, H * W, gng, gnb, 1e-6))
+    assert torch.equal(x1, x1_ref) and torch.equal(qkv, qkv_ref)
+    # the engine path
+    install()
+    att = importlib.import_module("ldm.modules.attention")
+    torch.manual_seed(7)
+    st = att.SpatialTransformer(320, 5, 64, depth=1, context_dim=1024, use_linear=True).to(d).eval()
+    with torch.no_grad():
+        for p_ in st.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.05)
+        for n_ in (st.norm, st.transformer_blocks[0].norm1, st.transformer_blocks[0].norm2, st.transformer_blocks[0].norm3):
+            n_.weight.add_(1.0)
+    ps = engine.PackedST(st)
+    ctx = torch.randn(N * 77, 1024, device=d).half()
+    outs = []
+    for flag in (True, False):
+        engine.STIN_GN = flag
+        try:
+            with torch.no_grad():
+                outs.append(engine.spatial_transformer(engine.Act(y, N, H, W, gs=gs), ctx, 77, ps).tok)
+        finally:
+            engine.STIN_GN = True
+    assert torch.equal(outs[0], outs[1])
