@@ -302,6 +302,11 @@ typedef struct lr_rowlin_args {
   int32_t M, C, N, ld_out, geglu;
   float ln_eps;
   int32_t ln;      /* 1: LayerNorm the rows first (w / bias carry gamma / beta); 0: plain Linear (SpatialTransformer.proj_in, attention.py:405-408) */
+  /* gn_part != NULL (ln = 0, geglu = 0): x holds RAW tokens and SpatialTransformer.norm (GroupNorm(32), attention.py:399-404) is applied to the
+   * rows as they are loaded, exactly as in lr_stin_args (gn_hw % 128 == 0). */
+  const float* gn_part; const float* gn_gamma; const float* gn_beta;
+  int32_t gn_chunks, gn_hw;
+  float gn_eps;
 } lr_rowlin_args;
 int lr_rowlin_f16(const lr_rowlin_args* args, lr_stream_t s);
 

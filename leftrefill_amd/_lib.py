@@ -81,7 +81,9 @@ class StinArgs(ctypes.Structure):
 class RowlinArgs(ctypes.Structure):
     """struct lr_rowlin_args (include/leftrefill_hip.h)."""
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("N", ctypes.c_int32), ("ld_out", ctypes.c_int32), ("geglu", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("ln", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("ld_out", ctypes.c_int32), ("geglu", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("ln", ctypes.c_int32),
+                ("gn_part", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_chunks", ctypes.c_int32), ("gn_hw", ctypes.c_int32),
+                ("gn_eps", ctypes.c_float)]
 
 
 class FfnArgs(ctypes.Structure):

@@ -30,11 +30,13 @@ struct RowlinParams {
   const void* x; const void* w; const float* bias; void* out;
   int M, N, ld_out, ny, np;    // np = 64-row pieces per block = N / (64 ny)
   float eps;
+  // GN (plain Linear only): x holds RAW tokens, the SpatialTransformer's GroupNorm(32) is applied to the rows as they are loaded (stin_block.hip)
+  const float* gn_part; const float* gn_gamma; const float* gn_beta; int gn_chunks, gn_hw; float gn_eps;
 };
 
 // C = 320 | 640 | 1280 (levels 0 / 1 / 2: one / two / four 320-k steps per 64-column piece); LN = false: a plain Linear (proj_in).
 // C = 320: every wave owns 32 rows as TWO B-operand sets (each weight fragment feeds two MFMAs; 256-row blocks, like stin_block.hip).
-template <typename T, int C, bool GEGLU, bool LN>
+template <typename T, int C, bool GEGLU, bool LN, bool GN = false>
 __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KL = C / 64;                // sub-tiles of 64 k, 5 per step
@@ -90,6 +92,26 @@ __global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const RowlinParams P
     }
   }
 
+  if constexpr (GN) {      // GroupNorm of the raw rows on the way in: the bits lr_groupnorm_apply_n would have written (chain_common.h)
+    float* tabA = par + RL_MAX_SLICE;
+    float* tabB = tabA + C;
+    xa_gn_tables(P.gn_part, P.gn_chunks, (rb * (RL_ROWS * RS)) / P.gn_hw, P.gn_hw, C, P.gn_gamma, P.gn_beta, P.gn_eps, tabA, tabB, tabB + C, t, RL_THREADS);
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs)
+#pragma unroll
+      for (int t5 = 0; t5 < KL; ++t5)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c0 = 64 * t5 + 32 * u + 8 * fq;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(tabA + c0), a1 = *reinterpret_cast<const f32x4*>(tabA + c0 + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(tabB + c0), b1 = *reinterpret_cast<const f32x4*>(tabB + c0 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xf[rs][t5][u][i] = (T)fmaf((float)xf[rs][t5][u][i], a0[i], b0[i]);
+            xf[rs][t5][u][4 + i] = (T)fmaf((float)xf[rs][t5][u][4 + i], a1[i], b1[i]);
+          }
+        }
+  }
   // ---- LayerNorm of the rows in registers (two-pass; gamma / beta live in W / bias)
   if constexpr (LN) {
 #pragma unroll
@@ -259,13 +281,13 @@ static int rowlin_ny(int M, int N, int rows) {
   return ny;
 }
 
-template <typename T, int C, bool GEGLU, bool LN>
+template <typename T, int C, bool GEGLU, bool LN, bool GN = false>
 static int rowlin_launch(const RowlinParams& P, hipStream_t st) {
-  const size_t smem = 3 * RL_SLOT + (size_t)RL_MAX_SLICE * sizeof(float);
+  const size_t smem = 3 * RL_SLOT + (size_t)(RL_MAX_SLICE + (GN ? 2 * C + 64 : 0)) * sizeof(float);
   static unsigned long long attr_done = 0;
   if (lr_attr_needed(&attr_done))
-    hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, C, GEGLU, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((rowlin_kernel<T, C, GEGLU, LN>), dim3((P.M / (C == 320 ? 2 * RL_ROWS : RL_ROWS)) * P.ny), dim3(RL_THREADS), smem, st, P);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<T, C, GEGLU, LN, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((rowlin_kernel<T, C, GEGLU, LN, GN>), dim3((P.M / (C == 320 ? 2 * RL_ROWS : RL_ROWS)) * P.ny), dim3(RL_THREADS), smem, st, P);
   return lr_launch_status();
 }
 
@@ -297,6 +319,15 @@ static int rowlin_t(const lr_rowlin_args* a, lr_stream_t s) {
   P.np = a->N / 64 / P.ny;
   if (P.np * 64 > RL_MAX_SLICE) return LR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)s;
+  const bool gn = a->gn_part != nullptr;
+  if (gn) {      // GroupNorm of the input rows: the plain Linear at C = 640 only (SpatialTransformer.norm + proj_in)
+    if (a->C != 640 || a->ln || a->geglu) return LR_E_UNSUPPORTED;
+    if (!a->gn_gamma || !a->gn_beta || a->gn_chunks <= 0 || a->gn_hw <= 0) return LR_E_ARG;
+    if (a->gn_hw % rows || a->M % a->gn_hw) return LR_E_UNSUPPORTED;      // a block stays inside one sample
+    if (((uintptr_t)a->gn_part & 7) || (((uintptr_t)a->gn_gamma | (uintptr_t)a->gn_beta) & 3)) return LR_E_ALIGN;
+  }
+  P.gn_part = a->gn_part; P.gn_gamma = a->gn_gamma; P.gn_beta = a->gn_beta; P.gn_chunks = a->gn_chunks; P.gn_hw = a->gn_hw; P.gn_eps = a->gn_eps;
+  if (gn) return rowlin_launch<T, 640, false, false, true>(P, st);
 #ifdef LR_DEV_VARIANTS
   if (a->C == 320) {      // level 0: the gated projection only (q|k|v and proj_in are stin_block's)
     if (a->geglu) return rowlin_launch<T, 320, true, true>(P, st);

@@ -684,6 +684,12 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
             h, qkv0 = ops.stin_block(x_in, ps.proj_in.w, ps.proj_in.b, pq.wf, pq.bf, eps=pq.eps,
                                      gn=(gs_in[2], gs_in[3], act.HW, ps.norm.g, ps.norm.b, ps.norm.eps))
             ws = False
+        elif (STIN_GN and gs_in is not None and gs_in[2] is not None and gn_fuse_ok(x_in) and fold_ok(x_in) and ps.proj_in.b is not None
+              and ps.proj_in.w.shape == (x_in.shape[1], x_in.shape[1]) and ps.blocks and ps.blocks[0].view_num is None
+              and act.HW % ops.ROWLIN_ROWS == 0 and ops.rowlin_ok(x_in.shape[0], x_in.shape[1], x_in.shape[1], "in")):
+            # level 1: GroupNorm + proj_in in one row-resident launch (same bits as gn_apply + proj_in)
+            h = ops.rowlin(x_in, ps.proj_in.w, ps.proj_in.b, ln=False, gn=(gs_in[2], gs_in[3], act.HW, ps.norm.g, ps.norm.b, ps.norm.eps))
+            ws = False
         else:
             h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
             if stin_fused(h, ps):

@@ -667,7 +667,7 @@ def rowlin_ok(M, C, N, kind="qkv"):
     return ROWLIN and C in ROWLIN_WIDTHS.get(kind, ()) and M % ROWLIN_ROWS == 0 and M >= ROWLIN_MIN_ROWS and N > 0 and N % 64 == 0
 
 
-def rowlin(x, w, bias, *, eps=1e-5, geglu=False, ln=True, out=None):
+def rowlin(x, w, bias, *, eps=1e-5, geglu=False, ln=True, out=None, gn=None):
     """LayerNorm(x) w^T + bias (geglu: value * gelu(gate) of the interleaved rows) with the rows resident in registers (lr_rowlin_f16):
     the wide short-K projections of a C = 640 block.  w / bias: packing.fold_layernorm (GEGLU: in packing.geglu_perm row order)."""
     lib = _lib.load()
@@ -683,6 +683,14 @@ def rowlin(x, w, bias, *, eps=1e-5, geglu=False, ln=True, out=None):
     a = RowlinArgs()
     a.x, a.w, a.bias, a.out = _p(x), _p(w), _p(bias), _p(out)
     a.M, a.C, a.N, a.ld_out, a.geglu, a.ln_eps, a.ln = M, C, N, out.stride(0), int(bool(geglu)), float(eps), int(bool(ln))
+    a.gn_part = a.gn_gamma = a.gn_beta = 0
+    a.gn_chunks = a.gn_hw = 0
+    a.gn_eps = 0.0
+    if gn is not None:      # (gp, chunks, HW, gamma, beta, eps): GroupNorm of the raw rows on the way in, see stin_block
+        gp, chunks, hw, gamma, beta, geps = gn
+        assert not ln and not geglu and gp.dtype == torch.float32 and gp.is_contiguous() and gp.shape == (M // hw, chunks, 32, 2) and hw % ROWLIN_ROWS == 0
+        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+        a.gn_part, a.gn_gamma, a.gn_beta, a.gn_chunks, a.gn_hw, a.gn_eps = _p(gp), _p(gamma), _p(beta), int(chunks), int(hw), float(geps)
     _lib.check(_fn(lib, "lr_rowlin_f16", x.dtype)(a, _stream()), "rowlin")
     return out
 

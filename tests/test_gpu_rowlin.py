@@ -207,3 +207,24 @@ def test_spatial_transformer_split_feed_forward_equals_fused_block():
     err = (outs[0] - outs[1]).abs().max().item()
     print(f"[split vs fused feed-forward] max abs diff {err:.3e} at |out| {outs[1].abs().max().item():.2f}")
     assert err <= 1e-2 * max(1.0, outs[1].abs().max().item())
+
+
+def test_rowlin_with_groupnorm_equals_groupnorm_apply_then_linear_bitwise():
+    """gn=...: SpatialTransformer.norm applied to the rows inside the launch (level 1: GroupNorm + proj_in), bit-identical to
+    lr_groupnorm_apply_n followed by the plain row-resident Linear."""
+    from leftrefill_amd import ops, packing
+    d = dev()
+    N, H, W, C = 2, 32, 64, 640
+    w, b, _g, _b = _params("gnlin", C, C)
+    gng = (1.0 + 0.3 * G.T("rowlin.gn.g", (C,))).to(d)
+    gnb = (0.2 * G.T("rowlin.gn.b", (C,))).to(d)
+    x0 = h16(G.T("rowlin.gn.x", (N, C, H, W)) * 0.7 + 0.4)
+    conv_w = h16(torch.from_numpy(weights.fill_like("rowlin.gn.conv", (C, C, 3, 3))))
+    tok = x0.permute(0, 2, 3, 1).reshape(N * H * W, C).half().contiguous().to(d)
+    y, gs = ops.gemm_conv(tok, packing.pack_conv(conv_w).to(d), B=N, H=H, W=W, taps=9, want_gn_stats=True)
+    part, R, gp, chunks = gs
+    assert gp is not None
+    h = ops.group_norm_groups(y, N, H * W, gng, gnb, 1e-6, False, gp, chunks)
+    ref = ops.rowlin(h, w.half().to(d), b.to(d), ln=False)
+    out = ops.rowlin(y, w.half().to(d), b.to(d), ln=False, gn=(gp, chunks, H * W, gng, gnb, 1e-6))
+    assert torch.equal(out, ref)
