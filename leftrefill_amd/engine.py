@@ -264,11 +264,6 @@ def linear(x, pl: PackedLinear, resid=None, M=None, want_stats=False):
     return ops.gemm_conv(x, pl.w, B=1, H=1, W=M, taps=1, bias=pl.b, resid=resid, want_stats=want_stats)
 
 
-def _PLAN_SCALE_ONE():
-    """(the row-resident kernels are row-local: every plan-scale gives the same bits, but keep the half-batch prefix on the tiled path)"""
-    return True
-
-
 def fold_ok(x):
     """The LayerNorm-folded GEMMs are inference kernels (no backward): use them unless autograd needs the LayerNorm."""
     return LN_FOLD and not (torch.is_grad_enabled() and x.requires_grad)
@@ -278,7 +273,7 @@ def ln_linear(x, st, pn: PackedNorm, pl: PackedLinear, wide=None):
     """Linear(LayerNorm(x)).  st: per-row (sum, sumsq) partials of x from the GEMM that produced it, or None.
     With st the LayerNorm is folded into the GEMM (no normalised tensor is written); otherwise the LayerNorm kernel runs.
     wide: "qkv" | "q" -- the kind of projection (ops.ROWLIN_WIDTHS) the row-resident kernel may take at this width."""
-    if wide and pl.wf is not None and fold_ok(x) and _PLAN_SCALE_ONE() and ops.rowlin_ok(x.shape[0], x.shape[1], pl.wf.shape[0], wide):
+    if wide and pl.wf is not None and fold_ok(x) and ops.rowlin_ok(x.shape[0], x.shape[1], pl.wf.shape[0], wide):
         return ops.rowlin(x, pl.wf, pl.bf, eps=pl.eps)
     if st is not None and pl.wf is not None and fold_ok(x):
         return ops.gemm_conv(x, pl.wf, B=1, H=1, W=x.shape[0], taps=1, bias=pl.bf, ln=(st, pl.eps, pl.cs))
