@@ -228,3 +228,33 @@ def test_rowlin_with_groupnorm_equals_groupnorm_apply_then_linear_bitwise():
     ref = ops.rowlin(h, w.half().to(d), b.to(d), ln=False)
     out = ops.rowlin(y, w.half().to(d), b.to(d), ln=False, gn=(gp, chunks, H * W, gng, gnb, 1e-6))
     assert torch.equal(out, ref)
+
+
+def test_rowlin_4wave_blocks_developer_variant():
+    """The measured-and-lost form (two independent 4-wave blocks per CU, knob LR_ROWLIN_W4, profiles/r06_rowlin_w4.txt): same bounds as the
+    product kernel; the plain Linear is bit-equal to it (same k order per output, one rounding)."""
+    from leftrefill_amd import _lib, ops, packing
+    from tests.test_gpu_ops import need_dev_build
+    need_dev_build()
+    d = dev()
+    M = 2048
+    x = h16(G.T("rowlin.w4.x", (M, C)) * 1.3 + 0.2)
+    w, b, gamma, beta = _params("p", 1920)
+    wf, bf, _cs = packing.fold_layernorm(w, b, gamma, beta)
+    wl, bl, _g, _b = _params("lin", C)
+    wg, bg, gg, betag = _params("g", 5120)
+    perm = packing.geglu_perm(2560)
+    wgf, bgf, _ = packing.fold_layernorm(wg, bg, gg, betag)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            _lib.dev_set("LR_ROWLIN_W4", mode)
+            outs[mode] = (ops.rowlin(x.half().to(d), wf.to(d), bf.to(d), eps=1e-5),
+                          ops.rowlin(x.half().to(d), wl.half().to(d), bl.to(d), ln=False),
+                          ops.rowlin(x.half().to(d), wgf[perm].contiguous().to(d), bgf[perm].contiguous().to(d), eps=1e-5, geglu=True))
+    finally:
+        _lib.dev_set("LR_ROWLIN_W4", None)
+    report("rowlin w4 q|k|v", outs[1][0], F.linear(unet_ref.layer_norm(x, gamma, beta), w, b), atol=2e-3)
+    assert torch.equal(outs[1][1], outs[0][1])
+    for a, bb in zip(outs[1], outs[0]):
+        assert (a.float() - bb.float()).abs().max().item() <= 6e-3
