@@ -390,6 +390,17 @@ int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float* gamma, fl
 int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
                      const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu,
                      float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s);
+/* ABI 25: the two backward passes with the gradient of the residual branch around the normalisation added in fp32 before the one
+ * rounding -- `x + f(LayerNorm(x))` (attention.py:279-283) and `skip_connection(x) + f(GroupNorm(x))` (openaimodel.py:254-274,
+ * attention.py:399-419) send two gradients to x; dres* (same layout as x*, NULL = none) is the one that does not pass through the
+ * normalisation, so the fan-in sum costs no pass of its own.  fwd_chunks: chunk count of fwd_partials ([N][fwd_chunks][32][2]: the
+ * per-group sums a producing GEMM wrote through lr_gemm_args.gn_group_out, or lr_groupnorm_finalize's [N][1][32][2]); 0 = the
+ * lr_groupnorm_stats layout of lr_groupnorm_bwd. */
+int lr_layernorm_bwd_res(const lr_half* x, const lr_half* dy, const lr_half* dres, const float* gamma, float eps, lr_half* dx,
+                         int M, int C, lr_stream_t s);
+int lr_groupnorm_bwd_res(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, const lr_half* dres1,
+                         const lr_half* dres2, int N, int HW, const float* fwd_partials, int fwd_chunks, const float* gamma,
+                         const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s);
 /* GEGLU: pre = projection + bias in the packed [u16 | g16] column layout (lr_gemm_conv_f16 with geglu = 0 on the packed
  * weights), dy [M][H] -> dpre [M][2H] (same layout): du = dy * gelu(g), dg = dy * u * gelu'(g). */
 int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, int H, lr_stream_t s);
@@ -397,7 +408,8 @@ int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, in
 int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s);
 /* Attention: forward that also saves the log2-domain log-sum-exp (lse [B][heads][Nq] fp32), and the backward that
  * recomputes P from it (two deterministic kernels: dQ over key tiles; dK, dV over query tiles; plus D = rowsum(dO o O)).
- * qt / kt / dot are lr_transpose_v_f16 copies of q / k / dout ([B][heads*64][ld], ld = rows rounded up to 64);
+ * qt / kt / dot / ld_qt / ld_kt: ignored since ABI 25 (rounds 2-5 took lr_transpose_v_f16 copies of q / k / dout there; the kernels now
+ * gather the k-major operands from the natural tiles with the LDS transpose read); the fields keep the struct layout, pass NULL / 0.
  * dsum: scratch [B][heads][Nq] fp32.  dq [B][Nq][lddq], dk / dv [B][Nkv][lddk | lddv], head h in columns h*64.. like q/k/v. */
 int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                          int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);
@@ -433,6 +445,11 @@ int lr_layernorm_bwd_bf16(const lr_half* x, const lr_half* dy, const float* gamm
 int lr_groupnorm_bwd_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
     const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials,
     lr_half* dx1, lr_half* dx2, lr_stream_t s);
+int lr_layernorm_bwd_res_bf16(const lr_half* x, const lr_half* dy, const lr_half* dres, const float* gamma, float eps, lr_half*
+    dx, int M, int C, lr_stream_t s);
+int lr_groupnorm_bwd_res_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, const lr_half* dres1,
+    const lr_half* dres2, int N, int HW, const float* fwd_partials, int fwd_chunks, const float* gamma, const float* beta,
+    float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s);
 int lr_nchw_f32_to_nhwc_bf16(const float* x1, int C1, const float* x2, int C2, lr_half* y, int Cpad, int N, int H, int
     W, lr_stream_t s);
 int lr_nhwc_f16_to_nchw_bf16(const lr_half* y, int Cstride, int C, void* out, int out_is_f32, int N, int H, int W,

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -105,6 +105,9 @@ SIGNATURES = {
     "lr_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
     "lr_groupnorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                          c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "lr_layernorm_bwd_res": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
+    "lr_groupnorm_bwd_res": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                             c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "lr_mv_gather_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_mv_scatter_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "lr_geglu_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p],
@@ -151,7 +154,7 @@ SIGNATURES = {
 
 # bfloat16 twins (include/leftrefill_hip.h, last section): same argument lists as the fp16 entry points
 BF16_TWINS = ["lr_groupnorm_stats", "lr_groupnorm_apply", "lr_groupnorm_apply_n", "lr_layernorm", "lr_layernorm_bwd",
-              "lr_groupnorm_bwd", "lr_nchw_f32_to_nhwc_f16", "lr_nhwc_f16_to_nchw", "lr_timestep_embedding", "lr_linear_small_m",
+              "lr_groupnorm_bwd", "lr_layernorm_bwd_res", "lr_groupnorm_bwd_res", "lr_nchw_f32_to_nhwc_f16", "lr_nhwc_f16_to_nchw", "lr_timestep_embedding", "lr_linear_small_m",
               "lr_mv_gather", "lr_mv_scatter", "lr_ddim_cfg_step", "lr_geglu_fwd", "lr_geglu_bwd", "lr_sumpool2x2",
               "lr_mv_gather_bwd", "lr_mv_scatter_bwd", "lr_attention_f16", "lr_attention_causal_f16", "lr_attention_lse_f16",
               "lr_attention_vt_f16", "lr_transpose_v_f16", "lr_attention_bwd_f16", "lr_xattn_block_f16",

@@ -2,14 +2,15 @@
 // (flash-attention style, no N x N matrix in memory).  Deterministic: two kernels, no atomics.
 //
 //   P  = exp2(c * q k^T - lse)          c = scale * log2(e), lse from lr_attention_lse_f16
-//   D  = rowsum(dO o O)                 (attn_bwd_prep_kernel)
+//   D  = rowsum(dO o O)                 (prologue of attn_bwd_dq_kernel, handed to attn_bwd_dkv_kernel through `dsum`)
 //   dV = P^T dO        dP = dO V^T      dS = P o (dP - D)
 //   dQ = scale * dS K  dK = scale * dS^T Q
 //
 // Both kernels keep the forward's register conventions (attention.hip): 32x32x16 MFMAs, one column (query or key) per
-// lane, the probability / dS tile feeds the next MFMA straight from the accumulator registers, and the operand that has
-// to be read "k-major" comes from a pre-transposed, key-permuted copy made by lr_transpose_v_f16 (K^T for dQ; Q^T and dO^T
-// for dK / dV), so every tile streams into LDS by DMA with the XOR swizzle and every fragment is one ds_read_b128.
+// lane, the probability / dS tile feeds the next MFMA straight from the accumulator registers.  The operand that has to be
+// read "k-major" (K^T for dQ; Q^T and dO^T for dK / dV) is the SAME natural [row][d] tile staged a second time by DMA with the
+// forward's transpose-read swizzle and gathered by ds_read_b64_tr_b16 (attention.hip, VM = 2): no pre-transposed copies exist
+// (round 6; rounds 2-5 made them with three lr_transpose_v_f16 launches per attention: 93 launches / 0.63 ms per training step).
 //
 //   attn_bwd_dq_kernel : block = 4 waves x 32 queries, loops over 64-key tiles.      12 of the 28 MFMA groups
 //   attn_bwd_dkv_kernel: block = 4 waves x 32 keys,    loops over 64-query tiles.    16 of the 28 MFMA groups
@@ -27,35 +28,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <typename T>
 struct AttnBwdParams {
   const T* q; const T* k; const T* v; const T* o; const T* dout;
-  const T* qt; const T* kt; const T* dot;   // pre-transposed [B][heads*64][ld_*]
   const float* lse; float* dsum;                   // [B][heads][Nq]
   T* dq; T* dk; T* dv;
-  int ldq, ldk, ldv, ldo, lddo, ld_qt, ld_kt, lddq, lddk, lddv, heads, Nq, Nkv, nblocks, ntile_blocks;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, heads, Nq, Nkv, nblocks, ntile_blocks;
   float c, scale;
 };
-
-// D[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one thread per (q, head)
-template <typename T>
-__global__ void attn_bwd_prep_kernel(const AttnBwdParams<T> P, int B) {
-  const long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const long long total = (long long)B * P.heads * P.Nq;
-  if (id >= total) return;
-  const int q = (int)(id % P.Nq);
-  const int h = (int)((id / P.Nq) % P.heads);
-  const int b = (int)(id / ((long long)P.Nq * P.heads));
-  const T* op = P.o + ((size_t)b * P.Nq + q) * P.ldo + h * 64;
-  const T* gp = P.dout + ((size_t)b * P.Nq + q) * P.lddo + h * 64;
-  float acc = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a[8], g[8];
-    lr_unpack8<T>(*reinterpret_cast<const uint4*>(op + j * 8), a);
-    lr_unpack8<T>(*reinterpret_cast<const uint4*>(gp + j * 8), g);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc = fmaf(a[i], g[i], acc);
-  }
-  P.dsum[id] = acc;
-}
 
 // 64 rows x 128 B tile -> LDS by DMA with the forward's swizzle; rows >= nrows read the zero page
 template <typename T>
@@ -70,16 +47,43 @@ __device__ __forceinline__ void ab_stage_rows(char* dst, const T* base, int ld, 
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + rbase * 128), 16, 0, 0);
   }
 }
-// 64 rows (d) x 128 B (one 64-column tile) of a pre-transposed operand; always in bounds (ld padded to whole tiles)
+// the same 64 rows x 128 B tile for the transpose read: 16-byte chunk c of row r sits in slot c ^ 4 ((r >> 1) & 1), so the four
+// rows of one ds_read_b64_tr_b16 (128 bytes apart) cover 64 distinct banks per half-wave (attention.hip, stage_vn)
 template <typename T>
-__device__ __forceinline__ void ab_stage_t(char* dst, const T* base, int ld, int col0, int w, int lane) {
+__device__ __forceinline__ void ab_stage_rows_tr(char* dst, const T* base, int ld, int row0, int nrows, int w, int lane,
+                                                 const T* zero) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rbase = (i * 4 + w) * 8;
     const int row = rbase + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * ld + col0 + chunk * 8), (lptr_t)(dst + rbase * 128), 16, 0, 0);
+    const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    const T* g = row0 + row < nrows ? base + (size_t)(row0 + row) * ld + chunk * 8 : zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + rbase * 128), 16, 0, 0);
   }
+}
+// A operand X^T[d = db*32 + ql][k-slots] of MFMA (rb, tt) out of the natural tile X[row][d]: k-slot (hi*8 + jj) is row
+// rb*32 + 16*tt + 4*hi + jj (jj < 4) and rb*32 + 16*tt + 8 + 4*hi + (jj - 4) (jj >= 4) -- exactly the rows one accumulator-fed
+// B operand (P or dS) carries.  Two transpose reads: a 16-lane group reads a [4 rows][16 d] block, every lane receives ONE d column.
+struct AbTr {
+  int off, chunk, swz;
+  __device__ __forceinline__ AbTr(int lane) {
+    const int hi = lane >> 5, j = (lane & 15) >> 2, q = lane & 3;
+    off = (4 * hi + j) * 128 + (q & 1) * 8;
+    chunk = 2 * ((lane >> 4) & 1) + (q >> 1);
+    swz = (j >> 1) << 2;
+  }
+};
+template <typename T>
+__device__ __forceinline__ vec8<T> ab_frag_tr(const char* tile, const AbTr& tr, int rb, int tt, int db) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+  const char* a = tile + (rb * 32 + 16 * tt) * 128 + tr.off + (((4 * db + tr.chunk) ^ tr.swz) << 4);
+  const vec4<T> va = __builtin_bit_cast(vec4<T>, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)a));
+  const vec4<T> vb = __builtin_bit_cast(vec4<T>, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(a + 8 * 128)));
+  vec8<T> f;
+  f[0] = va[0]; f[1] = va[1]; f[2] = va[2]; f[3] = va[3];
+  f[4] = vb[0]; f[5] = vb[1]; f[6] = vb[2]; f[7] = vb[3];
+  return f;
 }
 template <typename T>
 __device__ __forceinline__ vec8<T> ab_frag(const char* tile, int row, int chunk) {
@@ -91,7 +95,7 @@ __device__ __forceinline__ vec8<T> ab_frag(const char* tile, int row, int chunk)
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdParams<T> P) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * AB_TILE * 128];   // {K, V, K^T} x 2 buffers
+  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * AB_TILE * 128];   // {K, V, K in the transpose-read swizzle} x 2 buffers
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int qblk = blockIdx.x % P.ntile_blocks;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
 
   const T* kp = P.k + (size_t)b * P.Nkv * P.ldk + h * 64;
   const T* vp = P.v + (size_t)b * P.Nkv * P.ldv + h * 64;
-  const T* ktp = P.kt + ((size_t)b * P.heads + h) * 64 * P.ld_kt;
+  const AbTr tr(lane);
   const int qrow = qblk * 128 + w * 32 + ql;
   const int qc = min(qrow, P.Nq - 1);
   vec8<T> qf[4], gf[4];      // Q^T / dO^T B-operands: lane holds row qc, columns s4*16 + hi*8 .. +8
@@ -112,7 +116,19 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
     gf[s4] = *reinterpret_cast<const vec8<T>*>(P.dout + ((size_t)b * P.Nq + qc) * P.lddo + h * 64 + s4 * 16 + hi * 8);
   }
   const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + qc;
-  const float lse = P.lse[sidx], dsum = P.dsum[sidx];
+  const float lse = P.lse[sidx];
+  // D[q] = sum_d dO[q][d] O[q][d]: the lane already holds half of the query's dO row (columns s4*16 + hi*8 .. +8), the other half sits
+  // in lane ^ 32 -- computed here and written for the dK / dV kernel that follows on the stream (round 6: attn_bwd_prep_kernel, one
+  // uncoalesced launch per attention, is gone)
+  float dsum = 0.f;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const vec8<T> of = *reinterpret_cast<const vec8<T>*>(P.o + ((size_t)b * P.Nq + qc) * P.ldo + h * 64 + s4 * 16 + hi * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dsum = fmaf((float)gf[s4][i], (float)of[i], dsum);
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (hi == 0 && qrow < P.Nq) P.dsum[sidx] = dsum;
 
   f32x16 dq[2];
 #pragma unroll
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
     char* base = smem + buf * (3 * AB_TILE * 128);
     ab_stage_rows(base, kp, P.ldk, tile * AB_TILE, P.Nkv, w, lane, zero);
     ab_stage_rows(base + AB_TILE * 128, vp, P.ldv, tile * AB_TILE, P.Nkv, w, lane, zero);
-    ab_stage_t(base + 2 * AB_TILE * 128, ktp, P.ld_kt, tile * AB_TILE, w, lane);
+    ab_stage_rows_tr(base + 2 * AB_TILE * 128, kp, P.ldk, tile * AB_TILE, P.Nkv, w, lane, zero);
   };
   stage(0, 0);
   __syncthreads();
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          dq[db] = lr_mfma32(ab_frag<T>(Kt, db * 32 + ql, kb * 4 + tt * 2 + hi), dsf[kb][tt], dq[db]);
+          dq[db] = lr_mfma32(ab_frag_tr<T>(Kt, tr, kb, tt, db), dsf[kb][tt], dq[db]);
     __syncthreads();
   };
   const int nfull = P.Nkv / AB_TILE;
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dq_kernel(const AttnBwdPa
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdParams<T> P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // {Q, dO, Q^T, dO^T} x 2 buffers (64 KB) + lse, D (1 KB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // {Q, dO, and both again in the transpose-read swizzle} x 2 buffers (64 KB) + lse, D (1 KB)
   float (*s_lse)[AB_TILE] = reinterpret_cast<float (*)[AB_TILE]>(smem + 2 * 4 * AB_TILE * 128);
   float (*s_dsum)[AB_TILE] = s_lse + 2;
   const int t = threadIdx.x, lane = t & 63;
@@ -204,8 +220,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
 
   const T* qp = P.q + (size_t)b * P.Nq * P.ldq + h * 64;
   const T* gp = P.dout + (size_t)b * P.Nq * P.lddo + h * 64;
-  const T* qtp = P.qt + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
-  const T* gtp = P.dot + ((size_t)b * P.heads + h) * 64 * P.ld_qt;
+  const AbTr tr(lane);
   const float* lsep = P.lse + ((size_t)b * P.heads + h) * P.Nq;
   const float* dsp = P.dsum + ((size_t)b * P.heads + h) * P.Nq;
   const int krow = kblk * 128 + w * 32 + ql;
@@ -228,8 +243,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
     char* base = smem + buf * (4 * AB_TILE * 128);
     ab_stage_rows(base, qp, P.ldq, tile * AB_TILE, P.Nq, w, lane, zero);
     ab_stage_rows(base + AB_TILE * 128, gp, P.lddo, tile * AB_TILE, P.Nq, w, lane, zero);
-    ab_stage_t(base + 2 * AB_TILE * 128, qtp, P.ld_qt, tile * AB_TILE, w, lane);
-    ab_stage_t(base + 3 * AB_TILE * 128, gtp, P.ld_qt, tile * AB_TILE, w, lane);
+    ab_stage_rows_tr(base + 2 * AB_TILE * 128, qp, P.ldq, tile * AB_TILE, P.Nq, w, lane, zero);
+    ab_stage_rows_tr(base + 3 * AB_TILE * 128, gp, P.lddo, tile * AB_TILE, P.Nq, w, lane, zero);
     if (t < 2 * AB_TILE) {       // rows past Nq: lse = +inf -> P = 0, D = 0
       const int i = t & (AB_TILE - 1), qi = tile * AB_TILE + i;
       if (t < AB_TILE) s_lse[buf][i] = qi < P.Nq ? lsep[qi] : INFINITY;
@@ -279,9 +294,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const int chunk = qb * 4 + tt * 2 + hi;
-          dv[db] = lr_mfma32(ab_frag<T>(Gt, db * 32 + ql, chunk), pf[qb][tt], dv[db]);
-          dk[db] = lr_mfma32(ab_frag<T>(Qt, db * 32 + ql, chunk), dsf[qb][tt], dk[db]);
+          dv[db] = lr_mfma32(ab_frag_tr<T>(Gt, tr, qb, tt, db), pf[qb][tt], dv[db]);
+          dk[db] = lr_mfma32(ab_frag_tr<T>(Qt, tr, qb, tt, db), dsf[qb][tt], dk[db]);
         }
     __syncthreads();
   }
@@ -304,30 +318,23 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
 
 template <typename T>
 static int lr_attention_bwd_t(const lr_attn_bwd_args* a, lr_stream_t s) {
-  if (!a || !a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->qt || !a->kt || !a->dot || !a->dsum || !a->dq ||
-      !a->dk || !a->dv)
+  if (!a || !a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->dsum || !a->dq || !a->dk || !a->dv)
     return LR_E_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nkv <= 0) return LR_E_ARG;
   if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddo) % 8 || (a->lddq | a->lddk | a->lddv) % 4) return LR_E_ALIGN;
-  if (a->ld_qt % AB_TILE || a->ld_kt % AB_TILE || a->ld_qt < a->Nq || a->ld_kt < a->Nkv) return LR_E_ALIGN;
-  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o | (uintptr_t)a->dout | (uintptr_t)a->qt |
-       (uintptr_t)a->kt | (uintptr_t)a->dot) & 15)
-    return LR_E_ALIGN;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o | (uintptr_t)a->dout) & 15) return LR_E_ALIGN;
   AttnBwdParams<T> P;
   P.q = (const T*)a->q; P.k = (const T*)a->k; P.v = (const T*)a->v; P.o = (const T*)a->o;
-  P.dout = (const T*)a->dout; P.qt = (const T*)a->qt; P.kt = (const T*)a->kt; P.dot = (const T*)a->dot;
+  P.dout = (const T*)a->dout;
   P.lse = a->lse; P.dsum = a->dsum;
   P.dq = (T*)a->dq; P.dk = (T*)a->dk; P.dv = (T*)a->dv;
-  P.ldq = a->ldq; P.ldk = a->ldk; P.ldv = a->ldv; P.ldo = a->ldo; P.lddo = a->lddo; P.ld_qt = a->ld_qt; P.ld_kt = a->ld_kt;
+  P.ldq = a->ldq; P.ldk = a->ldk; P.ldv = a->ldv; P.ldo = a->ldo; P.lddo = a->lddo;
   P.lddq = a->lddq; P.lddk = a->lddk; P.lddv = a->lddv;
   P.heads = a->heads; P.Nq = a->Nq; P.Nkv = a->Nkv;
   P.scale = a->scale;
   P.c = a->scale * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)s;
-  const long long total = (long long)a->B * a->heads * a->Nq;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, a->B);
-  int rc = lr_launch_status();
-  if (rc) return rc;
+  int rc;
   P.ntile_blocks = (a->Nq + 127) / 128;
   hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), 0, st, P);
   rc = lr_launch_status();

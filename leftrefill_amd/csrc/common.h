@@ -75,7 +75,8 @@ __device__ __forceinline__ float lr_erf(float x) {
 // value instead of rcp + exp2 + a degree-5 polynomial; |GELU error| <= 6.4e-7 absolute over all x in fp32 evaluation
 // (checked on 1.8 M points, tools/fit_gelu.py) -- 3 orders below the fp16 / bf16 rounding of the stored result.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t lr_gelu_erf2(const f32x2_t x) {
+// Phi(x) - 0.5 for two values (the part of lr_gelu_erf2 the GEGLU backward shares: gelu'(x) = Phi(x) + x phi(x))
+__device__ __forceinline__ f32x2_t lr_phi_mhalf2(const f32x2_t x) {
   const f32x2_t a = {fminf(fabsf(x[0]), 6.08111832f), fminf(fabsf(x[1]), 6.08111832f)};
   f32x2_t p = __builtin_elementwise_fma(a, (f32x2_t){-1.874598518e-06f, -1.874598518e-06f}, (f32x2_t){6.238633299e-05f, 6.238633299e-05f});
   p = __builtin_elementwise_fma(p, a, (f32x2_t){-9.366052953e-04f, -9.366052953e-04f});
@@ -86,8 +87,10 @@ __device__ __forceinline__ f32x2_t lr_gelu_erf2(const f32x2_t x) {
   p = __builtin_elementwise_fma(p, a, (f32x2_t){-9.999946099e-01f, -9.999946099e-01f});
   const f32x2_t e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};     // Phi(-|x|)
   const f32x2_t h = (f32x2_t){0.5f, 0.5f} - e;
-  const f32x2_t d = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
-  return __builtin_elementwise_fma(x, d, x * 0.5f);
+  return (f32x2_t){copysignf(h[0], x[0]), copysignf(h[1], x[1])};
+}
+__device__ __forceinline__ f32x2_t lr_gelu_erf2(const f32x2_t x) {
+  return __builtin_elementwise_fma(x, lr_phi_mhalf2(x), x * 0.5f);
 }
 
 // scalar form: the same formula, so the unfused training forward (lr_geglu_fwd) and the fused epilogue agree

@@ -74,14 +74,30 @@ __global__ void linear_small_m_kernel(const T* __restrict__ a, int lda, const T*
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* s_a = reinterpret_cast<T*>(smem_raw);  // [MMAX][K]
   const int t = threadIdx.x;
-  for (int idx = t; idx < MMAX * K; idx += blockDim.x) {
-    const int m = idx / K, k = idx % K;
-    float v = 0.f;
-    if (m < M) {
-      v = (float)a[(size_t)m * lda + k];
-      if (act_in) v = lr_silu(v);
+  const int K8 = K >> 3;
+  if ((lda & 7) == 0 && (((uintptr_t)a) & 15) == 0) {      // 16-byte loads (round 6: the scalar staging loop was most of a batch-16 launch)
+    for (int idx = t; idx < MMAX * K8; idx += blockDim.x) {
+      const int m = idx / K8, k = (idx - m * K8) * 8;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        lr_unpack8<T>(*reinterpret_cast<const uint4*>(a + (size_t)m * lda + k), v);
+        if (act_in) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = lr_silu(v[i]);
+        }
+      }
+      *reinterpret_cast<uint4*>(s_a + m * K + k) = lr_pack8<T>(v);
     }
-    s_a[idx] = (T)v;
+  } else {
+    for (int idx = t; idx < MMAX * K; idx += blockDim.x) {
+      const int m = idx / K, k = idx % K;
+      float v = 0.f;
+      if (m < M) {
+        v = (float)a[(size_t)m * lda + k];
+        if (act_in) v = lr_silu(v);
+      }
+      s_a[idx] = (T)v;
+    }
   }
   __syncthreads();
   const int lane = t & 63, wave = t >> 6;
@@ -222,7 +238,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 24; }
+extern "C" int lr_abi_version(void) { return 25; }
 
 #ifdef LR_DEV_VARIANTS
 // developer build only: name -> value table behind LR_DEV (common.h); set through lr_dev_set by the Python front end
@@ -291,7 +307,12 @@ static int lr_linear_small_m_t(const lr_half* a, int lda, const lr_half* w, cons
   if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) return LR_E_ARG;
   if (M > 16) return LR_E_UNSUPPORTED;
   if (K % 8) return LR_E_ALIGN;
-  const int cpw = 4, waves = 4;
+  // columns per wave: every block stages the M activation rows once, so wide layers take more columns per block (about two blocks per
+  // CU); a column's arithmetic does not depend on it (one lane-strided K loop + one wave sum per column): same bits for every value
+  const int waves = 4;
+  int cpw = (N + waves * 512 - 1) / (waves * 512);
+  if (cpw < 4) cpw = 4;
+  if (cpw > 32) cpw = 32;
   dim3 grid((N + cpw * waves - 1) / (cpw * waves)), block(64 * waves);
   hipStream_t st = (hipStream_t)s;
   if (M <= 4)
@@ -367,11 +388,16 @@ __global__ void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict_
     lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
     lr_unpack8<T>(*reinterpret_cast<const uint4*>(dy + m * H + c), d);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float cdf = 0.5f * (1.0f + lr_erf(g[i] * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[i] * g[i]);
-      du[i] = d[i] * g[i] * cdf;
-      dg[i] = d[i] * u[i] * fmaf(g[i], pdf, cdf);
+    for (int i = 0; i < 8; i += 2) {      // two values per instruction stream (packed fp32), Phi from the forward's own formula
+      const f32x2_t gg = {g[i], g[i + 1]}, dd = {d[i], d[i + 1]}, uu = {u[i], u[i + 1]};
+      const f32x2_t ph = lr_phi_mhalf2(gg);                                                    // Phi(g) - 0.5
+      const f32x2_t q = gg * gg * -0.72134752044448170368f;                                    // -g^2 / 2 in log2 units
+      const f32x2_t pdf = (f32x2_t){__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])} * 0.3989422804014327f;
+      const f32x2_t gelu = __builtin_elementwise_fma(gg, ph, gg * 0.5f);                       // == lr_gelu_erf2(g)
+      const f32x2_t dgel = __builtin_elementwise_fma(gg, pdf, ph + 0.5f);                      // Phi + g phi
+      const f32x2_t a = dd * gelu, b = dd * uu * dgel;
+      du[i] = a[0]; du[i + 1] = a[1];
+      dg[i] = b[0]; dg[i + 1] = b[1];
     }
     *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc) = lr_pack8<T>(du);
     *reinterpret_cast<uint4*>(dpre + m * 2 * H + pc + 16) = lr_pack8<T>(dg);
@@ -391,7 +417,11 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out,
     lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc), u);
     lr_unpack8<T>(*reinterpret_cast<const uint4*>(pre + m * 2 * H + pc + 16), g);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = u[i] * lr_gelu_erf(g[i]);
+    for (int i = 0; i < 8; i += 2) {      // (packed pairs: same formula, same bits as the scalar form)
+      const f32x2_t ge = lr_gelu_erf2((f32x2_t){g[i], g[i + 1]});
+      o[i] = u[i] * ge[0];
+      o[i + 1] = u[i + 1] * ge[1];
+    }
     *reinterpret_cast<uint4*>(out + m * H + c) = lr_pack8<T>(o);
   }
 }

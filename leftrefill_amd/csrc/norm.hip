@@ -517,9 +517,11 @@ extern "C" int lr_softmax_rows_f16(const lr_half* s, lr_half* p, int M, int N, f
 // =====================================================================================================================
 
 // ---- LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  One wave per row.
+//      dres (or NULL): the gradient that reaches x along the residual branch around the LayerNorm (x + f(LayerNorm(x))); it is added
+//      in fp32 before the one rounding, so the fan-in sum of the two branches is not a separate pass (and not a second rounding).
 template <int NV, typename T>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
-                                     float eps, T* __restrict__ dx, int M, int C) {
+                                     float eps, T* __restrict__ dx, int M, int C, const T* __restrict__ dres) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -575,6 +577,12 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restric
       float f[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] = rstd * (g[j][i] - s1 - v[j][i] * s2);
+      if (dres) {
+        float e[8];
+        lr_unpack8<T>(*reinterpret_cast<const uint4*>(dres + (size_t)row * C + o * 8), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += e[i];
+      }
       *reinterpret_cast<uint4*>(dx + (size_t)row * C + o * 8) = lr_pack8<T>(f);
     }
   }
@@ -582,17 +590,17 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restric
 
 template <typename T>
 static int lr_layernorm_bwd_t(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M,
-                                int C, lr_stream_t s) {
+                                int C, lr_stream_t s, const lr_half* dres = nullptr) {
   if (!x || !dy || !gamma || !dx || M <= 0) return LR_E_ARG;
   if (C % 8 || C > 2048) return LR_E_ALIGN;
   const int nv = (C / 8 + 63) / 64;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)s;
   switch (nv) {
-    case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
-    case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
-    case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
-    default: hipLaunchKernelGGL((layernorm_bwd_kernel<4, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C); break;
+    case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C, (const T*)dres); break;
+    case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C, (const T*)dres); break;
+    case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C, (const T*)dres); break;
+    default: hipLaunchKernelGGL((layernorm_bwd_kernel<4, T>), grid, block, 0, st, (const T*)x, (const T*)dy, gamma, eps, (T*)dx, M, C, (const T*)dres); break;
   }
   return lr_launch_status();
 }
@@ -632,7 +640,7 @@ template <typename T>
 __global__ void gn_bwd_stats_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, int HW,
                                     const T* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float eps, int silu, float* __restrict__ out, int nOct,
-                                    int R, int nchunks) {
+                                    int R, int nchunks, int fwd_chunks) {
   extern __shared__ float s_part[];  // [R][C][2]
   __shared__ float s_mean[32], s_rstd[32];
   const int C = C1 + C2, Cg = C / 32;
@@ -641,7 +649,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x1, int C1, const T* _
   const int per = (HW + nchunks - 1) / nchunks;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   const int c0 = o * 8;
-  gn_finalize_stats(fwd, n, nchunks, HW, Cg, eps, s_mean, s_rstd);
+  gn_finalize_stats(fwd, n, fwd_chunks, HW, Cg, eps, s_mean, s_rstd);
   __syncthreads();
   const T* src;
   int cs;
@@ -701,14 +709,14 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* _
                                     const T* __restrict__ dy, const float* __restrict__ fwd, const float* __restrict__ bwd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int silu,
                                     T* __restrict__ dx1, T* __restrict__ dx2, int pix_per_block, int nOct, int R,
-                                    int nchunks) {
+                                    int nchunks, int fwd_chunks, const T* __restrict__ dres1, const T* __restrict__ dres2) {
   __shared__ float s_mean[32], s_rstd[32], s_c1[32], s_c2[32];
   const int C = C1 + C2, Cg = C / 32;
   const int n = blockIdx.y, t = threadIdx.x;
   const int o = t % nOct, r = t / nOct;
   const int c0 = o * 8;
   const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-  gn_finalize_stats(fwd, n, nchunks, HW, Cg, eps, s_mean, s_rstd);
+  gn_finalize_stats(fwd, n, fwd_chunks, HW, Cg, eps, s_mean, s_rstd);
   __syncthreads();
   if (t < 128) {
     const int g = t >> 2, sub = t & 3;
@@ -726,10 +734,11 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* _
   __syncthreads();
   if (r >= R) return;
   const T* src;
+  const T* rsrc;      // residual-branch gradient of this source (or NULL), same layout as the source
   T* dst;
   int cs;
-  if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; dst = dx1 + ((size_t)n * HW) * C1 + c0; cs = C1; }
-  else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); dst = dx2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; }
+  if (c0 < C1) { src = x1 + ((size_t)n * HW) * C1 + c0; dst = dx1 + ((size_t)n * HW) * C1 + c0; cs = C1; rsrc = dres1 ? dres1 + ((size_t)n * HW) * C1 + c0 : nullptr; }
+  else { src = x2 + ((size_t)n * HW) * C2 + (c0 - C1); dst = dx2 + ((size_t)n * HW) * C2 + (c0 - C1); cs = C2; rsrc = dres2 ? dres2 + ((size_t)n * HW) * C2 + (c0 - C1) : nullptr; }
   const T* gsrc = dy + ((size_t)n * HW) * C + c0;
   float mu[8], rs[8], ga[8], be[8], k1[8], k2[8];
 #pragma unroll
@@ -748,6 +757,12 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* _
       const float z = fmaf(xh, ga[i], be[i]);
       const float g = gv[i] * gn_act_grad(z, silu) * ga[i];
       f[i] = rs[i] * (g - k1[i] - xh * k2[i]);
+    }
+    if (rsrc) {      // fan-in of the residual branch (x + f(GroupNorm(x))): fp32 add before the one rounding
+      float e[8];
+      lr_unpack8<T>(*reinterpret_cast<const uint4*>(rsrc + (size_t)pp * cs), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += e[i];
     }
     *reinterpret_cast<uint4*>(dst + (size_t)pp * cs) = lr_pack8<T>(f);
   };
@@ -769,8 +784,9 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* _
 template <typename T>
 static int lr_groupnorm_bwd_t(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW,
                                 const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu,
-                                float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) {
-  if (!x1 || !dy || !fwd_partials || !bwd_partials || !gamma || !beta || !dx1 || N <= 0 || HW <= 0) return LR_E_ARG;
+                                float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s, int fwd_chunks = 0,
+                                const lr_half* dres1 = nullptr, const lr_half* dres2 = nullptr) {
+  if (!x1 || !dy || !fwd_partials || !bwd_partials || !gamma || !beta || !dx1 || N <= 0 || HW <= 0 || fwd_chunks < 0) return LR_E_ARG;
   if (!x2) C2 = 0;
   if (C2 && !dx2) return LR_E_ARG;
   const int C = C1 + C2;
@@ -780,11 +796,21 @@ static int lr_groupnorm_bwd_t(const lr_half* x1, int C1, const lr_half* x2, int 
   if (R < 1) R = 1;
   const int threads = nOct * R;
   if (threads > 1024 || threads < 128) return LR_E_UNSUPPORTED;
-  const int nchunks = gn_nchunks(N, HW, C);
+  if (fwd_chunks == 0) fwd_chunks = gn_nchunks(N, HW, C);      // fwd_partials from lr_groupnorm_stats of the same input
+  // chunks of the backward's own statistics pass: ~1024 blocks (round 6; the forward pass's ~256 left one 4-wave block per CU, 32 KB of
+  // loads in flight per CU: 2.6 TB/s on x + dy) -- a pure function of the shape like the forward's count
+  int nchunks = (LR_DEV("LR_GN_BWD_BLOCKS", 1024) + N - 1) / N;
+  {
+    const int lo = gn_nchunks(N, HW, C);
+    if (nchunks < lo) nchunks = lo;
+    if (nchunks > LR_GN_CHUNKS) nchunks = LR_GN_CHUNKS;
+    if (nchunks > HW / 8) nchunks = HW / 8;
+    if (nchunks < 1) nchunks = 1;
+  }
   hipStream_t st = (hipStream_t)s;
   hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(nchunks, N), dim3(threads), (size_t)R * C * 2 * sizeof(float), st,
                      (const T*)x1, C1, (const T*)x2, C2, HW, (const T*)dy, fwd_partials, gamma, beta, eps, silu,
-                     bwd_partials, nOct, R, nchunks);
+                     bwd_partials, nOct, R, nchunks, fwd_chunks);
   int rc = lr_launch_status();
   if (rc) return rc;
   long long blocks = ((long long)N * HW * C * 2) >> 18;
@@ -794,7 +820,7 @@ static int lr_groupnorm_bwd_t(const lr_half* x1, int C1, const lr_half* x2, int 
   if (ppb > HW) ppb = HW;
   hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, st, (const T*)x1, C1,
                      (const T*)x2, C2, HW, (const T*)dy, fwd_partials, bwd_partials, gamma, beta, eps, silu, (T*)dx1,
-                     (T*)dx2, ppb, nOct, R, nchunks);
+                     (T*)dx2, ppb, nOct, R, nchunks, fwd_chunks, (const T*)dres1, (const T*)dres2);
   return lr_launch_status();
 }
 
@@ -811,3 +837,9 @@ extern "C" int lr_layernorm_bwd(const lr_half* x, const lr_half* dy, const float
 extern "C" int lr_layernorm_bwd_bf16(const lr_half* x, const lr_half* dy, const float* gamma, float eps, lr_half* dx, int M, int C, lr_stream_t s) { return lr_layernorm_bwd_t<bf16>(x, dy, gamma, eps, dx, M, C, s); }
 extern "C" int lr_groupnorm_bwd(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW, const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<f16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s); }
 extern "C" int lr_groupnorm_bwd_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, int N, int HW, const float* fwd_partials, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<bf16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s); }
+// ABI 25: the same backward passes with the residual-branch gradient(s) of the input added before the rounding (dres* may be NULL), and
+// GroupNorm forward partials with their own chunk count (the producer-epilogue [N][fwd_chunks][32][2] sums of lr_gemm_args.gn_group_out)
+extern "C" int lr_layernorm_bwd_res(const lr_half* x, const lr_half* dy, const lr_half* dres, const float* gamma, float eps, lr_half* dx, int M, int C, lr_stream_t s) { return lr_layernorm_bwd_t<f16>(x, dy, gamma, eps, dx, M, C, s, dres); }
+extern "C" int lr_layernorm_bwd_res_bf16(const lr_half* x, const lr_half* dy, const lr_half* dres, const float* gamma, float eps, lr_half* dx, int M, int C, lr_stream_t s) { return lr_layernorm_bwd_t<bf16>(x, dy, gamma, eps, dx, M, C, s, dres); }
+extern "C" int lr_groupnorm_bwd_res(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, const lr_half* dres1, const lr_half* dres2, int N, int HW, const float* fwd_partials, int fwd_chunks, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<f16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s, fwd_chunks, dres1, dres2); }
+extern "C" int lr_groupnorm_bwd_res_bf16(const lr_half* x1, int C1, const lr_half* x2, int C2, const lr_half* dy, const lr_half* dres1, const lr_half* dres2, int N, int HW, const float* fwd_partials, int fwd_chunks, const float* gamma, const float* beta, float eps, int silu, float* bwd_partials, lr_half* dx1, lr_half* dx2, lr_stream_t s) { return lr_groupnorm_bwd_t<bf16>(x1, C1, x2, C2, dy, N, HW, fwd_partials, gamma, beta, eps, silu, bwd_partials, dx1, dx2, s, fwd_chunks, dres1, dres2); }

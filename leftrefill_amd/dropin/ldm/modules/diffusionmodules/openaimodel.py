@@ -26,6 +26,8 @@ from leftrefill_amd import train_ops as ops     # == leftrefill_amd.ops unless a
 from ldm.modules.attention import SpatialTransformer
 from ldm.modules.diffusionmodules.util import conv_nd, linear, normalization, zero_module
 
+# training: every cross-attention's [k;v] projection of the context as ONE GEMM (and one input-gradient GEMM); 0 = one per block
+TRAIN_KV_BATCH = os.environ.get("LEFTREFILL_TRAIN_KV_BATCH", "1") != "0"
 # a sampler's per-timestep embedding rows computed once per sampling (UNetModel.prepare_timesteps); 0 = recompute them every step
 EMB_TABLE = os.environ.get("LEFTREFILL_EMB_TABLE", "1") != "0"
 
@@ -441,6 +443,16 @@ class UNetModel(nn.Module):
         # 9.2 GB peak, 30.2 ms per step); `recompute_in_backward = True` restores the reference's trade (7.6 GB, 39.4 ms).
         recompute = (self.recompute_in_backward and self.use_checkpoint and torch.is_grad_enabled()
                      and context.requires_grad)
+        if kv_cache is None and TRAIN_KV_BATCH and torch.is_grad_enabled() and context.requires_grad and P["tblocks"]:
+            # training: the [k;v] projections of the context for EVERY cross-attention as one GEMM (N = sum 2C = 24960 for the SD2 UNet)
+            # and, in the backward, one input-gradient GEMM over the concatenated d[k;v] (K = 24960) instead of 16 + 16 launches on
+            # 77 x batch rows each (24 us apiece at 16 x 77 rows) and 15 fan-in adds of the context gradient
+            w_all = P.get("kv_all_w")
+            if w_all is None or w_all.dtype != self.compute_dtype:
+                w_all = P["kv_all_w"] = torch.cat([pt.attn2.kv.w for pt in P["tblocks"]], 0).contiguous()
+            kv_all = ops.gemm_conv(ctx, w_all, B=1, H=1, W=N * L, taps=1)
+            parts = ops.split_cols(kv_all, [pt.attn2.kv.w.shape[0] for pt in P["tblocks"]])
+            kv_cache = [(p_, None) for p_ in parts]
 
         def ckpt(fn, act, *tensors):
             if not (recompute and (act.tok.requires_grad or any(t_.requires_grad for t_ in tensors))):
@@ -455,10 +467,15 @@ class UNetModel(nn.Module):
             def body(tok, tok2, *ts):
                 out = fn(E.Act(tok, n_, h_, w_, tok2=tok2, gs=gs_, gs2=gs2_), *ts)
                 shape["hw"] = (out.H, out.W)
-                return out.materialize()
+                # the block's own epilogue statistics leave the checkpoint with its output (round 6: the differentiable GroupNorm of the
+                # next block takes them, exactly like the plain forward -- the two modes stay bit-identical)
+                g_ = out.gs if out.tok2 is None else None
+                shape["gs"] = None if g_ is None else (g_[1], g_[3])
+                return (out.materialize(),) + ((None, None) if g_ is None else (g_[0], g_[2]))
 
-            y = torch_checkpoint(body, act.tok, act.tok2, *tensors, use_reentrant=False)
-            return E.Act(y, n_, *shape["hw"])
+            y, part, gp = torch_checkpoint(body, act.tok, act.tok2, *tensors, use_reentrant=False)
+            gs_out = None if shape["gs"] is None else (part, shape["gs"][0], gp, shape["gs"][1])
+            return E.Act(y, n_, *shape["hw"], gs=gs_out)
 
         def run(steps, act, half=False):
             """half: `act` is the first half of a CFG batch with identical halves; a SpatialTransformer ends that state."""

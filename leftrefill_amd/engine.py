@@ -289,7 +289,28 @@ FF_PROJ = __import__("os").environ.get("LEFTREFILL_FF_PROJ", "1") != "0"
 
 
 def gn_fuse_ok(x):
+    """Inference-only GroupNorm fusions (no backward): the skip-fused conv, the row-resident entries, the one-launch `out` block."""
     return GN_FUSE and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+# differentiable forward (round 6): GroupNorm statistics from the producers' epilogues; LEFTREFILL_TRAIN_GN_STATS=0 runs the statistics pass
+TRAIN_GN_STATS = __import__("os").environ.get("LEFTREFILL_TRAIN_GN_STATS", "1") != "0"
+# ... and the residual branches' gradients added inside the LayerNorm / GroupNorm backward kernels; LEFTREFILL_TRAIN_FORK=0: autograd's fan-in adds
+TRAIN_FORK = __import__("os").environ.get("LEFTREFILL_TRAIN_FORK", "1") != "0"
+
+
+def gn_stats_ok(x):
+    """Producer-epilogue GroupNorm statistics: also in the differentiable forward (round 6) -- no gradient flows through the sums, the
+    consuming GroupNorm's backward re-derives mean / rstd from them (train_ops._GroupNorm)."""
+    return GN_FUSE and (TRAIN_GN_STATS or not torch.is_grad_enabled())
+
+
+def training(x):
+    return torch.is_grad_enabled() and x.requires_grad
+
+
+def forking(x):
+    return TRAIN_FORK and training(x)
 
 
 def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False, skip=None):
@@ -305,16 +326,29 @@ def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn
             H, W = act.H, act.W
     else:
         H, W = act.H, act.W
-    want = gn_stats and gn_fuse_ok(act.tok) and pc.cout == pc.w.shape[0]
+    want = gn_stats and gn_stats_ok(act.tok) and pc.cout == pc.w.shape[0]
     y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
                       asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want, skip=skip)
     y, gs = y if want else (y, None)
     return Act(y, act.N, H, W, gs=gs)
 
 
+def _gn_train_stats(act: Act):
+    """How the differentiable GroupNorm gets its statistics (train_ops._GroupNorm `stats`): the producers' sums, else None = own pass."""
+    HW = act.HW
+    if not (act.gs is not None and HW % act.gs[1] == 0 and gn_stats_ok(act.tok)
+            and (act.tok2 is None or (act.gs2 is not None and HW % act.gs2[1] == 0))):
+        return None
+    if act.tok2 is None and act.gs[2] is not None:
+        return ("groups", act.gs[2], act.gs[3])
+    return ("channels", act.gs, act.gs2)
+
+
 def gn(act: Act, pn: PackedNorm, silu):
     """GroupNorm(32)(+SiLU) of the (virtually concatenated) activation; statistics from the producers when they came along."""
     HW = act.HW
+    if training(act.tok) or (act.tok2 is not None and training(act.tok2)):
+        return Act(ops.group_norm(act.tok, act.N, HW, pn.g, pn.b, pn.eps, silu, act.tok2, stats=_gn_train_stats(act)), act.N, act.H, act.W)
     fused = (act.gs is not None and HW % act.gs[1] == 0 and gn_fuse_ok(act.tok)
              and (act.tok2 is None or (act.gs2 is not None and HW % act.gs2[1] == 0)))
     if fused and act.tok2 is None and act.gs[2] is not None:
@@ -328,9 +362,20 @@ def gn(act: Act, pn: PackedNorm, silu):
     return Act(y, act.N, act.H, act.W)
 
 
+def gn_fork(act: Act, pn: PackedNorm, silu):
+    """Training: (GroupNorm(act), act') -- act' is `act` for the residual branch around the GroupNorm (the ResBlock's skip path, the
+    SpatialTransformer's `+ x_in`): the gradient of that branch is then added inside the GroupNorm's backward kernel (lr_groupnorm_bwd_res)
+    instead of by a separate fan-in add."""
+    y, t1, t2 = ops.group_norm_fork(act.tok, act.N, act.HW, pn.g, pn.b, pn.eps, silu, act.tok2, stats=_gn_train_stats(act))
+    return Act(y, act.N, act.H, act.W), Act(t1, act.N, act.H, act.W, tok2=t2)
+
+
 def resblock(act: Act, pr: PackedRes, emb_out):
     """emb_out: [N, Cout] fp16 (row stride may exceed Cout) = emb_layers(emb), added to every pixel of sample n."""
-    h = gn(act, pr.n1, True)
+    if forking(act.tok) or (act.tok2 is not None and forking(act.tok2)):
+        h, act = gn_fork(act, pr.n1, True)
+    else:
+        h = gn(act, pr.n1, True)
     h = conv(h, pr.c1, rowvec=emb_out, gn_stats=True)
     h = gn(h, pr.n2, True)
     if pr.c2s is not None and SKIP_FUSED and gn_fuse_ok(act.tok) and gn_fuse_ok(h.tok) and (act.tok2 is None or gn_fuse_ok(act.tok2)):
@@ -356,6 +401,9 @@ def self_attention(x, st, pn, pa: PackedAttn, B, L, want_stats=False, qkv=None, 
     """x + to_out(attention(LayerNorm(x) Wqkv)); st: row statistics of x (or None); qkv: the projection when its producer already
     made it (ops.stin_block); wide: single-view blocks let the row-resident kernel take the projection (the multi-view forms keep the
     LayerNorm-folded GEMM, whose arithmetic the sharded path reproduces bit for bit)."""
+    if qkv is None and forking(x):
+        n, x = ops.layer_norm_fork(x, pn.g, pn.b, pn.eps)      # the residual's gradient joins inside the LayerNorm backward kernel
+        qkv = linear(n, pa.qkv)
     qkv = ln_linear(x, st, pn, pa.qkv, wide=wide) if qkv is None else qkv
     a = ops.attention_qkv(qkv, B, pa.heads, L, pa.dim_head ** -0.5)
     return linear(a, pa.out, resid=x, want_stats=want_stats)
@@ -418,6 +466,9 @@ def cross_attention(x, st, pn, ctx, pa: PackedAttn, B, L, Lc, kv=None, want_stat
         with plan_batch_scale(2):
             q = ln_linear(x, st, pn, pa.q, wide="q")
         q, x = dup2(q), dup2(x)
+    elif forking(x):
+        n, x = ops.layer_norm_fork(x, pn.g, pn.b, pn.eps)
+        q = linear(n, pa.q)
     else:
         q = ln_linear(x, st, pn, pa.q, wide="q")
     vt = None
@@ -510,7 +561,7 @@ def _ffn(x, st, pt: PackedTBlock, want_stats, post=None, fused=None):
         g = ops.gemm_conv(x, pt.geglu_wf, B=1, H=1, W=x.shape[0], taps=1, bias=pt.geglu_bf, geglu=True,
                           ln=(st, pt.n3.eps, pt.geglu_cs))
     else:
-        n3 = ops.layer_norm(x, pt.n3.g, pt.n3.b, pt.n3.eps)
+        n3, x = (ops.layer_norm_fork if TRAIN_FORK else (lambda *a_: (ops.layer_norm(*a_), x)))(x, pt.n3.g, pt.n3.b, pt.n3.eps)      # (training: the residual below takes the fork's x)
         g = ops.gemm_conv(n3, pt.geglu_w, B=1, H=1, W=n3.shape[0], taps=1, bias=pt.geglu_b, geglu=True)
     if compose:
         # SpatialTransformer.proj_out behind the block: (Wp W2) g + Wp x + b' + x_in in one GEMM over [g | x] (PackedST.ff_proj_w)
@@ -686,7 +737,11 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
             h = ops.rowlin(x_in, ps.proj_in.w, ps.proj_in.b, ln=False, gn=(gs_in[2], gs_in[3], act.HW, ps.norm.g, ps.norm.b, ps.norm.eps))
             ws = False
         else:
-            h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
+            if forking(x_in):
+                h, xa = gn_fork(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False)
+                h, x_in = h.tok, xa.tok
+            else:
+                h = gn(Act(x_in, act.N, act.H, act.W, gs=gs_in), ps.norm, False).tok
             if stin_fused(h, ps):
                 # one launch: proj_in + LayerNorm + the block's fused q|k|v projection (level 0); x1 and qkv leave while the next
                 # columns multiply
@@ -707,7 +762,7 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
         assert st_dup_ok(ps)
         x_in = dup2(x_in)
         act = Act(x_in, 2 * act.N, act.H, act.W)
-    want = gn_fuse_ok(h)
+    want = gn_fuse_ok(h)      # inference: proj_out rides behind the last feed-forward (fused block / composed GEMM) with GroupNorm sums
     for i, pt in enumerate(ps.blocks):
         kv = kv_cache[pt.kv_slot] if kv_cache is not None else None
         last = i + 1 == len(ps.blocks)
@@ -724,6 +779,7 @@ def spatial_transformer(act: Act, ctx, Lc, ps: PackedST, kv_cache=None, dup=Fals
         if isinstance(r[0], str):           # "post": proj_out + x_in ran behind the block's feed-forward
             return Act(r[1], act.N, act.H, act.W, gs=r[2])
         h, st = r
+    want = gn_stats_ok(h)
     y = ops.gemm_conv(h, ps.proj_out.w, B=1, H=1, W=h.shape[0], taps=1, bias=ps.proj_out.b, resid=x_in, want_gn_stats=want,
                       gn_hw=act.HW)
     y, gs = y if want else (y, None)

@@ -46,6 +46,7 @@ def dgrad_weight(wt, taps, lo, hi):
 class _GemmConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, resid, wt, bias, rowvec, kw):
+        ctx.set_materialize_grads(False)      # (the statistics outputs carry no gradient: no zero tensors made for them)
         ctx.kw, ctx.wt, ctx.bias = kw, wt, bias
         ctx.C1 = x1.shape[-1]
         ctx.C2 = 0 if x2 is None else x2.shape[-1]
@@ -58,11 +59,23 @@ class _GemmConv(torch.autograd.Function):
             ctx.save_for_backward(pre)
             return geglu_fwd(pre)
         ctx.save_for_backward()                                            # plain conv / linear: dX needs only dY and W
+        if kw.get("want_gn_stats"):
+            # the producer-side GroupNorm statistics of the inference path (per-channel row-block partials + per-group sums): no
+            # gradient flows through them, the consuming GroupNorm's backward re-derives mean / rstd from the same sums
+            meta = kw.pop("_gs_meta")
+            y, gs = ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
+            if gs is None:
+                return y, None, None
+            meta[:] = [gs[1], gs[3]]
+            ctx.mark_non_differentiable(*[t for t in (gs[0], gs[2]) if t is not None])
+            return y, gs[0], gs[2]
         return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         kw, wt = ctx.kw, ctx.wt
+        if dy is None:
+            return None, None, None, None, None, None, None
         dy = dy.contiguous()
         B, H, W = kw["B"], kw["H"], kw["W"]
         Hs, Ws = kw.get("Hs") or H, kw.get("Ws") or W
@@ -100,7 +113,11 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
         raise NotImplementedError("the K-extended GEMM (skip=) is an inference kernel; differentiate the two layers separately")
     if kw.get("ln") is not None:
         raise NotImplementedError("the LayerNorm-folded GEMM is an inference kernel; differentiate layer_norm + gemm_conv")
-    if kw.pop("want_stats", False) or kw.pop("want_gn_stats", False):   # epilogue statistics feed inference-only fusions
+    if kw.pop("want_stats", False):                                     # row statistics feed the LayerNorm fold: inference only
+        kw.pop("want_gn_stats", None)
+        return gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw), None
+    if kw.get("want_gn_stats") and (kw.get("geglu") or kw.get("gelu") or kw.get("out") is not None):
+        kw.pop("want_gn_stats")
         return gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw), None
     if rowvec is not None and rowvec.requires_grad:
         raise NotImplementedError("gradient w.r.t. the time embedding is not produced (nothing trainable sits upstream of it)")
@@ -108,6 +125,11 @@ def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
         raise ValueError("out= is not supported while autograd is recording")
     if kw.get("gelu"):
         raise NotImplementedError("the plain-GELU epilogue (text tower) has no backward; differentiate the PyTorch module instead")
+    if kw.get("want_gn_stats"):
+        meta = kw["_gs_meta"] = []
+        y, part, gp = _GemmConv.apply(x1, x2, resid, wt, bias, rowvec, kw)
+        return y, (None if part is None else (part, meta[0], gp, meta[1]))
+    kw.pop("want_gn_stats", None)
     return _GemmConv.apply(x1, x2, resid, wt, bias, rowvec, kw)
 
 
@@ -139,66 +161,119 @@ def sumpool2x2(x, N, H, W):
 
 
 class _GroupNorm(torch.autograd.Function):
+    """GroupNorm(32)(+SiLU) over the virtual concat [x1 | x2].
+    stats: None (statistics pass), ("groups", gp [N, chunks, 32, 2], chunks) = per-group sums of x1 out of its producer's epilogue,
+           or ("channels", gs1, gs2) = per-channel row-block partials of the source(s), reduced by lr_groupnorm_finalize.
+    fork: also return x1 (and x2) as outputs -- the caller routes the residual branch (`x + f(GroupNorm(x))`, or the ResBlock's
+          skip_connection) through them, so its gradient arrives HERE and is added inside the backward kernel (lr_groupnorm_bwd_res)
+          instead of by a separate fan-in add of torch.autograd."""
+
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, N, HW, eps, silu):
+    def forward(ctx, x1, x2, gamma, beta, N, HW, eps, silu, stats, fork):
+        ctx.set_materialize_grads(False)      # an unused fork output arrives as None, not as a tensor of zeros
         lib = _lib.load()
         C1 = x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
-        partials = torch.empty(N * ops.GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
         y = torch.empty(N * HW, C1 + C2, device=x1.device, dtype=x1.dtype)
         st = _stream()
-        _lib.check(_lib.fn(lib, "lr_groupnorm_stats", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
-        _lib.check(_lib.fn(lib, "lr_groupnorm_apply", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta), float(eps),
-                                          int(bool(silu)), _p(y), st), "groupnorm_apply")
+        if stats is None:
+            partials, chunks = torch.empty(N * ops.GN_CHUNKS * 64, device=x1.device, dtype=torch.float32), 0
+            _lib.check(_lib.fn(lib, "lr_groupnorm_stats", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), st), "groupnorm_stats")
+        elif stats[0] == "groups":
+            assert x2 is None
+            partials, chunks = stats[1], stats[2]
+            assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape == (N, chunks, 32, 2)
+        else:
+            gs1, gs2 = stats[1], stats[2]
+            p1, r1 = gs1[:2]
+            p2, r2 = gs2[:2] if x2 is not None else (None, 1)
+            assert p1.shape == (N * HW // r1, C1, 2) and HW % r1 == 0 and (x2 is None or (p2.shape == (N * HW // r2, C2, 2) and HW % r2 == 0))
+            partials, chunks = torch.empty(N * 64, device=x1.device, dtype=torch.float32), 1
+            _lib.check(lib.lr_groupnorm_finalize(_p(p1), C1, r1, _p(p2), C2, r2, N, HW, _p(partials), st), "groupnorm_finalize")
+        if chunks == 0:
+            _lib.check(_lib.fn(lib, "lr_groupnorm_apply", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), _p(gamma), _p(beta),
+                                                                  float(eps), int(bool(silu)), _p(y), st), "groupnorm_apply")
+        else:
+            _lib.check(_lib.fn(lib, "lr_groupnorm_apply_n", x1.dtype)(_p(x1), C1, _p(x2), C2, N, HW, _p(partials), chunks, _p(gamma),
+                                                                    _p(beta), float(eps), int(bool(silu)), _p(y), st), "groupnorm_apply_n")
         ctx.save_for_backward(x1, x2, gamma, beta, partials)
-        ctx.meta = (N, HW, float(eps), int(bool(silu)))
+        ctx.meta = (N, HW, float(eps), int(bool(silu)), chunks)
+        if fork:
+            return y, x1, x2
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d1=None, d2=None):
         lib = _lib.load()
         x1, x2, gamma, beta, partials = ctx.saved_tensors
-        N, HW, eps, silu = ctx.meta
-        dy = dy.contiguous()
+        N, HW, eps, silu, chunks = ctx.meta
         C1 = x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
-        scratch = torch.empty_like(partials)
+        if dy is None:      # only the residual branch carries a gradient
+            return d1, d2, None, None, None, None, None, None, None, None
+        dy = dy.contiguous()
+        d1 = None if d1 is None else d1.contiguous()
+        d2 = None if d2 is None else d2.contiguous()
+        scratch = torch.empty(N * ops.GN_CHUNKS * 64, device=x1.device, dtype=torch.float32)
         dx1 = torch.empty_like(x1)
         dx2 = None if x2 is None else torch.empty_like(x2)
-        _lib.check(_lib.fn(lib, "lr_groupnorm_bwd", x1.dtype)(_p(x1), C1, _p(x2), C2, _p(dy), N, HW, _p(partials), _p(gamma), _p(beta), eps, silu,
-                                        _p(scratch), _p(dx1), _p(dx2), _stream()), "groupnorm_bwd")
-        return dx1, dx2, None, None, None, None, None, None
+        _lib.check(_lib.fn(lib, "lr_groupnorm_bwd_res", x1.dtype)(_p(x1), C1, _p(x2), C2, _p(dy), _p(d1), _p(d2), N, HW, _p(partials), chunks,
+                                                                _p(gamma), _p(beta), eps, silu, _p(scratch), _p(dx1), _p(dx2), _stream()),
+                   "groupnorm_bwd_res")
+        return dx1, dx2, None, None, None, None, None, None, None, None
 
 
-def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None):
+def group_norm(x1, N, HW, gamma, beta, eps, silu, x2=None, stats=None):
     if not _needs_grad(x1, x2):
+        assert stats is None
         return ops.group_norm(x1, N, HW, gamma, beta, eps, silu, x2)
-    return _GroupNorm.apply(x1.contiguous(), None if x2 is None else x2.contiguous(), gamma, beta, N, HW, eps, silu)
+    return _GroupNorm.apply(x1.contiguous(), None if x2 is None else x2.contiguous(), gamma, beta, N, HW, eps, silu, stats, False)
+
+
+def group_norm_fork(x1, N, HW, gamma, beta, eps, silu, x2=None, stats=None):
+    """(GroupNorm(...), x1', x2'): x1' / x2' are x1 / x2 for the residual branch around the GroupNorm (see _GroupNorm)."""
+    assert _needs_grad(x1, x2)
+    return _GroupNorm.apply(x1.contiguous(), None if x2 is None else x2.contiguous(), gamma, beta, N, HW, eps, silu, stats, True)
 
 
 class _LayerNorm(torch.autograd.Function):
+    """fork: also return x as an output -- the residual `x + f(LayerNorm(x))` is taken from it, so the residual branch's gradient is
+    added inside the backward kernel (lr_layernorm_bwd_res) instead of by a separate fan-in add of torch.autograd."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork):
+        ctx.set_materialize_grads(False)
         y = ops.layer_norm(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma)
         ctx.eps = float(eps)
-        return y
+        return (y, x) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         lib = _lib.load()
         x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None
         dy = dy.contiguous()
+        dres = None if dres is None else dres.contiguous()
         dx = torch.empty_like(x)
         M, C = x.shape
-        _lib.check(_lib.fn(lib, "lr_layernorm_bwd", x.dtype)(_p(x), _p(dy), _p(gamma), ctx.eps, _p(dx), M, C, _stream()), "layernorm_bwd")
-        return dx, None, None, None
+        _lib.check(_lib.fn(lib, "lr_layernorm_bwd_res", x.dtype)(_p(x), _p(dy), _p(dres), _p(gamma), ctx.eps, _p(dx), M, C, _stream()),
+                   "layernorm_bwd_res")
+        return dx, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     if not _needs_grad(x):
         return ops.layer_norm(x, gamma, beta, eps)
-    return _LayerNorm.apply(x.contiguous(), gamma, beta, eps)
+    return _LayerNorm.apply(x.contiguous(), gamma, beta, eps, False)
+
+
+def layer_norm_fork(x, gamma, beta, eps=1e-5):
+    """(LayerNorm(x), x'): use x' for the residual add behind the branch (see _LayerNorm); plain (LayerNorm(x), x) without autograd."""
+    if not _needs_grad(x):
+        return ops.layer_norm(x, gamma, beta, eps), x
+    return _LayerNorm.apply(x.contiguous(), gamma, beta, eps, True)
 
 
 class _ToNCHW(torch.autograd.Function):
@@ -225,16 +300,13 @@ def _attention_backward(q, k, v, out, lse, dout, meta, dq, dk, dv):
     lib = _lib.load()
     B, heads, Nq, Nkv, scale = meta
     dout = dout.contiguous()
-    qt = ops.transpose_v(q, B, heads, Nq)
-    kt = ops.transpose_v(k, B, heads, Nkv)
-    dot = ops.transpose_v(dout, B, heads, Nq)
     dsum = torch.empty_like(lse)
     a = AttnBwdArgs()
     a.q, a.k, a.v, a.o, a.dout = _p(q), _p(k), _p(v), _p(out), _p(dout)
-    a.qt, a.kt, a.dot, a.lse, a.dsum = _p(qt), _p(kt), _p(dot), _p(lse), _p(dsum)
+    a.qt, a.kt, a.dot, a.lse, a.dsum = 0, 0, 0, _p(lse), _p(dsum)       # (no transposed copies since ABI 25: LDS transpose reads)
     a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
     a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
-    a.ld_qt, a.ld_kt = qt.shape[2], kt.shape[2]
+    a.ld_qt, a.ld_kt = 0, 0
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
     _lib.check(_lib.fn(lib, "lr_attention_bwd_f16", q.dtype)(a, _stream()), "attention_bwd")
@@ -311,6 +383,43 @@ class _AttentionQ_KV(torch.autograd.Function):
         return dq, dkv, None, None, None, None, None
 
 
+class _SplitCols(torch.autograd.Function):
+    """x [M, sum sizes] -> column-slice views; the backward concatenates the slices' gradients (ONE copy launch) instead of
+    scattering each of them into a zero tensor of the full width and summing those."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.rows = tuple(sizes), x.shape[0]
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(x[:, off:off + n])
+            off += n
+        assert off == x.shape[1]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros(ctx.rows, n) for g, n in zip(grads, ctx.sizes)]
+        return torch.cat(parts, dim=1), None
+
+
+def split_cols(x, sizes):
+    if not _needs_grad(x):
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(x[:, off:off + n])
+            off += n
+        return tuple(outs)
+    return _SplitCols.apply(x, tuple(sizes))
+
+
+def _rows_ok(t):
+    """[rows, cols] with unit column stride and 16-byte aligned rows (a column slice of a wider buffer): the attention kernels take it as is."""
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
 def attention(q, k, v, B, heads, Nq, Nkv, scale, out=None, vt=None):
     if not _needs_grad(q, k, v):
         return ops.attention(q, k, v, B, heads, Nq, Nkv, scale, out=out, vt=vt)
@@ -326,7 +435,7 @@ def attention_qkv(qkv, B, heads, L, scale):
 def attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=None):
     if not _needs_grad(q, kv):
         return ops.attention_q_kv(q, kv, B, heads, Nq, Nkv, scale, vt=vt)
-    return _AttentionQ_KV.apply(q.contiguous(), kv.contiguous(), B, heads, Nq, Nkv, scale)
+    return _AttentionQ_KV.apply(q.contiguous(), kv if _rows_ok(kv) else kv.contiguous(), B, heads, Nq, Nkv, scale)
 
 
 class _MvGather(torch.autograd.Function):

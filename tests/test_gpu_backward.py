@@ -77,6 +77,87 @@ def test_groupnorm_backward(N, C1, C2, H, W, silu, eps):
         check(f"groupnorm {tag} dx2", from_tok(x2.grad, N, H, W), xr.grad[:, C1:])
 
 
+@pytest.mark.parametrize("M,C", [(300, 320), (130, 1280)])
+def test_layernorm_fork_backward(M, C):
+    """x + f(LayerNorm(x)) with the residual taken from the fork's second output: ONE backward kernel adds the residual branch's
+    gradient in fp32 (lr_layernorm_bwd_res), the result is the autograd gradient of the same expression."""
+    from leftrefill_amd import train_ops as T
+    x = h16(G.T(f"lnf.x{C}", (M, C)))
+    dy = h16(G.T(f"lnf.dy{C}", (M, C)))
+    g = torch.from_numpy(weights.fill_like(f"lnf.{C}.weight", (C,)))
+    b = torch.from_numpy(weights.fill_like(f"lnf.{C}.bias", (C,)))
+    xr = x.clone().requires_grad_(True)
+    (2.0 * F.layer_norm(xr, (C,), g, b, 1e-5) + xr).backward(dy)
+    xd = x.half().to(dev()).requires_grad_(True)
+    n, xa = T.layer_norm_fork(xd, g.to(dev()), b.to(dev()), 1e-5)
+    (2.0 * n + xa).backward(dy.half().to(dev()))
+    check(f"layernorm fork {M}x{C}", xd.grad, xr.grad)
+    # the fork's second output alone (the normalised branch unused) passes its gradient through
+    xd2 = x.half().to(dev()).requires_grad_(True)
+    _, xa2 = T.layer_norm_fork(xd2, g.to(dev()), b.to(dev()), 1e-5)
+    xa2.backward(dy.half().to(dev()))
+    assert torch.equal(xd2.grad, dy.half().to(dev()))
+
+
+@pytest.mark.parametrize("N,C1,C2,H,W,silu,eps", [(2, 320, 0, 8, 16, True, 1e-5), (1, 640, 320, 16, 8, True, 1e-5),
+                                                   (2, 320, 0, 16, 16, False, 1e-6)])
+def test_groupnorm_fork_backward(N, C1, C2, H, W, silu, eps):
+    """f(GroupNorm([x1 | x2])) + [x1 | x2] through the fork: the residual gradients of both sources join inside lr_groupnorm_bwd_res."""
+    from leftrefill_amd import train_ops as T
+    C = C1 + C2
+    tag = f"gnf.{C1}.{C2}.{H}"
+    x = h16(G.T(tag + ".x", (N, C, H, W)))
+    dy = h16(G.T(tag + ".dy", (N, C, H, W)))
+    g = torch.from_numpy(weights.fill_like(tag + ".weight", (C,)))
+    b = torch.from_numpy(weights.fill_like(tag + ".bias", (C,)))
+    xr = x.clone().requires_grad_(True)
+    y = F.group_norm(xr, 32, g, b, eps)
+    ((F.silu(y) if silu else y) + 0.5 * xr).backward(dy)
+    x1 = to_tok(x[:, :C1]).requires_grad_(True)
+    x2 = to_tok(x[:, C1:]).requires_grad_(True) if C2 else None
+    out, a1, a2 = T.group_norm_fork(x1, N, H * W, g.to(dev()), b.to(dev()), eps, silu, x2)
+    res = 0.5 * (a1 if a2 is None else torch.cat([a1, a2], dim=1))
+    (out + res).backward(to_tok(dy))
+    check(f"groupnorm fork {tag} dx1", from_tok(x1.grad, N, H, W), xr.grad[:, :C1])
+    if C2:
+        check(f"groupnorm fork {tag} dx2", from_tok(x2.grad, N, H, W), xr.grad[:, C1:])
+
+
+@pytest.mark.parametrize("N,Cin,C,H,W,cat", [(2, 320, 320, 16, 16, False), (1, 640, 640, 32, 16, False), (2, 320, 320, 16, 16, True)])
+def test_groupnorm_backward_with_producer_statistics(N, Cin, C, H, W, cat):
+    """The differentiable forward takes the GroupNorm statistics out of the producing conv's epilogue (per-group sums, or per-channel
+    partials + finalize for a virtual concat): conv -> GroupNorm + SiLU differentiated against torch.autograd on the same function."""
+    from leftrefill_amd import engine as E, packing, train_ops as T
+    tag = f"gnp.{Cin}.{C}.{H}.{int(cat)}"
+    x = h16(G.T(tag + ".x", (N, Cin, H, W)))
+    w = h16(torch.from_numpy(weights.fill_like(tag + ".w", (C, Cin, 3, 3))))
+    bb = torch.from_numpy(weights.fill_like(tag + ".b", (C,)))
+    Cn = 2 * C if cat else C
+    g = torch.from_numpy(weights.fill_like(tag + ".weight", (Cn,)))
+    b = torch.from_numpy(weights.fill_like(tag + ".bias", (Cn,)))
+    dy = h16(G.T(tag + ".dy", (N, Cn, H, W)))
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, bb, padding=1)
+    yr = torch.cat([yr, 0.5 * yr], 1) if cat else yr
+    F.silu(F.group_norm(h16(yr.detach()) + (yr - yr.detach()), 32, g, b, 1e-5)).backward(dy)      # (the HIP side normalises the rounded conv output)
+    wp = packing.pack_conv(w, cin_pad=Cin).to(dev())
+    bp = packing.pack_bias(bb).to(dev())
+    x1 = to_tok(x).requires_grad_(True)
+    y1, gs1 = T.gemm_conv(x1, wp, B=N, H=H, W=W, taps=9, bias=bp, want_gn_stats=True)
+    assert gs1 is not None and y1.requires_grad and not gs1[0].requires_grad
+    if cat:
+        y2, gs2 = T.gemm_conv(x1, (0.5 * wp.float()).half(), B=N, H=H, W=W, taps=9, bias=0.5 * bp, want_gn_stats=True)
+        act = E.Act(y1, N, H, W, tok2=y2, gs=gs1, gs2=gs2)
+    else:
+        act = E.Act(y1, N, H, W, gs=gs1)
+    st = E._gn_train_stats(act)
+    assert st is not None and st[0] == ("channels" if cat else "groups")
+    pn = type("PN", (), {"g": g.to(dev()), "b": b.to(dev()), "eps": 1e-5})()
+    out = E.gn(act, pn, True)      # (goes through train_ops: the inputs require grad)
+    out.tok.backward(to_tok(dy))
+    check(f"conv -> groupnorm (producer statistics) {tag} dx", from_tok(x1.grad, N, H, W), xr.grad, rtol=4e-3, atol_scale=4e-3)
+
+
 def _conv_bwd_case(name, N, Cin, Cout, H, W, taps=9, stride=1, up=0, C2=0, resid=False):
     from leftrefill_amd import packing, train_ops as T
     Ct = Cin + C2
