@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leftrefill_amd import ops  # noqa: E402
 
 
+GRAPH = False
+
+
 def run(M, N, K, taps, tm, tn, splits, reps, geglu=False, pipe=0):
     dev = torch.device("cuda:0")
     C = K // taps
@@ -32,6 +35,24 @@ def run(M, N, K, taps, tm, tn, splits, reps, geglu=False, pipe=0):
         f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if GRAPH:      # the launches replayed from a hipGraph: GPU time without the host's per-call cost (~15 us through ctypes)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            f()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                f()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        return us, 2.0 * M * N * K / us / 1e6
     e0.record()
     for _ in range(reps):
         f()
@@ -46,7 +67,9 @@ if __name__ == "__main__":
     ap.add_argument("dims", type=int, nargs="+")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--geglu", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="time a hipGraph of the launches (no host cost per call)")
     a = ap.parse_args()
+    GRAPH = a.graph
     M, N, K, taps = a.dims[:4]
     ops.AUTOTUNE = False
     if len(a.dims) >= 6:
