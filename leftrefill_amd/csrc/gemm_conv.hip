@@ -85,6 +85,7 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const int cpt = (P.C1 + P.C2) >> 6;   // 64-channel chunks per tap
   const int cpt1 = P.C1 >> 6;
   const int nk_main = P.taps * cpt;
+  [[maybe_unused]] const bool simple = P.taps == 1 && P.p2 == nullptr && P.C3 + P.C4 == 0;      // block-uniform (kernel arguments)
   const int cpt3 = P.C3 >> 6;           // K-steps of the pointwise extension (GemmParams.p3 / p4) behind the taps
   const int nk_all = nk_main + ((P.C3 + P.C4) >> 6);
   const int k_per = (nk_all + P.splits - 1) / P.splits;
@@ -111,11 +112,25 @@ __global__ __launch_bounds__(GEMM_THREADS, BN == 64 ? 4 : BN == 128 ? 3 : 2) voi
   const unsigned kstep_bytes = P.wt_pm ? (unsigned)P.N * 128u : 128u;
   unsigned avo[4] = {OOB, OOB, OOB, OOB};
   int seg_tap = -1, seg_src = -1;
+  [[maybe_unused]] int pk_kt = -2, pk_tap = 0, pk_cc = 0;      // (tap, chunk) of the last K-step staged
   auto stage = [&](int buf, int kt) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
     int tap, cc, srcsel;
-    if (kt < nk_main) { tap = kt / cpt; cc = kt - tap * cpt; srcsel = cc < cpt1 ? 0 : 1; }
+#ifdef LR_GEMM_NO_PREP     // timing-decomposition build: no per-step bookkeeping at all (pointwise single-source shapes only)
+    tap = 0; cc = kt; srcsel = 0;
+    if (false) {}
+#else
+    if (simple) { tap = 0; cc = kt; srcsel = 0; }      // pointwise, one source: K-step kt is channel chunk kt (no tap / source arithmetic)
+#endif
+    else if (kt < nk_main) {
+      // K-steps arrive in order: the (tap, chunk) pair is advanced, not divided out (the scalar division sat on every wave's path
+      // once per K-step, between the barrier and the next fragment reads)
+      if (kt == pk_kt + 1) { if (++pk_cc == cpt) { pk_cc = 0; ++pk_tap; } }
+      else { pk_tap = kt / cpt; pk_cc = kt - pk_tap * cpt; }
+      pk_kt = kt;
+      tap = pk_tap; cc = pk_cc; srcsel = cc < cpt1 ? 0 : 1;
+    }
     else { tap = 16; cc = kt - nk_main; srcsel = cc < cpt3 ? 2 : 3; }      // pointwise extension: tap (0, 0) of sources 3 / 4
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform: new tap or crossing a source boundary
       seg_tap = tap; seg_src = srcsel;
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   // source changes
   unsigned avo[NA];
   int seg_tap = -1, seg_src = -1;
+  [[maybe_unused]] int pk_kt = -2, pk_tap = 0, pk_cc = 0;      // (tap, chunk) of the last K-step staged
   // descriptors of the current A segment and of the weights (zero-length for a stage past the end of K); rebuilt from
   // the kernel arguments when the segment / tile changes instead of holding 4 SGPRs per operand
   __amdgpu_buffer_rsrc_t rsA = uniform_rsrc((const void*)P.wt, 0), rsB = rsA;
@@ -303,6 +319,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   const int cpt = P.c16 ? 1 : (P.C1 + P.C2) >> 6;
   const int cpt1 = P.c16 ? 1 : P.C1 >> 6;
   const int nk_main = P.c16 ? 3 : P.taps * cpt;
+  [[maybe_unused]] const bool simple = P.taps == 1 && !P.c16 && P.p2 == nullptr && P.C3 + P.C4 == 0;      // block-uniform (kernel arguments)
   const int cpt3 = P.C3 >> 6;                           // K-steps of the pointwise extension (GemmParams.p3 / p4): source 3, then 4
   const int nk_all = nk_main + ((P.C3 + P.C4) >> 6);
   const int k_per = (nk_all + P.splits - 1) / P.splits;
@@ -351,7 +368,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
       koff = (unsigned)kt * (P.wt_pm ? (unsigned)P.N * 128u : 128u);
     } else {
     int tap, cc, srcsel;
-    if (kt < nk_main) { tap = kt / cpt; cc = kt - tap * cpt; srcsel = cc < cpt1 ? 0 : 1; }
+#ifdef LR_GEMM_NO_PREP     // timing-decomposition build: no per-step bookkeeping at all (pointwise single-source shapes only)
+    tap = 0; cc = kt; srcsel = 0;
+    if (false) {}
+#else
+    if (simple) { tap = 0; cc = kt; srcsel = 0; }      // pointwise, one source: K-step kt is channel chunk kt (no tap / source arithmetic)
+#endif
+    else if (kt < nk_main) {
+      // K-steps arrive in order: the (tap, chunk) pair is advanced, not divided out (the scalar division sat on every wave's path
+      // once per K-step, between the barrier and the next fragment reads)
+      if (kt == pk_kt + 1) { if (++pk_cc == cpt) { pk_cc = 0; ++pk_tap; } }
+      else { pk_tap = kt / cpt; pk_cc = kt - pk_tap * cpt; }
+      pk_kt = kt;
+      tap = pk_tap; cc = pk_cc; srcsel = cc < cpt1 ? 0 : 1;
+    }
     else { tap = 16; cc = kt - nk_main; srcsel = cc < cpt3 ? 2 : 3; }      // pointwise extension: tap (0, 0) of sources 3 / 4
     if (tap != seg_tap || srcsel != seg_src) {      // wave-uniform
       seg_tap = tap; seg_src = srcsel;
@@ -386,6 +416,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
   auto stage_issue = [&](int buf) __attribute__((always_inline)) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
+#ifdef LR_GEMM_NO_DMA      // timing-decomposition build (tools/sweep_decomp.sh): no operand traffic, the loop multiplies whatever the LDS holds
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ((i * NW + w) * 8) * 128), 16, avo[i], coff, 0, 0);
@@ -406,6 +439,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
     const char* As = smem + buf * STAGE;
     const char* Bs = As + A_BYTES;
     const int kc = ks * 4 + fq;
+#ifdef LR_GEMM_NO_READS    // timing-decomposition build: fragments from registers (no ds_read traffic)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[i][e] = (T)(float)(buf + ks + i);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[j][e] = (T)(float)(buf - ks + j);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * (TM * 16) + i * 16 + fr;
@@ -421,11 +465,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_conv_pipe_kernel(const GemmParam
 #ifdef LR_GEMM_SETPRIO      // developer A/B build: raise the wave's priority over its SIMD partner while it issues matrix work
     __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef LR_GEMM_NO_MFMA     // timing-decomposition build: the fragments are consumed by one VALU add per accumulator tile instead of an MFMA
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[j][i][0] += (float)wf[j][0] + (float)xf[i][0];
+#else
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         acc[j][i] = lr_mfma16(wf[j], xf[i], acc[j][i]);
+#endif
 #ifdef LR_GEMM_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
