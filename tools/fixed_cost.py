@@ -1,5 +1,5 @@
 """Fixed cost of a launch per kernel_table row: the same (M, N, tile plan) with ONE K-step (K = 64, pointwise), i.e. launch + pipeline
-fill + the epilogue's residual read / store -- the third term of tools/floor_table.py.  MI355X.
+fill + the epilogue's residual read / store -- the third term of tools/floor_table.py.  MI355X.  Timed as hipGraph replays (GPU side only).
 
     python tools/fixed_cost.py BENCH.json > profiles/r06_fixed_cost.json
 
@@ -17,14 +17,26 @@ from tools.floor_table import load_line  # noqa: E402
 
 
 def timed(fn, n=20):
+    """us per launch of n launches replayed from ONE hipGraph: the GPU-side cost.  (Round 6's first table timed eager launches: ~10 us per
+    row, most of it the host's ctypes call -- the same launches replay in 5.6-7.5 us.)"""
     fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n):
-            fn()
+        g.replay()
         e1.record()
         e1.synchronize()
         best = min(best, 1e3 * e0.elapsed_time(e1) / n)
