@@ -13,6 +13,8 @@ from leftrefill_amd import ops  # noqa: E402
 
 
 GRAPH = False
+COLD = 0
+COLD_X = False
 
 
 def run(M, N, K, taps, tm, tn, splits, reps, geglu=False, pipe=0):
@@ -29,8 +31,18 @@ def run(M, N, K, taps, tm, tn, splits, reps, geglu=False, pipe=0):
     w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     b = torch.randn(N, device=dev)
     out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=torch.float16)
-    f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits,
-                              geglu=geglu, pipe=pipe)
+    if COLD > 1:      # COLD distinct weight (and input) copies, visited in turn: every launch streams its weights from HBM like a layer of the step
+        ws = [w.clone() for _ in range(COLD)]
+        xs = [x.clone() for _ in range(COLD if COLD_X else 1)]
+        cnt = [0]
+
+        def f():
+            i = cnt[0] % COLD
+            cnt[0] += 1
+            return ops.gemm_conv(xs[i % len(xs)], ws[i], B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits, geglu=geglu, pipe=pipe)
+    else:
+        f = lambda: ops.gemm_conv(x, w, B=B, H=Hh, W=W, taps=taps, bias=b, out=out, tile_m=tm, tile_n=tn, splits=splits,
+                                  geglu=geglu, pipe=pipe)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
@@ -68,8 +80,11 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--geglu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="time a hipGraph of the launches (no host cost per call)")
+    ap.add_argument("--cold", type=int, default=0, help="cycle through this many weight copies (> cache capacity: every launch reads HBM)")
+    ap.add_argument("--cold-x", action="store_true", help="... and as many input copies")
     a = ap.parse_args()
     GRAPH = a.graph
+    COLD, COLD_X = a.cold, a.cold_x
     M, N, K, taps = a.dims[:4]
     ops.AUTOTUNE = False
     if len(a.dims) >= 6:

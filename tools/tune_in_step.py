@@ -95,20 +95,46 @@ def main():
     ap.add_argument("--greedy-keys", type=int, default=30)
     ap.add_argument("--greedy-cands", type=int, default=3)
     ap.add_argument("--accept-ms", type=float, default=0.015)
-    ap.add_argument("--workload", default="single", choices=["single", "mv5"])
+    ap.add_argument("--workload", default="single", choices=["single", "mv5", "train"],
+                    help="train: one eager training step of configs[4] (bf16, batch 16 at 256x512: forward + input-gradient backward); first phase only")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table_instep.json"))
     a = ap.parse_args()
     device = torch.device("cuda:0")
-    model = bench.build_model(device, a.workload)
-    unet = model.model.diffusion_model
-    B = a.batch
-    c_concat, c_cross, uc_cross, x_T = bench.synthetic_batch(B, 64, 128, device, 7)
-    x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
-    t = torch.full((2 * B,), 501, device=device, dtype=torch.long)
-    ctx = torch.cat([uc_cross, c_cross]).half()
+    train_step = None
+    if a.workload == "train":
+        # the step of bench.train_bench (NVS task model, prompt tokens trainable, bf16) without the optimizer: the GEMM launches of the
+        # forward and of the input-gradient backward, in the order and cache state the training step runs them
+        model = bench.build_model(device, "nvs").train()
+        unet = model.model.diffusion_model
+        unet.compute_dtype = torch.bfloat16
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        g = torch.Generator(device=device).manual_seed(1099)
+        tokens = torch.nn.Parameter(0.02 * torch.randn(73, 1024, device=device, generator=g))
+        base_ctx = torch.randn(16, 77, 1024, device=device, generator=g)
+        c_cat = torch.randn(16, 5, 32, 64, device=device, generator=g)
+        x_start = torch.randn(16, 4, 32, 64, device=device, generator=g)
+        noise = torch.randn(16, 4, 32, 64, device=device, generator=g)
+        t_buf = torch.randint(0, 1000, (16,), device=device, generator=g)
+
+        def train_step(install):
+            install()
+            ctx_ = torch.cat([base_ctx[:, :1], base_ctx[:, 1:74] + tokens, base_ctx[:, 74:]], dim=1)
+            loss, _ = model.p_losses(x_start, {"c_concat": [c_cat], "c_crossattn": [ctx_]}, t_buf, noise=noise)
+            loss.backward()
+            tokens.grad = None
+        x = t = ctx = None
+    else:
+        model = bench.build_model(device, a.workload)
+        unet = model.model.diffusion_model
+        B = a.batch
+        c_concat, c_cross, uc_cross, x_T = bench.synthetic_batch(B, 64, 128, device, 7)
+        x = torch.cat([torch.cat([x_T] * 2), torch.cat([c_concat] * 2)], dim=1)
+        t = torch.full((2 * B,), 501, device=device, dtype=torch.long)
+        ctx = torch.cat([uc_cross, c_cross]).half()
     unet.use_hip_graph = False
 
     events = []          # (key, e0, e1, plan)
@@ -129,8 +155,11 @@ def main():
         """one eager step -> {key: (total us, launches, resolved plan)}"""
         events.clear()
         ops.LAUNCH_HOOK = None
-        with torch.no_grad():
-            bench.eager_unet_step(unet, x, t, ctx, hook=lambda: setattr(ops, "LAUNCH_HOOK", hook))
+        if train_step is not None:
+            train_step(lambda: setattr(ops, "LAUNCH_HOOK", hook))
+        else:
+            with torch.no_grad():
+                bench.eager_unet_step(unet, x, t, ctx, hook=lambda: setattr(ops, "LAUNCH_HOOK", hook))
         torch.cuda.synchronize()
         ops.LAUNCH_HOOK = None
         res = defaultdict(lambda: [0.0, 0, None])
@@ -183,7 +212,7 @@ def main():
         fold_ref(run_pass())
         print(f"trial {j + 1}/{len(cands)} {cand} done", flush=True)
     ops.PLAN_TRIAL = None
-    if a.greedy:
+    if a.greedy and train_step is None:
         return greedy(a, unet, x, t, ctx, keys, base, per_cand)
     table = dict(ops.tile_cache())
     gain = 0.0
