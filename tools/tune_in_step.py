@@ -99,6 +99,7 @@ def main():
                     help="train: one eager training step of configs[4] (bf16, batch 16 at 256x512: forward + input-gradient backward); first phase only")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--splits", type=int, nargs="*", default=[], help="explicit split-K factors to try besides 1 and the heuristic's (e.g. 2 3 4 6 8)")
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table_instep.json"))
     a = ap.parse_args()
@@ -177,7 +178,7 @@ def main():
     print(f"{len(keys)} GEMM shapes, {sum(v[1] for v in base.values())} launches per step", flush=True)
     cands = []
     for tm, tn, stg in ops.TILE_CANDIDATES:
-        for sp in (1, 0):
+        for sp in (1, 0) + tuple(a.splits):
             cands.append((tm, tn, sp, stg))
     best_ref = {k: float("inf") for k in keys}                       # table plan: best of all reference passes
     best_trial = {k: (float("inf"), None) for k in keys}             # (us, resolved plan)
