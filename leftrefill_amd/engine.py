@@ -299,6 +299,10 @@ TRAIN_GN_STATS = __import__("os").environ.get("LEFTREFILL_TRAIN_GN_STATS", "1") 
 TRAIN_FORK = __import__("os").environ.get("LEFTREFILL_TRAIN_FORK", "1") != "0"
 
 
+# ... and the skip-extended last conv of a width-changing ResBlock in the differentiable forward; LEFTREFILL_TRAIN_SKIP_FUSED=0: two GEMMs + residual
+TRAIN_SKIP_FUSED = __import__("os").environ.get("LEFTREFILL_TRAIN_SKIP_FUSED", "1") != "0"
+
+
 def gn_stats_ok(x):
     """Producer-epilogue GroupNorm statistics: also in the differentiable forward (round 6) -- no gradient flows through the sums, the
     consuming GroupNorm's backward re-derives mean / rstd from them (train_ops._GroupNorm)."""
@@ -313,7 +317,7 @@ def forking(x):
     return TRAIN_FORK and training(x)
 
 
-def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False, skip=None):
+def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn_stats=False, skip=None, skip_parts=None):
     """3x3 pad-1 conv (stride 1|2, optional nearest-2x upsample; asym: pad bottom/right only) or 1x1 conv over an Act.
     gn_stats: the output feeds a GroupNorm -- let the epilogue produce its statistics (Act.gs).
     skip = (tok, tok2 | None): pointwise K extension (pc is a FusedSkipConv), see ops.gemm_conv."""
@@ -327,8 +331,9 @@ def conv(act: Act, pc: PackedConv, rowvec=None, resid=None, up=0, asym=False, gn
     else:
         H, W = act.H, act.W
     want = gn_stats and gn_stats_ok(act.tok) and pc.cout == pc.w.shape[0]
+    extra = {} if skip_parts is None else {"skip_parts": skip_parts}      # (training: the two layers of a skip-extended conv, for its backward)
     y = ops.gemm_conv(act.tok, pc.w, B=act.N, H=H, W=W, Hs=act.H, Ws=act.W, taps=pc.taps, stride=pc.stride, up=up,
-                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want, skip=skip)
+                      asym=asym, x2=act.tok2, bias=pc.b, rowvec=rowvec, resid=resid, want_gn_stats=want, skip=skip, **extra)
     y, gs = y if want else (y, None)
     return Act(y, act.N, H, W, gs=gs)
 
@@ -381,6 +386,10 @@ def resblock(act: Act, pr: PackedRes, emb_out):
     if pr.c2s is not None and SKIP_FUSED and gn_fuse_ok(act.tok) and gn_fuse_ok(h.tok) and (act.tok2 is None or gn_fuse_ok(act.tok2)):
         # inference: the 1x1 skip_connection of a width-changing block rides on the last conv's K loop (no separate GEMM, no residual pass)
         return conv(h, pr.c2s, gn_stats=True, skip=(act.tok, act.tok2))
+    if (pr.c2s is not None and SKIP_FUSED and TRAIN_SKIP_FUSED and (training(h.tok) or training(act.tok) or (act.tok2 is not None and training(act.tok2)))
+            and h.tok2 is None):
+        # training (round 6): the same one-launch form; its backward runs the 3x3 and the pointwise input-gradient GEMMs on the layers' own weights
+        return conv(h, pr.c2s, gn_stats=True, skip=(act.tok, act.tok2), skip_parts=(pr.c2.w, pr.skip.w))
     if pr.skip is not None:
         resid = conv(act, pr.skip).tok
     else:

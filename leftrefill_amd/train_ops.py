@@ -105,12 +105,65 @@ class _GemmConv(torch.autograd.Function):
         return dxs[0], dxs[1], dresid, None, None, None, None
 
 
-def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, **kw):
+class _ConvSkip(torch.autograd.Function):
+    """3x3 conv with the pointwise skip_connection riding on its K loop (lr_gemm_args.skip1: `skip_connection(x) + conv(h)` of a width-changing
+    ResBlock as ONE accumulation): the forward is the inference launch; the backward is three independent input-gradient GEMMs on the two
+    layers' own packed weights (d h: 3x3 dgrad; d s1 / d s2: pointwise dgrads on the row slices of the skip weight)."""
+
+    @staticmethod
+    def forward(ctx, h, s1, s2, wf, bias, w_main, w_skip, kw):
+        ctx.set_materialize_grads(False)
+        ctx.kw, ctx.w_main, ctx.w_skip = kw, w_main, w_skip
+        ctx.Cs1 = s1.shape[-1]
+        ctx.Cs2 = 0 if s2 is None else s2.shape[-1]
+        want = kw.pop("want_gn_stats", False)
+        meta = kw.pop("_gs_meta", None)
+        r = ops.gemm_conv(h, wf, bias=bias, skip=(s1, s2), want_gn_stats=want, **kw)
+        if not want:
+            return r
+        y, gs = r
+        if gs is None:
+            return y, None, None
+        meta[:] = [gs[1], gs[3]]
+        ctx.mark_non_differentiable(*[t for t in (gs[0], gs[2]) if t is not None])
+        return y, gs[0], gs[2]
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return (None,) * 8
+        kw = ctx.kw
+        dy = dy.contiguous()
+        B, H, W = kw["B"], kw["H"], kw["W"]
+        M = B * H * W
+        dh = ds1 = ds2 = None
+        if ctx.needs_input_grad[0]:
+            Ch = ctx.w_main.shape[1] // 9
+            dh = ops.gemm_conv(dy, dgrad_weight(ctx.w_main, 9, 0, Ch), B=B, H=H, W=W, taps=9)
+        if ctx.needs_input_grad[1]:
+            ds1 = ops.gemm_conv(dy, dgrad_weight(ctx.w_skip, 1, 0, ctx.Cs1), B=1, H=1, W=M, taps=1)
+        if ctx.Cs2 and ctx.needs_input_grad[2]:
+            ds2 = ops.gemm_conv(dy, dgrad_weight(ctx.w_skip, 1, ctx.Cs1, ctx.Cs1 + ctx.Cs2), B=1, H=1, W=M, taps=1)
+        return dh, ds1, ds2, None, None, None, None, None
+
+
+def gemm_conv(x1, wt, *, x2=None, bias=None, rowvec=None, resid=None, skip_parts=None, **kw):
+    """skip_parts = (packed 3x3 weight, packed pointwise skip weight): the two layers of a skip-extended conv (`skip=`) on their own -- what its
+    backward multiplies by; without them a skip-extended conv cannot be differentiated."""
     sk = kw.get("skip") or ()
     if not _needs_grad(x1, x2, resid, *[t for t in sk if t is not None]):
         return ops.gemm_conv(x1, wt, x2=x2, bias=bias, rowvec=rowvec, resid=resid, **kw)
     if sk:
-        raise NotImplementedError("the K-extended GEMM (skip=) is an inference kernel; differentiate the two layers separately")
+        if skip_parts is None or x2 is not None or rowvec is not None or resid is not None or kw.get("taps") != 9 or kw.get("stride", 1) != 1 or kw.get("up"):
+            raise NotImplementedError("a K-extended GEMM (skip=) is differentiable only as a plain 3x3 conv + pointwise skip with skip_parts=")
+        kw = dict(kw)
+        s1, s2 = kw.pop("skip")
+        if kw.get("want_gn_stats"):
+            meta = kw["_gs_meta"] = []
+            y, part, gp = _ConvSkip.apply(x1, s1, s2, wt, bias, skip_parts[0], skip_parts[1], kw)
+            return y, (None if part is None else (part, meta[0], gp, meta[1]))
+        kw.pop("want_gn_stats", None)
+        return _ConvSkip.apply(x1, s1, s2, wt, bias, skip_parts[0], skip_parts[1], kw)
     if kw.get("ln") is not None:
         raise NotImplementedError("the LayerNorm-folded GEMM is an inference kernel; differentiate layer_norm + gemm_conv")
     if kw.pop("want_stats", False):                                     # row statistics feed the LayerNorm fold: inference only

@@ -204,6 +204,39 @@ def test_conv_linear_input_gradients():
     _conv_bwd_case("cb_out", 2, 320, 64, 8, 16)          # padded output conv (4 -> 64 channels)
 
 
+@pytest.mark.parametrize("N,Ch,C1,C2,Cout,H,W", [(2, 640, 320, 0, 640, 16, 16), (1, 320, 640, 320, 320, 16, 32)])
+def test_skip_extended_conv_backward(N, Ch, C1, C2, Cout, H, W):
+    """conv3x3(h) + skip_connection([s1 | s2]) as ONE launch in the differentiable forward (lr_gemm_args.skip1); the backward multiplies dY by
+    the two layers' own weights: dh, ds1, ds2 against torch.autograd of the two-conv formulation."""
+    from leftrefill_amd import packing, train_ops as T
+    tag = f"csk.{Ch}.{C1}.{C2}.{Cout}"
+    h = h16(G.T(tag + ".h", (N, Ch, H, W)))
+    sx = h16(G.T(tag + ".s", (N, C1 + C2, H, W)))
+    w3 = h16(torch.from_numpy(weights.fill_like(tag + ".w3", (Cout, Ch, 3, 3))))
+    w1 = h16(torch.from_numpy(weights.fill_like(tag + ".w1", (Cout, C1 + C2, 1, 1))))
+    b3 = torch.from_numpy(weights.fill_like(tag + ".b3", (Cout,)))
+    b1 = torch.from_numpy(weights.fill_like(tag + ".b1", (Cout,)))
+    dy = h16(G.T(tag + ".dy", (N, Cout, H, W)))
+    hr, sr = h.clone().requires_grad_(True), sx.clone().requires_grad_(True)
+    yr = F.conv2d(hr, w3, b3, padding=1) + F.conv2d(sr, w1, b1)
+    yr.backward(dy)
+    wp3 = packing.pack_conv(w3, cin_pad=Ch).to(dev())
+    wp1 = packing.pack_conv(w1, cin_pad=C1 + C2).to(dev())
+    wf = torch.cat([wp3, wp1], dim=1).contiguous()
+    bf = (packing.pack_bias(b3) + packing.pack_bias(b1)).to(dev())
+    hd = to_tok(h).requires_grad_(True)
+    s1 = to_tok(sx[:, :C1]).requires_grad_(True)
+    s2 = to_tok(sx[:, C1:]).requires_grad_(True) if C2 else None
+    y, gs = T.gemm_conv(hd, wf, B=N, H=H, W=W, taps=9, bias=bf, skip=(s1, s2), skip_parts=(wp3, wp1), want_gn_stats=True)
+    check(tag + " forward", from_tok(y.detach(), N, H, W), yr.detach(), rtol=3e-3, atol_scale=3e-3)
+    assert gs is not None and not gs[0].requires_grad
+    y.backward(to_tok(dy))
+    check(tag + " dh", from_tok(hd.grad, N, H, W), hr.grad)
+    check(tag + " ds1", from_tok(s1.grad, N, H, W), sr.grad[:, :C1])
+    if C2:
+        check(tag + " ds2", from_tok(s2.grad, N, H, W), sr.grad[:, C1:])
+
+
 def test_geglu_backward():
     from leftrefill_amd import packing, train_ops as T
     C, M = 320, 200
