@@ -651,3 +651,28 @@ def test_bench_dist_selftest_gloo_world2(fail):
         else:
             assert not st["ok"] and st["failed_stage"] == fail and "forced failure" in st["stages"][fail]["error"]
             assert st["stages"]["all_gather_into_tensor_f16"]["ok"]
+
+
+def test_split_cols_backward_is_one_concatenation():
+    """train_ops.split_cols (the per-block slices of the batched context K|V projection): column-slice views forward, the gradient of the wide
+    tensor is the concatenation of the slices' gradients; an unused slice contributes zeros.  Pure torch: runs on CPU."""
+    import torch
+    from leftrefill_amd import train_ops as T
+    x = torch.randn(5, 12, requires_grad=True)
+    a, b, c = T.split_cols(x, [4, 2, 6])
+    assert a.shape == (5, 4) and b.shape == (5, 2) and c.shape == (5, 6)
+    assert a.data_ptr() == x.data_ptr() and c.stride(0) == 12      # views, no copies
+    (2.0 * a).sum().backward(retain_graph=True)
+    ref = torch.zeros(5, 12)
+    ref[:, :4] = 2.0
+    assert torch.equal(x.grad, ref)
+    x.grad = None
+    ((a * 1.5).sum() + (c * c).sum()).backward()
+    ref = torch.zeros(5, 12)
+    ref[:, :4] = 1.5
+    ref[:, 6:] = 2.0 * x.detach()[:, 6:]
+    assert torch.allclose(x.grad, ref)
+    # without autograd: plain views
+    y = torch.randn(3, 6)
+    p, q = T.split_cols(y, [2, 4])
+    assert p.data_ptr() == y.data_ptr() and q.shape == (3, 4)
