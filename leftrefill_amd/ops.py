@@ -352,14 +352,14 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             _untabulated.add(key)
             import sys
             print(f"[leftrefill] untabulated GEMM shape {key} (taps {taps}, H {H}, W {W}, skip {skip is not None})", file=sys.stderr, flush=True)
-        if best is None and scale != 1:      # the static heuristic's answer for the scaled batch
+        if best is None and (scale != 1 or (HEURISTIC_REFINE and skip is None and not per_sample and not c16)):
+            # not in the table: the library's static heuristic for the (scaled) batch, refined by what the in-step tuning of round 6 found on
+            # every small-M shape (_refine_plan); a caller of the C ABI without this front end gets the unrefined heuristic
             a.B = B * scale
             if ln is not None or want_stats:
                 a.splits = 1                 # row statistics / the LayerNorm fold never split K -- like the unscaled plan below
-            plan = (ctypes.c_int32 * 4)()
-            lib.lr_gemm_plan(a, plan)
-            a.B, a.splits = B, 0
-            best = tuple(plan)
+            best = _refine_plan(lib, a, geglu or gelu) if HEURISTIC_REFINE and skip is None and not per_sample and not c16 else _lib_plan(lib, a)
+            a.B, a.splits, a.tile_m, a.tile_n, a.pipe = B, 0, 0, 0, 0
         if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             best = _tune_tiles(lib, a, x1.device, geglu, ln is not None or want_stats, want_stats)
             tile_cache()[key] = best
@@ -416,6 +416,37 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
     return (out, stats) if want_stats else out
 
 
+# untabulated shapes: refine the library's static plan (LEFTREFILL_HEURISTIC_REFINE=0: take it as is)
+HEURISTIC_REFINE = os.environ.get("LEFTREFILL_HEURISTIC_REFINE", "1") != "0"
+
+
+def _lib_plan(lib, a):
+    plan = (ctypes.c_int32 * 4)()
+    lib.lr_gemm_plan(a, plan)
+    return tuple(plan)
+
+
+def _refine_plan(lib, a, act_epilogue):
+    """The static heuristic's plan for `a`, with the two regularities of the in-step tuned table applied to 128-row tiles (round 6: with weights
+    streamed from HBM the 2-stage 4-wave kernel loses to the 4-stage ring on every shape whose tiles fit the chip in one round, and 160-column
+    tiles beat 128 where they divide N): tile_n 160 if N % 160 == 0, the 4-stage ring (pipe 4) if the tiles number <= 256.  A pure function of
+    the shape like the table."""
+    base = _lib_plan(lib, a)
+    tm, tn = base[0], base[1]
+    if tm != 128 or act_epilogue:
+        return base
+    M = a.B * a.H * a.W
+    if a.N % 160 == 0:
+        tn = 160
+    if tn not in (128, 160) or ((M + 127) // 128) * ((a.N + tn - 1) // tn) > 256:
+        return base
+    keep = (a.tile_m, a.tile_n, a.pipe)
+    a.tile_m, a.tile_n, a.pipe = 128, tn, 4
+    plan = _lib_plan(lib, a)                 # split-K factor of the refined tile
+    a.tile_m, a.tile_n, a.pipe = keep
+    return (128, tn, plan[2], 4)
+
+
 def gemm_plan(M, N, K, **kw):
     """(tile_m, tile_n, splits, pipe) lr_gemm_conv_f16 uses for a shape: the in-tree table, else the static heuristic."""
     best = tile_cache().get(tile_key(M, N, K, **kw))
@@ -425,9 +456,10 @@ def gemm_plan(M, N, K, **kw):
     a = GemmArgs()
     a.B, a.H, a.W, a.N, a.taps, a.C1 = 1, 1, M, N, kw.get("taps", 1), K // kw.get("taps", 1)
     a.geglu = int(kw.get("geglu", False))
-    plan = (ctypes.c_int32 * 4)()
-    _lib.check(lib.lr_gemm_plan(a, plan), "gemm_plan")
-    return tuple(plan)[:3] + (0,)
+    if kw.get("ln") or kw.get("stats"):
+        a.splits = 1
+    plan = _refine_plan(lib, a, bool(kw.get("geglu") or kw.get("gelu"))) if HEURISTIC_REFINE else _lib_plan(lib, a)
+    return tuple(plan)[:3] + (plan[3] if plan[3] in (4, 8) else 0,)
 
 
 def _workspace(lib, a, device):
