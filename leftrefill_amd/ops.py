@@ -433,9 +433,19 @@ def _refine_plan(lib, a, act_epilogue):
     the shape like the table."""
     base = _lib_plan(lib, a)
     tm, tn = base[0], base[1]
+    M = a.B * a.H * a.W
+    if (a.taps == 9 and a.stride == 1 and a.up == 0 and not a.asym and not act_epilogue and not a.ln_stats and not a.stats_out and a.W % 16 == 0
+            and a.H % 16 == 0 and a.Hs == a.H and a.Ws == a.W and a.N % 160 == 0 and M >= 8192 and (a.C1 + a.C2) % 64 == 0 and M < (1 << 28)):
+        # third regularity: the 3x3 stride-1 convs of the large levels run on the halo-tile instance (input patch resident in LDS) -- 320-column
+        # tiles where they still fill the chip
+        tn = 320 if a.N % 320 == 0 and ((M + 255) // 256) * (a.N // 320) >= 200 else 160
+        keep = (a.tile_m, a.tile_n, a.pipe)
+        a.tile_m, a.tile_n, a.pipe = 256, tn, 8
+        plan = _lib_plan(lib, a)
+        a.tile_m, a.tile_n, a.pipe = keep
+        return (256, tn, plan[2], 8)
     if tm != 128 or act_epilogue:
         return base
-    M = a.B * a.H * a.W
     if a.N % 160 == 0:
         tn = 160
     if tn not in (128, 160) or ((M + 127) // 128) * ((a.N + tn - 1) // tn) > 256:
