@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--workload", default="single", choices=["single", "mv5", "train"],
                     help="train: one eager training step of configs[4] (bf16, batch 16 at 256x512: forward + input-gradient backward); first phase only")
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--add-new", action="store_true", help="tabulate the shapes the table does not know (e.g. --batch 8)")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--splits", type=int, nargs="*", default=[], help="explicit split-K factors to try besides 1 and the heuristic's (e.g. 2 3 4 6 8)")
     ap.add_argument("--min-gain", type=float, default=0.03)
@@ -221,6 +222,15 @@ def main():
         ref, (tr, plan) = best_ref[k], best_trial[k]
         n = base[k][1]
         cur = tuple(table.get(k, ())) if k in table else None
+        if plan is not None and cur is None and a.add_new:
+            # a shape the table does not know (another batch size): tabulate the better of the refined heuristic's plan and the best trial
+            hp = canon(base[k][2]) if base[k][2] is not None else None
+            take = canon(plan) if (hp is None or (tr < ref * (1.0 - a.min_gain) and (ref - tr) / n >= 1.0)) else hp
+            print(f"{k}: new, heuristic {list(hp) if hp else None} {ref / n:7.1f} us, best trial {list(canon(plan))} {tr / n:7.1f} us  x{n} -> {list(take)}", flush=True)
+            table[k] = list(take)
+            if take != hp:
+                gain += ref - tr
+            continue
         if plan is None or cur is None:
             continue
         cur4 = tuple(cur) + ((0,) if len(cur) == 3 else ())
