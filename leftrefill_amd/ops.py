@@ -352,7 +352,7 @@ def gemm_conv(x1, wt, *, B, H, W, Hs=None, Ws=None, taps=1, stride=1, up=0, asym
             _untabulated.add(key)
             import sys
             print(f"[leftrefill] untabulated GEMM shape {key} (taps {taps}, H {H}, W {W}, skip {skip is not None})", file=sys.stderr, flush=True)
-        if best is None and (scale != 1 or (HEURISTIC_REFINE and skip is None and not per_sample and not c16)):
+        if best is None and (scale != 1 or (HEURISTIC_REFINE and not AUTOTUNE and skip is None and not per_sample and not c16)):
             # not in the table: the library's static heuristic for the (scaled) batch, refined by what the in-step tuning of round 6 found on
             # every small-M shape (_refine_plan); a caller of the C ABI without this front end gets the unrefined heuristic
             a.B = B * scale
