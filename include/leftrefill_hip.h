@@ -408,8 +408,12 @@ int lr_geglu_bwd(const lr_half* pre, const lr_half* dy, lr_half* dpre, int M, in
 int lr_geglu_fwd(const lr_half* pre, lr_half* out, int M, int H, lr_stream_t s);
 /* Attention: forward that also saves the log2-domain log-sum-exp (lse [B][heads][Nq] fp32), and the backward that
  * recomputes P from it (two deterministic kernels: dQ over key tiles; dK, dV over query tiles; plus D = rowsum(dO o O)).
- * qt / kt / dot / ld_qt / ld_kt: ignored since ABI 25 (rounds 2-5 took lr_transpose_v_f16 copies of q / k / dout there; the kernels now
- * gather the k-major operands from the natural tiles with the LDS transpose read); the fields keep the struct layout, pass NULL / 0.
+ * kt / dot / ld_kt: ignored since ABI 25 (rounds 2-5 took lr_transpose_v_f16 copies of q / k / dout in qt / kt / dot; the kernels now gather
+ * the k-major operands from the natural tiles with the LDS transpose read); the fields keep the struct layout, pass NULL / 0.
+ * qt / ld_qt (ABI 26): query split of the dK / dV kernel for few keys against many queries (the 77-key cross-attention of the 64 x 128
+ * level is ONE key block per (batch, head)): ld_qt = number of query slices (0 / 1 = none, <= 64), qt = fp32 workspace of
+ * ld_qt * B * heads * ceil(Nkv / 128) * 2 * 128 * 64 floats (16-byte aligned); the slices' partial dK / dV are summed in slice order by a
+ * second launch (deterministic).  NULL / 0 keep the single-slice kernel.
  * dsum: scratch [B][heads][Nq] fp32.  dq [B][Nq][lddq], dk / dv [B][Nkv][lddk | lddv], head h in columns h*64.. like q/k/v. */
 int lr_attention_lse_f16(const lr_half* q, int ldq, const lr_half* k, int ldk, const lr_half* v, int ldv, lr_half* o,
                          int ldo, float* lse, int B, int heads, int Nq, int Nkv, float scale, lr_stream_t s);

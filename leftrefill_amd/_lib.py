@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # LEFTREFILL_LIB_PATH: developer override (same-box A/B of two builds of the library)
 LIB_PATH = os.environ.get("LEFTREFILL_LIB_PATH") or os.path.join(HERE, "lib", "libleftrefill_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 

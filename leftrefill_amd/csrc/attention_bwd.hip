@@ -31,6 +31,7 @@ struct AttnBwdParams {
   const float* lse; float* dsum;                   // [B][heads][Nq]
   T* dq; T* dk; T* dv;
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, heads, Nq, Nkv, nblocks, ntile_blocks;
+  int q_splits; float* kv_ws;      // dK / dV kernel: query tiles split over q_splits blocks per key block, fp32 partials [split][bh][kblk][dk | dv][128][64]
   float c, scale;
 };
 
@@ -213,7 +214,9 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int kblk = blockIdx.x % P.ntile_blocks;
-  const int bh = blockIdx.x / P.ntile_blocks;
+  const int rest = blockIdx.x / P.ntile_blocks;
+  const int sp = rest % P.q_splits;      // this block's slice of the query tiles (q_splits = 1: all of them)
+  const int bh = rest / P.q_splits;
   const int h = bh % P.heads, b = bh / P.heads;
   const int ql = lane & 31, hi = lane >> 5;
   const T* zero = reinterpret_cast<const T*>(lr_zero_page);
@@ -238,7 +241,9 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
     for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  const int ntiles = (P.Nq + AB_TILE - 1) / AB_TILE;
+  const int ntiles_all = (P.Nq + AB_TILE - 1) / AB_TILE;
+  const int t_per = (ntiles_all + P.q_splits - 1) / P.q_splits;
+  const int t0 = sp * t_per, ntiles = min(ntiles_all, t0 + t_per);      // this block runs query tiles [t0, ntiles)
   auto stage = [&](int buf, int tile) {
     char* base = smem + buf * (4 * AB_TILE * 128);
     ab_stage_rows(base, qp, P.ldq, tile * AB_TILE, P.Nq, w, lane, zero);
@@ -251,11 +256,11 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
       else s_dsum[buf][i] = qi < P.Nq ? dsp[qi] : 0.f;
     }
   };
-  stage(0, 0);
+  if (t0 < ntiles) stage(0, t0);
   __syncthreads();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
+  for (int tile = t0; tile < ntiles; ++tile) {
+    const int cur = (tile - t0) & 1;
     if (tile + 1 < ntiles) stage(cur ^ 1, tile + 1);
     const char* Qs = smem + cur * (4 * AB_TILE * 128);
     const char* Gs = Qs + AB_TILE * 128;
@@ -300,6 +305,20 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
     __syncthreads();
   }
 
+  if (P.q_splits > 1) {      // fp32 partials of this query slice (unscaled dK), summed in a fixed order by attn_bwd_kv_reduce_kernel
+    const int nbh = gridDim.x / (P.q_splits * P.ntile_blocks);
+    float* wp = P.kv_ws + ((((size_t)sp * nbh + bh) * P.ntile_blocks + kblk) * 2) * (128 * 64) + (size_t)(w * 32 + ql) * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = {dk[db][g * 4], dk[db][g * 4 + 1], dk[db][g * 4 + 2], dk[db][g * 4 + 3]};
+        const f32x4 c2 = {dv[db][g * 4], dv[db][g * 4 + 1], dv[db][g * 4 + 2], dv[db][g * 4 + 3]};
+        *reinterpret_cast<f32x4*>(wp + db * 32 + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<f32x4*>(wp + 128 * 64 + db * 32 + 8 * g + 4 * hi) = c2;
+      }
+    return;
+  }
   if (krow < P.Nkv) {
     T* dkp = P.dk + ((size_t)b * P.Nkv + krow) * P.lddk + h * 64;
     T* dvp = P.dv + ((size_t)b * P.Nkv + krow) * P.lddv + h * 64;
@@ -314,6 +333,34 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_dkv_kernel(const AttnBwdP
         *reinterpret_cast<vec4<T>*>(dvp + db * 32 + 8 * g + 4 * hi) = c2;
       }
   }
+}
+
+// sum of the q_splits partial dK / dV tiles of a (batch, head, key block), splits in order: one thread per 4 consecutive d of a key
+template <typename T>
+__global__ void attn_bwd_kv_reduce_kernel(const AttnBwdParams<T> P, int nbh) {
+  const long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long total = (long long)nbh * P.ntile_blocks * 128 * 16;
+  if (id >= total) return;
+  const int d4 = (int)(id & 15) * 4;
+  const int key = (int)((id >> 4) & 127);
+  const long long tile = id >> 11;      // bh * ntile_blocks + kblk
+  const int kblk = (int)(tile % P.ntile_blocks);
+  const int bh = (int)(tile / P.ntile_blocks);
+  const int krow = kblk * 128 + key;
+  if (krow >= P.Nkv) return;
+  const size_t split_stride = (size_t)nbh * P.ntile_blocks * 2 * (128 * 64);
+  const float* src = P.kv_ws + (size_t)tile * 2 * (128 * 64) + (size_t)key * 64 + d4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, c2 = a;
+  for (int sidx = 0; sidx < P.q_splits; ++sidx) {
+    a += *reinterpret_cast<const f32x4*>(src + sidx * split_stride);
+    c2 += *reinterpret_cast<const f32x4*>(src + sidx * split_stride + 128 * 64);
+  }
+  const int h = bh % P.heads, b = bh / P.heads;
+  vec4<T> ka, va;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ka[i] = (T)(a[i] * P.scale); va[i] = (T)c2[i]; }
+  *reinterpret_cast<vec4<T>*>(P.dk + ((size_t)b * P.Nkv + krow) * P.lddk + h * 64 + d4) = ka;
+  *reinterpret_cast<vec4<T>*>(P.dv + ((size_t)b * P.Nkv + krow) * P.lddv + h * 64 + d4) = va;
 }
 
 template <typename T>
@@ -333,6 +380,8 @@ static int lr_attention_bwd_t(const lr_attn_bwd_args* a, lr_stream_t s) {
   P.heads = a->heads; P.Nq = a->Nq; P.Nkv = a->Nkv;
   P.scale = a->scale;
   P.c = a->scale * 1.44269504088896340736f;
+  P.q_splits = 1;
+  P.kv_ws = nullptr;
   hipStream_t st = (hipStream_t)s;
   int rc;
   P.ntile_blocks = (a->Nq + 127) / 128;
@@ -345,7 +394,18 @@ static int lr_attention_bwd_t(const lr_attn_bwd_args* a, lr_stream_t s) {
   if (lr_attr_needed(&attr_done)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_smem);
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(P.ntile_blocks * a->heads * a->B), dim3(AB_THREADS), dkv_smem, st, P);
+  // ABI 26: `qt` / `ld_qt` of the argument struct carry the query split of this kernel (few key blocks against many queries -- the 77-key
+  // cross-attention of the 64 x 128 level is 1 key block per (batch, head): 80 blocks for 256 CUs): ld_qt = number of query slices (0 / 1 =
+  // none), qt = fp32 workspace of ld_qt * B * heads * ceil(Nkv / 128) * 2 * 128 * 64 floats
+  P.q_splits = a->ld_qt > 1 && a->qt ? a->ld_qt : 1;
+  P.kv_ws = P.q_splits > 1 ? (float*)const_cast<lr_half*>(a->qt) : nullptr;
+  if (P.q_splits > 64 || (P.kv_ws && ((uintptr_t)P.kv_ws & 15))) return LR_E_ARG;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(P.ntile_blocks * P.q_splits * a->heads * a->B), dim3(AB_THREADS), dkv_smem, st, P);
+  rc = lr_launch_status();
+  if (rc || P.q_splits == 1) return rc;
+  const int nbh = a->heads * a->B;
+  const long long total = (long long)nbh * P.ntile_blocks * 128 * 16;
+  hipLaunchKernelGGL(attn_bwd_kv_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, nbh);
   return lr_launch_status();
 }
 

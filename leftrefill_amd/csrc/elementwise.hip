@@ -238,7 +238,7 @@ static inline int grid_for(long long total, int block, int cap = 4096) {
   return (int)g;
 }
 
-extern "C" int lr_abi_version(void) { return 25; }
+extern "C" int lr_abi_version(void) { return 26; }
 
 #ifdef LR_DEV_VARIANTS
 // developer build only: name -> value table behind LR_DEV (common.h); set through lr_dev_set by the Python front end

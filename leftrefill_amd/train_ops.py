@@ -348,6 +348,20 @@ def nhwc_to_nchw(y, N, H, W, C, out_dtype=None):
     return _ToNCHW.apply(y, N, H, W, C, out_dtype)
 
 
+ATTN_BWD_QSPLIT = __import__("os").environ.get("LEFTREFILL_ATTN_BWD_QSPLIT", "1") != "0"
+
+
+def attn_bwd_q_splits(B, heads, Nq, Nkv):
+    """Query slices of the dK / dV kernel (lr_attn_bwd_args.ld_qt): 1 unless its (batch, head, key block) grid leaves most of the 256 CUs
+    idle while every block walks >= 8 query tiles -- then enough slices to fill the chip once, at least 4 tiles each.  A pure function of
+    the shape (the sum order of the slices is fixed)."""
+    blocks = B * heads * ((Nkv + 127) // 128)
+    tiles = (Nq + 63) // 64
+    if not ATTN_BWD_QSPLIT or blocks > 128 or tiles < 8:
+        return 1
+    return max(1, min(256 // blocks, tiles // 4, 64))
+
+
 def _attention_backward(q, k, v, out, lse, dout, meta, dq, dk, dv):
     """dq / dk / dv: pre-allocated (possibly strided column-slice) outputs."""
     lib = _lib.load()
@@ -357,9 +371,13 @@ def _attention_backward(q, k, v, out, lse, dout, meta, dq, dk, dv):
     a = AttnBwdArgs()
     a.q, a.k, a.v, a.o, a.dout = _p(q), _p(k), _p(v), _p(out), _p(dout)
     a.qt, a.kt, a.dot, a.lse, a.dsum = 0, 0, 0, _p(lse), _p(dsum)       # (no transposed copies since ABI 25: LDS transpose reads)
+    qs, ws = attn_bwd_q_splits(B, heads, Nq, Nkv), None
+    if qs > 1:      # few key blocks against many queries (the level-0 cross-attention): the dK / dV kernel's query tiles split over more blocks
+        ws = torch.empty(qs * B * heads * ((Nkv + 127) // 128) * 2 * 128 * 64, device=q.device, dtype=torch.float32)
+        a.qt = _p(ws)
     a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
     a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
-    a.ld_qt, a.ld_kt = 0, 0
+    a.ld_qt, a.ld_kt = (qs if qs > 1 else 0), 0
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.B, a.heads, a.Nq, a.Nkv, a.scale = B, heads, Nq, Nkv, scale
     _lib.check(_lib.fn(lib, "lr_attention_bwd_f16", q.dtype)(a, _stream()), "attention_bwd")

@@ -255,7 +255,7 @@ def test_geglu_backward():
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nkv", [(1, 1, 64, 64), (2, 2, 128, 128), (1, 3, 300, 200), (2, 5, 256, 77), (1, 2, 512, 1024),
-                                            (1, 2, 2048, 2048)])
+                                            (1, 2, 2048, 2048), (2, 5, 2048, 77), (1, 2, 1000, 200)])      # (the last two: query-split dK / dV)
 def test_attention_backward(B, heads, Nq, Nkv):
     """dQ, dK, dV of softmax(q k^T / 8) v per head vs torch.autograd on the fp32 formulation; q / k / v are strided column
     slices of one fused buffer like in the UNet; the forward output of the lse-saving kernel must equal the plain one."""
